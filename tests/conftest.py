@@ -1,0 +1,37 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+def load_golden(name):
+    with np.load(os.path.join(GOLDEN, name + '.npz')) as z:
+        return {k: z[k] for k in z.files}
+
+
+def golden_flow(fx, d, n_layers=2, n_hidden=None, cond_layers=2):
+    """Rebuild the oracle (CPU) flow a fixture was generated with."""
+    from oracle import flow as oflow
+    ck = {'n_layers': cond_layers}
+    if n_hidden is not None:
+        ck['n_hidden'] = n_hidden
+    f = oflow.Flow(oflow.RealNVP((d,), n_layers=n_layers, conditioner_kwargs=ck))
+    sd = {k[len('flow/'):]: torch.from_numpy(v) for k, v in fx.items() if k.startswith('flow/')}
+    f.load_state_dict(sd)
+    return f
+
+
+@pytest.fixture
+def golden():
+    return load_golden
