@@ -1,0 +1,263 @@
+/*
+ * nfmc_hip.h -- C ABI of libnfmc_hip.so: the MI355X (gfx950) implementation of the nfmc hot path.
+ *
+ * The reference (davidnabergoj/nfmc) is pure Python on PyTorch and has no FFI; its two seams for
+ * this path are `MCMCSampler.propose` (nfmc/algorithms/sampling/mcmc/base.py:27-34) and the
+ * torchflows `Flow` methods called at jump.py:205,218, imh.py:214,221, neutra.py:60.  Each entry
+ * point below names the reference code it replaces.  INTEGRATION.md shows the ctypes binding a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   ownership   every pointer is a BORROWED device allocation (e.g. torch tensor.data_ptr());
+ *               the library never allocates or frees user-visible memory; scratch is caller-supplied.
+ *   layout      row-major contiguous fp32 `(n, d)` state, `(n,)` per-chain vectors, u8 masks.
+ *   errors      return 0 on success; negative = argument error (NFMC_E*); positive = hipError_t.
+ *               No C++ exception crosses the boundary.
+ *   async       every call only enqueues work on `stream` (a hipStream_t) and returns; re-entrant,
+ *               no global mutable state.
+ *   rng         native mode: Philox4x32-10 keyed by `seed`, counter (chain id, transition, block, stream)
+ *               -- spec in oracle/philox.py; replay mode: caller-supplied normals/uniforms
+ *               (non-NULL replay pointers), used for parity tests against the reference's noise.
+ */
+#ifndef NFMC_HIP_H
+#define NFMC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* nfmc_stream_t; /* hipStream_t */
+
+#define NFMC_ABI_VERSION 1
+
+enum {
+    NFMC_OK = 0,
+    NFMC_EINVAL = -1,       /* NULL pointer / non-positive size */
+    NFMC_ESHAPE = -2,       /* shape outside what the kernels support (see nfmc_limits) */
+    NFMC_EALIGN = -3,       /* pointer not aligned as required (state rows: 4 B; 16 B enables vector IO) */
+    NFMC_EUNSUPPORTED = -4, /* valid request with no kernel instantiation (e.g. unknown potential kind) */
+    NFMC_ESCRATCH = -5      /* scratch buffer too small: see nfmc_stats_scratch_bytes */
+};
+
+/* ---- closed-form potentials U(x) (negative log density), evaluated with their gradient in-kernel.
+ * Replaces `self.target(x)` + `torch.autograd.grad` (langevin.py:66-68,80-82; hmc.py:40-48). */
+enum {
+    NFMC_POT_QUADRATIC = 0, /* U = sum_j a_j (x_j - b_j)^2 ; a,b per coordinate or scalar */
+    NFMC_POT_FUNNEL = 1     /* U = x_0^2/(2 s^2) + sum_{i>=1} [x_i^2 / (2 e^{x_0}) + x_0/2], s = a_scalar */
+};
+
+typedef struct {
+    int32_t kind;
+    int32_t reserved;
+    const float* a; /* (d,) or NULL -> a_scalar */
+    const float* b; /* (d,) or NULL -> b_scalar */
+    float a_scalar;
+    float b_scalar;
+} NfmcPotential;
+
+typedef struct {
+    uint64_t seed;
+    uint64_t chain_offset;        /* global id of row 0 (chains sharded over GPUs keep global ids) */
+    uint32_t step0;               /* transition index of the first step of this call */
+    uint32_t reserved;
+    const float* replay_normals;  /* NULL -> native Philox; else (n_steps, n, d) */
+    const float* replay_uniforms; /* NULL -> native Philox; else (n_steps, n)     */
+} NfmcRng;
+
+/* Streaming statistics, all ACCUMULATED (+=) by the kernels.  Replaces
+ * `MCMCExpectation.update` for f = x, x^2 and the counters of `MCMCStatistics`
+ * (nfmc/algorithms/sampling/base.py:75-95,126-161; mcmc/base.py:79-86). */
+enum { NFMC_CNT_ACCEPTED = 0, NFMC_CNT_ATTEMPTED = 1, NFMC_CNT_NONFINITE = 2, NFMC_CNT_WORDS = 4 };
+
+typedef struct {
+    double* sum_x;                /* (d,)  += sum over steps and chains of x     (NULL: statistics off) */
+    double* sum_x2;               /* (d,)  += ... of x^2 */
+    unsigned long long* counters; /* (NFMC_CNT_WORDS,) */
+    double* scratch;              /* per-workgroup partials, >= nfmc_stats_scratch_bytes(d) bytes */
+    int64_t scratch_bytes;
+} NfmcStats;
+
+int64_t nfmc_stats_scratch_bytes(int32_t d);
+
+/* ---- K1 (+K6, K7): n_steps fused Langevin transitions.
+ * Replaces `Langevin.propose` + the masked update + counters + moments of `MCMCSampler.sample`
+ * (langevin.py:61-122; mcmc/base.py:74-90). */
+typedef struct {
+    float* x;                   /* (n, d) in/out */
+    int64_t n;
+    int32_t d;
+    int32_t n_steps;            /* 1..NFMC_MAX_STEPS_PER_CALL */
+    float step_size;
+    int32_t adjust;             /* 1 = MALA, 0 = ULA */
+    const float* inv_mass_diag; /* (d,) or NULL = ones (mcmc/base.py:113-116) */
+    NfmcPotential pot;
+    NfmcRng rng;
+    NfmcStats stats;
+    float* samples;             /* NULL or (n_steps, n, d): state after every step (MCMCSamples.add) */
+    uint8_t* masks_out;         /* NULL or (n_steps, n) accept masks (tests / split path) */
+    float* log_ratio_out;       /* NULL or (n_steps, n) */
+} NfmcMalaArgs;
+
+int nfmc_mala_steps_f32(const NfmcMalaArgs* args, nfmc_stream_t stream);
+
+/* ---- K2: n_steps fused HMC trajectories.  Replaces `HMC.propose`/`hmc_trajectory` (hmc.py:61-126). */
+typedef struct {
+    float* x;
+    int64_t n;
+    int32_t d;
+    int32_t n_steps;
+    float step_size;
+    int32_t n_leapfrog;
+    int32_t adjust;             /* 1 = HMC, 0 = UHMC */
+    int32_t reserved;
+    const float* inv_mass_diag;
+    NfmcPotential pot;
+    NfmcRng rng;
+    NfmcStats stats;
+    float* samples;
+    uint8_t* masks_out;
+    float* log_ratio_out;
+} NfmcHmcArgs;
+
+int nfmc_hmc_steps_f32(const NfmcHmcArgs* args, nfmc_stream_t stream);
+
+/* ---- RealNVP (the build's spec: DESIGN.md "RealNVP spec"; stands in for torchflows.RealNVP,
+ * call sites nfmc/util.py:280-281). */
+typedef struct {
+    int32_t d;                /* flattened event size */
+    int32_t n_coupling;       /* number of (ReversePermutation, AffineCoupling) pairs */
+    int32_t n_hidden;         /* H */
+    int32_t n_hidden_layers;  /* conditioner hidden layers (>= 1) */
+    float min_scale;          /* m in alpha = exp(u/2 + log(1-m)) + m */
+    int32_t reserved;
+    const float* ea0_log_scale; /* (d,) first ElementwiseAffine */
+    const float* ea0_shift;
+    const float* ea1_log_scale; /* (d,) last ElementwiseAffine */
+    const float* ea1_shift;
+    const float* weights;     /* per coupling layer (logical, un-permuted coordinates), HP = padded H:
+                                 W1T (d_a, HP) | b1 (HP) | [WhT (HP_in, HP_out) | bh (HP)] x (n_hidden_layers-1)
+                                 | W3 (2 d_b, HP) | b3 (2 d_b);  W1T/WhT are the TRANSPOSES of the PyTorch Linear
+                                 weights (in, out), W3 keeps (out, in); rows [0, d_b) of W3 give u_alpha, rows
+                                 [d_b, 2 d_b) give u_beta; d_a = d/2, d_b = d - d_a */
+    int64_t layer_stride;     /* floats between consecutive coupling layers */
+} NfmcRealNVP;
+
+/* HP: n_hidden padded to the kernels' width (4, 8, 16, 32, then multiples of 32); padding is zero-filled. */
+int32_t nfmc_realnvp_padded_hidden(int32_t n_hidden);
+int64_t nfmc_realnvp_layer_floats(int32_t d, int32_t n_hidden, int32_t n_hidden_layers);
+
+/* K4: x -> z, logdet_forward; log_prob = N(z;0,I) + logdet (either output may be NULL).
+ * Replaces `bijection.forward` / `Flow.log_prob` (jump.py:218, imh.py:214). */
+int nfmc_realnvp_forward_f32(const NfmcRealNVP* flow, const float* x, int64_t n, float* z, float* logdet,
+                             float* log_prob, nfmc_stream_t stream);
+
+/* K3: z -> x, logdet_inverse; z == NULL draws z ~ N(0,I) from `rng` (stream 2); log_q = log q(x).
+ * Replaces `bijection.inverse` / `Flow.sample(n, return_log_prob=True)` (jump.py:205, imh.py:221, neutra.py:60). */
+int nfmc_realnvp_inverse_f32(const NfmcRealNVP* flow, const float* z, int64_t n, float* x, float* logdet,
+                             float* log_q, const NfmcRng* rng, nfmc_stream_t stream);
+
+/* ---- K3+K4+K6+K7 fused: n_steps independent-MH transitions with the flow as proposal.
+ * n_steps = 1, logq_cached = 0 is the jump of `JumpNFMC.sample` (jump.py:205-243);
+ * n_steps = K with the cached log q(x) is `FixedIMH.sample` (imh.py:214-249). */
+typedef struct {
+    float* x;                 /* (n, d) in/out */
+    float* logq;              /* (n,) cached log q(x): read if logq_cached, always written */
+    int64_t n;
+    int32_t n_steps;
+    int32_t logq_cached;
+    int32_t adjusted;         /* 0: accept every proposal (adjusted_jumps=False, jump.py:228-229) */
+    int32_t reserved;
+    NfmcRealNVP flow;
+    NfmcPotential pot;
+    NfmcRng rng;              /* replay_normals are the latents z (n_steps, n, d) */
+    NfmcStats stats;          /* counters use the ACCEPTED/ATTEMPTED words */
+    float* samples;
+    uint8_t* masks_out;
+    float* log_ratio_out;
+} NfmcFlowMhArgs;
+
+int nfmc_flow_mh_steps_f32(const NfmcFlowMhArgs* args, nfmc_stream_t stream);
+
+/* ---- K5 + K2: HMC in latent space on U~(z) = U(f^-1(z)) - logdet_inv(z), gradient by a hand-written
+ * VJP through the coupling stack.  Replaces `NeuTra.adjusted_target` under `HMC.propose`
+ * (neutra.py:58-68,109-129; hmc.py:40-48,96-126). */
+typedef struct {
+    float* z;                 /* (n, d) latent state in/out */
+    int64_t n;
+    int32_t n_steps;
+    int32_t n_leapfrog;
+    float step_size;
+    int32_t adjust;
+    const float* inv_mass_diag;
+    NfmcRealNVP flow;
+    NfmcPotential pot;
+    NfmcRng rng;
+    NfmcStats stats;          /* moments of the latent z (reference quirk) */
+    float* samples;
+    uint8_t* masks_out;
+    float* log_ratio_out;
+} NfmcNeutraHmcArgs;
+
+int nfmc_neutra_hmc_steps_f32(const NfmcNeutraHmcArgs* args, nfmc_stream_t stream);
+
+/* Adjusted potential and its gradient alone (tests; split path). */
+int nfmc_neutra_potential_grad_f32(const NfmcRealNVP* flow, const NfmcPotential* pot, const float* z, int64_t n,
+                                   float* u_out, float* grad_out, nfmc_stream_t stream);
+
+/* ---- split path for arbitrary Python targets (U and grad U come from torch autograd on the GPU).
+ * K6: mask = log(u) < lp_t' - lp_t + lp_q - lp_q' (nfmc/util.py:382-392), x[mask] = x'[mask]
+ * (mcmc/base.py:77), optional carried per-chain scalars, counters. */
+typedef struct {
+    float* x;                 /* (n, d) in/out */
+    const float* x_prime;     /* (n, d) */
+    int64_t n;
+    int32_t d;
+    int32_t n_carry;          /* 0..2 per-chain vectors selected with the same mask (imh.py:233) */
+    const float* log_ratio;   /* (n,) or NULL = accept all */
+    const float* uniforms;    /* (n,) replay uniforms or NULL -> Philox stream `rng_tag` */
+    float* carry[2];
+    const float* carry_prime[2];
+    NfmcRng rng;
+    int32_t rng_tag;          /* 1 = accept stream, 3 = jump stream */
+    int32_t reserved;
+    NfmcStats stats;          /* moments of the post-selection x + counters */
+    uint8_t* mask_out;
+} NfmcSelectArgs;
+
+int nfmc_mh_accept_select_f32(const NfmcSelectArgs* args, nfmc_stream_t stream);
+
+/* Langevin proposal and log acceptance ratio from externally computed U, grad U
+ * (langevin.py:74-76 and :31-42,88-105). */
+int nfmc_langevin_propose_f32(const float* x, const float* grad_u, const float* inv_mass_diag, float step_size,
+                              int64_t n, int32_t d, const NfmcRng* rng, float* x_prime, nfmc_stream_t stream);
+int nfmc_langevin_log_ratio_f32(const float* x, const float* x_prime, const float* u, const float* u_prime,
+                                const float* grad_u, const float* grad_u_prime, const float* inv_mass_diag,
+                                float step_size, int64_t n, int32_t d, float* log_ratio, nfmc_stream_t stream);
+
+/* K7 alone: sum_x += sum_rows x, sum_x2 += sum_rows x^2 over a (rows, d) block. */
+int nfmc_moments_update_f32(const float* x, int64_t rows, int32_t d, const NfmcStats* stats, nfmc_stream_t stream);
+
+/* Philox normals / uniforms alone (tests pin the native stream against oracle/philox.py). */
+int nfmc_philox_normals_f32(const NfmcRng* rng, int32_t tag, int64_t n, int32_t d, float* out, nfmc_stream_t stream);
+int nfmc_philox_uniforms_f32(const NfmcRng* rng, int32_t tag, int64_t n, float* out, nfmc_stream_t stream);
+
+/* ---- introspection */
+#define NFMC_MAX_STEPS_PER_CALL 512
+typedef struct {
+    int32_t abi_version;
+    int32_t max_d_sampler;   /* largest d for nfmc_mala/hmc_steps */
+    int32_t max_d_flow;      /* largest d for the RealNVP kernels */
+    int32_t max_hidden_valu; /* H up to which the VALU conditioner path is used */
+    int32_t max_hidden;      /* largest H (MFMA path) */
+    int32_t max_steps_per_call;
+} NfmcLimits;
+
+int nfmc_limits(NfmcLimits* out);
+const char* nfmc_error_string(int code);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NFMC_HIP_H */

@@ -1,0 +1,77 @@
+"""Builds nfmc_amd/libnfmc_hip.so (the C-ABI library of include/nfmc_hip.h) with hipcc for gfx950.
+
+    python -m nfmc_amd.build [--force]
+
+hipcc cross-compiles without a GPU, so this runs in the build container; the resulting .so travels
+with the tree to the GPU box.  Translation units are compiled in parallel and linked once.
+"""
+import concurrent.futures
+import hashlib
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, 'csrc')
+INCLUDE = os.path.join(ROOT, 'include')
+OBJ = os.path.join(CSRC, 'build')
+LIB = os.path.join(HERE, 'libnfmc_hip.so')
+
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+FLAGS = ['-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-I' + INCLUDE, '-I' + CSRC,
+         '-Wno-unused-result']
+
+
+def sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith('.hip'))
+
+
+def _digest():
+    h = hashlib.sha256()
+    for root in (CSRC, INCLUDE):
+        for f in sorted(os.listdir(root)):
+            p = os.path.join(root, f)
+            if os.path.isfile(p) and f.endswith(('.hip', '.hpp', '.h')):
+                h.update(f.encode())
+                with open(p, 'rb') as fh:
+                    h.update(fh.read())
+    h.update(' '.join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def _compile(src):
+    obj = os.path.join(OBJ, src[:-4] + '.o')
+    cmd = [HIPCC] + FLAGS + ['-c', os.path.join(CSRC, src), '-o', obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError('hipcc failed for %s:\n%s' % (src, r.stderr[-4000:]))
+    return obj
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    stamp = os.path.join(OBJ, 'digest.txt')
+    dig = _digest()
+    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == dig:
+        return LIB
+    if not os.path.exists(HIPCC):
+        raise RuntimeError('hipcc not found at %s; cannot build libnfmc_hip.so' % HIPCC)
+    srcs = sources()
+    if verbose:
+        print('[nfmc_amd.build] compiling %d translation units for gfx950' % len(srcs), flush=True)
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        objs = list(ex.map(_compile, srcs))
+    cmd = [HIPCC, '-shared', '-fPIC', '--offload-arch=gfx950', '-o', LIB] + objs
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError('link failed:\n' + r.stderr[-4000:])
+    with open(stamp, 'w') as fh:
+        fh.write(dig)
+    if verbose:
+        print('[nfmc_amd.build] wrote', LIB, flush=True)
+    return LIB
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)

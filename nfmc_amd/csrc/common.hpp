@@ -1,0 +1,281 @@
+// Shared device helpers for the nfmc gfx950 kernels: Philox4x32-10, Box-Muller on the hardware
+// transcendentals, chain-group reductions, closed-form potentials, deterministic statistics.
+// gfx950 only: wave = 64 lanes, no portability layer.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "nfmc_hip.h"
+
+namespace nfmc {
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;          // 4 waves per workgroup
+constexpr int kWavesPerBlock = kBlock / kWave;
+constexpr int kMaxGrid = 2048;       // 256 CUs x 8 workgroups; larger problems grid-stride
+constexpr int kStatTail = 4;         // per-workgroup scratch tail: accepted, nonfinite, 2 spare
+
+// RNG stream tags (oracle/philox.py)
+constexpr uint32_t kTagNoise = 0, kTagAccept = 1, kTagLatent = 2, kTagJump = 3;
+
+// ------------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al. SC'11).  The key schedule is wave-uniform, so the compiler keeps the
+// ten round keys in SGPRs; the 32x32->64 products become v_mad_u64_u32.
+__device__ __forceinline__ uint4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                                uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1;
+        c3 = (uint32_t)p0;
+        c0 = n0;
+        c2 = n2;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return make_uint4(c0, c1, c2, c3);
+}
+
+// (0,1) uniform with 23 random bits, exact in fp32: (2 (r >> 9) + 1) 2^-24.
+__device__ __forceinline__ float u32_to_uniform(uint32_t r) {
+    return (float)(2u * (r >> 9) + 1u) * 0x1p-24f;
+}
+
+// Two standard normals from two words.  v_log_f32 is log2, v_cos/v_sin take revolutions, so
+// R = sqrt(-2 ln2 log2 u1), angle = u2 -- no 2 pi multiply and no range reduction.
+__device__ __forceinline__ void box_muller(uint32_t ra, uint32_t rb, float& za, float& zb) {
+    const float u1 = fmaf((float)ra, 0x1p-32f, 0x1p-33f);
+    const float u2 = (float)rb * 0x1p-32f;
+    const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
+    za = rad * __builtin_amdgcn_cosf(u2);
+    zb = rad * __builtin_amdgcn_sinf(u2);
+}
+
+// Four normals for coordinate block `blk` of (chain, step) on stream `tag`.
+__device__ __forceinline__ void philox_normal4(uint32_t chain, uint32_t step, uint32_t blk, uint32_t tag, uint32_t k0,
+                                               uint32_t k1, float (&z)[4]) {
+    const uint4 r = philox4x32_10(chain, step, blk, tag, k0, k1);
+    box_muller(r.x, r.y, z[0], z[1]);
+    box_muller(r.z, r.w, z[2], z[3]);
+}
+
+__device__ __forceinline__ uint32_t pick_word(const uint4& r, uint32_t i) {
+    return i == 0 ? r.x : (i == 1 ? r.y : (i == 2 ? r.z : r.w));
+}
+
+// natural log on v_log_f32 (log2): |err| <~ 1 ulp of log2 -- used for the Metropolis test log(u).
+__device__ __forceinline__ float fast_ln(float v) { return 0.6931471805599453f * __builtin_amdgcn_logf(v); }
+__device__ __forceinline__ float fast_exp(float v) { return __builtin_amdgcn_exp2f(1.4426950408889634f * v); }
+
+// ------------------------------------------------------------------------------------------------
+// Butterfly all-reduce over the LPC consecutive lanes that share one chain.  fp add is commutative,
+// so every lane of the group ends with the bitwise same sum: the accept decision needs no broadcast.
+template <int LPC>
+__device__ __forceinline__ float group_allreduce(float v) {
+#pragma unroll
+    for (int m = 1; m < LPC; m <<= 1) v += __shfl_xor(v, m, kWave);
+    return v;
+}
+
+template <int LPC>
+__device__ __forceinline__ float group_broadcast0(float v) {
+    // value held by the group's first lane
+    return __shfl(v, (int)(threadIdx.x & 63) & ~(LPC - 1), kWave);
+}
+
+// Sum over the lanes of a wave that hold the SAME coordinates of DIFFERENT chains (stride LPC).
+template <int LPC>
+__device__ __forceinline__ double cross_chain_reduce(double v) {
+#pragma unroll
+    for (int m = LPC; m < kWave; m <<= 1) v += __shfl_xor(v, m, kWave);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Potentials.  `term` is the coordinate's share of U (U = group sum of terms), `grad` dU/dx_c.
+// Coordinates beyond d carry a = 0 / x = 0 so they contribute exactly zero.
+template <int CPL, int LPC, bool FAST>
+struct QuadraticPot {
+    // U = sum a_c (x_c - b_c)^2
+    float a_s, b_s;
+    float a[FAST ? 1 : CPL], b[FAST ? 1 : CPL];
+    struct Ctx {};
+
+    __device__ __forceinline__ void init(const NfmcPotential& p, int g, int d) {
+        a_s = p.a_scalar;
+        b_s = p.b_scalar;
+        if constexpr (!FAST) {
+#pragma unroll
+            for (int i = 0; i < CPL; ++i) {
+                const int c = g * CPL + i;
+                const bool ok = c < d;
+                a[i] = ok ? (p.a ? p.a[c] : p.a_scalar) : 0.f;
+                b[i] = ok ? (p.b ? p.b[c] : p.b_scalar) : 0.f;
+            }
+        }
+    }
+    __device__ __forceinline__ Ctx prepare(const float (&)[CPL], int, int) const { return Ctx{}; }
+    __device__ __forceinline__ float aa(int i) const { return FAST ? a_s : a[FAST ? 0 : i]; }
+    __device__ __forceinline__ float bb(int i) const { return FAST ? b_s : b[FAST ? 0 : i]; }
+    __device__ __forceinline__ float grad(const Ctx&, int i, float x) const { return 2.f * aa(i) * (x - bb(i)); }
+    __device__ __forceinline__ float term(const Ctx&, int i, float x) const {
+        const float t = x - bb(i);
+        return aa(i) * t * t;
+    }
+};
+
+template <int CPL, int LPC, bool FAST>
+struct FunnelPot {
+    // U = x0^2/(2 s^2) + sum_{i>=1} [ x_i^2 e^{-x0} / 2 + x0 / 2 ]
+    float inv_s2, half_dm1;
+    bool lead;          // this lane holds coordinate 0 in register 0
+    float valid[CPL];   // 1 for real coordinates, 0 for padding
+    struct Ctx {
+        float x0, e, s;  // x_0, exp(-x_0), sum_{i>=1} x_i^2
+    };
+
+    __device__ __forceinline__ void init(const NfmcPotential& p, int g, int d) {
+        inv_s2 = 1.f / (p.a_scalar * p.a_scalar);
+        half_dm1 = 0.5f * (float)(d - 1);
+        lead = (g == 0);
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) valid[i] = (g * CPL + i) < d ? 1.f : 0.f;
+    }
+    __device__ __forceinline__ Ctx prepare(const float (&x)[CPL], int, int) const {
+        Ctx c;
+        c.x0 = group_broadcast0<LPC>(x[0]);
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) s = fmaf(x[i], (lead && i == 0) ? 0.f : x[i], s);
+        c.s = group_allreduce<LPC>(s);
+        c.e = fast_exp(-c.x0);
+        return c;
+    }
+    __device__ __forceinline__ float grad(const Ctx& c, int i, float x) const {
+        const float g0 = c.x0 * inv_s2 - 0.5f * c.e * c.s + half_dm1;
+        return (lead && i == 0) ? g0 : x * c.e * valid[i];
+    }
+    __device__ __forceinline__ float term(const Ctx& c, int i, float x) const {
+        const float t0 = 0.5f * c.x0 * c.x0 * inv_s2 + half_dm1 * c.x0;
+        return (lead && i == 0) ? t0 : 0.5f * c.e * x * x;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Row IO for the blocked layout: lane g of a chain group holds coordinates g*CPL .. g*CPL+CPL-1.
+template <int CPL, bool VEC>
+__device__ __forceinline__ void load_row(const float* __restrict__ base, int64_t row, int d, int g, bool active,
+                                         float (&x)[CPL]) {
+    if constexpr (VEC) {
+        const float4* p = reinterpret_cast<const float4*>(base + row * d + g * CPL);
+#pragma unroll
+        for (int i = 0; i < CPL / 4; ++i) {
+            float4 v = active ? p[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            x[4 * i] = v.x;
+            x[4 * i + 1] = v.y;
+            x[4 * i + 2] = v.z;
+            x[4 * i + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            const int c = g * CPL + i;
+            x[i] = (active && c < d) ? base[row * d + c] : 0.f;
+        }
+    }
+}
+
+template <int CPL, bool VEC>
+__device__ __forceinline__ void store_row(float* __restrict__ base, int64_t row, int d, int g, bool active,
+                                          const float (&x)[CPL]) {
+    if constexpr (VEC) {
+        if (active) {
+            float4* p = reinterpret_cast<float4*>(base + row * d + g * CPL);
+#pragma unroll
+            for (int i = 0; i < CPL / 4; ++i) p[i] = make_float4(x[4 * i], x[4 * i + 1], x[4 * i + 2], x[4 * i + 3]);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            const int c = g * CPL + i;
+            if (active && c < d) base[row * d + c] = x[i];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Deterministic statistics.  Each lane carries fp32 partial sums over the <= 512 steps of one call;
+// they are widened to fp64, reduced over the chains of the wave by shuffles, over the waves of the
+// workgroup through LDS, written to the workgroup's slot of the scratch slab, and a second tiny
+// kernel folds the slab into the accumulators in a fixed order (no atomics: run-to-run bitwise equal).
+template <int CPL, int LPC>
+__device__ __forceinline__ void block_stats_flush(const float (&sx)[CPL], const float (&sxx)[CPL], uint32_t accepted,
+                                                  uint32_t nonfinite, double* __restrict__ scratch) {
+    constexpr int DP = CPL * LPC;
+    __shared__ double red[kWavesPerBlock][2 * DP + kStatTail];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane % LPC;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        const double a = cross_chain_reduce<LPC>((double)sx[i]);
+        const double b = cross_chain_reduce<LPC>((double)sxx[i]);
+        if (lane < LPC) {
+            red[wave][g * CPL + i] = a;
+            red[wave][DP + g * CPL + i] = b;
+        }
+    }
+    if (lane == 0) {
+        red[wave][2 * DP + 0] = (double)accepted;
+        red[wave][2 * DP + 1] = (double)nonfinite;
+        red[wave][2 * DP + 2] = 0.0;
+        red[wave][2 * DP + 3] = 0.0;
+    }
+    __syncthreads();
+    double* out = scratch + (size_t)blockIdx.x * (2 * DP + kStatTail);
+    for (int t = threadIdx.x; t < 2 * DP + kStatTail; t += kBlock) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < kWavesPerBlock; ++w) s += red[w][t];
+        out[t] = s;
+    }
+}
+
+// scratch (nblocks, 2*dp + kStatTail) -> stats (+=); one workgroup.
+static __global__ void stats_finish_kernel(const double* __restrict__ scratch, int nblocks, int dp, int d, NfmcStats st,
+                                    unsigned long long attempted) {
+    const int width = 2 * dp + kStatTail;
+    for (int t = threadIdx.x; t < width; t += blockDim.x) {
+        double s = 0.0;
+        for (int b = 0; b < nblocks; ++b) s += scratch[(size_t)b * width + t];
+        if (t < dp) {
+            if (t < d) st.sum_x[t] += s;
+        } else if (t < 2 * dp) {
+            if (t - dp < d) st.sum_x2[t - dp] += s;
+        } else if (t == 2 * dp) {
+            st.counters[NFMC_CNT_ACCEPTED] += (unsigned long long)(s + 0.5);
+            st.counters[NFMC_CNT_ATTEMPTED] += attempted;
+        } else if (t == 2 * dp + 1) {
+            st.counters[NFMC_CNT_NONFINITE] += (unsigned long long)(s + 0.5);
+        }
+    }
+}
+
+inline int64_t stats_scratch_doubles(int dp) { return (int64_t)kMaxGrid * (2 * dp + kStatTail); }
+
+inline int padded_d(int d) {
+    int p = 4;
+    while (p < d) p <<= 1;
+    return p;
+}
+
+#define NFMC_HIP_CHECK_LAUNCH()                \
+    do {                                       \
+        hipError_t e_ = hipGetLastError();     \
+        if (e_ != hipSuccess) return (int)e_;  \
+    } while (0)
+
+}  // namespace nfmc

@@ -1,0 +1,211 @@
+// RealNVP on the VALU path (conditioner width H <= 32): one chain per lane, the chain's row of the
+// (64 x d) wave tile lives in LDS, conditioner weights are wave-uniform and arrive through the scalar
+// cache (s_load + SGPR operands of v_fmac), so the MLP costs no LDS bandwidth and no cross-lane traffic.
+//
+// Spec: DESIGN.md "RealNVP spec" / oracle/flow.py.  Weight blob per coupling layer (logical,
+// un-permuted coordinates; HP = n_hidden rounded up to a multiple of 4, padding rows/cols are zero):
+//     W1T (d_a, HP) | b1 (HP) | [WhT (HP_in, HP_out) | bh (HP)] x (n_hl-1) | W3 (2 d_b, HP) | b3 (2 d_b)
+// ReversePermutation is never materialised: layer l (0-based) sees logical coordinate j at physical
+// position (l even ? d-1-j : j) because l+1 reversals precede it.
+#pragma once
+
+#include "common.hpp"
+
+namespace nfmc {
+
+constexpr float kLog2Pi = 1.8378770664093453f;
+
+__device__ __forceinline__ float fast_tanh(float v) {
+    // 1 - 2 / (e^{2v} + 1); exact limits at +-inf, abs err ~1e-7
+    const float e = __builtin_amdgcn_exp2f(2.8853900817779268f * v);
+    return 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
+}
+
+// LDS row stride (floats) for a d-wide tile: multiple of 4 with stride/4 odd, so the 16 lanes of a
+// ds_read_b128 group fall on 16 distinct 4-bank slots.
+__host__ __device__ inline int tile_stride(int d) {
+    int s = (d + 3) & ~3;
+    if (((s >> 2) & 1) == 0) s += 4;
+    return s;
+}
+
+struct FlowGeom {
+    int d, d_a, d_b, n_hl, n_coupling;
+    int64_t layer_stride;
+    float log1m, m;
+};
+
+__device__ __forceinline__ FlowGeom make_geom(const NfmcRealNVP& f) {
+    FlowGeom g;
+    g.d = f.d;
+    g.d_a = f.d / 2;
+    g.d_b = f.d - g.d_a;
+    g.n_hl = f.n_hidden_layers;
+    g.n_coupling = f.n_coupling;
+    g.layer_stride = f.layer_stride;
+    g.m = f.min_scale;
+    g.log1m = __logf(1.f - f.min_scale);
+    return g;
+}
+
+// physical position of logical coordinate j in coupling layer with reversal flag `rev`
+__device__ __forceinline__ int phys(int j, int d, bool rev) { return rev ? d - 1 - j : j; }
+
+// Conditioner hidden stack: h = tanh(... tanh(W1 x_a + b1) ...) for this lane's chain.
+template <int HP>
+__device__ __forceinline__ void conditioner_hidden(const float* __restrict__ row, const float* __restrict__ W,
+                                                   const FlowGeom& g, bool rev, float (&h)[HP]) {
+    const float* b1 = W + (int64_t)g.d_a * HP;
+#pragma unroll
+    for (int k = 0; k < HP; ++k) h[k] = b1[k];
+    for (int j = 0; j < g.d_a; ++j) {
+        const float xj = row[phys(j, g.d, rev)];
+        const float* w = W + (int64_t)j * HP;
+#pragma unroll
+        for (int k = 0; k < HP; ++k) h[k] = fmaf(w[k], xj, h[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < HP; ++k) h[k] = fast_tanh(h[k]);
+    const float* Wh = b1 + HP;
+    for (int l = 1; l < g.n_hl; ++l) {
+        float t[HP];
+        const float* bh = Wh + HP * HP;
+#pragma unroll
+        for (int k = 0; k < HP; ++k) t[k] = bh[k];
+#pragma unroll
+        for (int i = 0; i < HP; ++i) {
+#pragma unroll
+            for (int k = 0; k < HP; ++k) t[k] = fmaf(Wh[i * HP + k], h[i], t[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < HP; ++k) h[k] = fast_tanh(t[k]);
+        Wh = bh + HP;
+    }
+}
+
+__device__ __forceinline__ const float* w3_of(const float* __restrict__ W, const FlowGeom& g, int HP) {
+    return W + (int64_t)g.d_a * HP + HP + (int64_t)(g.n_hl - 1) * (HP * HP + HP);
+}
+
+// One coupling layer applied in place to this lane's row.  Returns the layer's log|det| contribution
+// (forward: +sum log alpha; inverse: -sum log alpha).
+template <int HP, bool INVERSE>
+__device__ __forceinline__ float coupling_apply(float* __restrict__ row, const float* __restrict__ W,
+                                                const FlowGeom& g, bool rev) {
+    float h[HP];
+    conditioner_hidden<HP>(row, W, g, rev, h);
+    const float* W3 = w3_of(W, g, HP);
+    const float* b3 = W3 + (int64_t)2 * g.d_b * HP;
+    float ld = 0.f;
+    for (int t = 0; t < g.d_b; ++t) {
+        float ua = b3[t], ub = b3[g.d_b + t];
+        const float* wa = W3 + (int64_t)t * HP;
+        const float* wb = W3 + (int64_t)(g.d_b + t) * HP;
+#pragma unroll
+        for (int k = 0; k < HP; ++k) {
+            ua = fmaf(wa[k], h[k], ua);
+            ub = fmaf(wb[k], h[k], ub);
+        }
+        const float alpha = fast_exp(fmaf(0.5f, ua, g.log1m)) + g.m;
+        const float beta = 0.5f * ub;
+        const int p = phys(g.d_a + t, g.d, rev);
+        const float v = row[p];
+        ld += fast_ln(alpha);
+        row[p] = INVERSE ? (v - beta) * __builtin_amdgcn_rcpf(alpha) : fmaf(alpha, v, beta);
+    }
+    return INVERSE ? -ld : ld;
+}
+
+// x -> z in place; returns logdet_forward.
+template <int HP>
+__device__ __forceinline__ float flow_forward_row(float* __restrict__ row, const NfmcRealNVP& f, const FlowGeom& g) {
+    float ld = 0.f;
+    for (int c = 0; c < g.d; ++c) {
+        const float ls = f.ea0_log_scale[c];
+        row[c] = fmaf(fast_exp(ls), row[c], f.ea0_shift[c]);
+        ld += ls;
+    }
+    for (int l = 0; l < g.n_coupling; ++l)
+        ld += coupling_apply<HP, false>(row, f.weights + l * g.layer_stride, g, (l & 1) == 0);
+    // the last ElementwiseAffine acts on logical coordinates: physical p <-> logical (odd #reversals ? d-1-p : p)
+    const bool rev = (g.n_coupling & 1) != 0;
+    for (int c = 0; c < g.d; ++c) {
+        const int p = phys(c, g.d, rev);
+        const float ls = f.ea1_log_scale[c];
+        row[p] = fmaf(fast_exp(ls), row[p], f.ea1_shift[c]);
+        ld += ls;
+    }
+    return ld;
+}
+
+// z -> x in place; returns logdet_inverse.
+template <int HP>
+__device__ __forceinline__ float flow_inverse_row(float* __restrict__ row, const NfmcRealNVP& f, const FlowGeom& g) {
+    float ld = 0.f;
+    const bool rev_last = (g.n_coupling & 1) != 0;
+    for (int c = 0; c < g.d; ++c) {
+        const int p = phys(c, g.d, rev_last);
+        const float ls = f.ea1_log_scale[c];
+        row[p] = (row[p] - f.ea1_shift[c]) * fast_exp(-ls);
+        ld -= ls;
+    }
+    for (int l = g.n_coupling - 1; l >= 0; --l)
+        ld += coupling_apply<HP, true>(row, f.weights + l * g.layer_stride, g, (l & 1) == 0);
+    for (int c = 0; c < g.d; ++c) {
+        const float ls = f.ea0_log_scale[c];
+        row[c] = (row[c] - f.ea0_shift[c]) * fast_exp(-ls);
+        ld -= ls;
+    }
+    return ld;
+}
+
+// The tile of the final z (forward) / initial z (inverse) is in LOGICAL order of the last layer when the
+// number of reversals is odd; these helpers map a logical latent coordinate to its tile column.
+__device__ __forceinline__ int latent_col(int c, const FlowGeom& g) { return phys(c, g.d, (g.n_coupling & 1) != 0); }
+
+// Potential value for a whole row held by one lane.
+__device__ __forceinline__ float potential_row(const float* __restrict__ row, const NfmcPotential& p, int d) {
+    if (p.kind == NFMC_POT_FUNNEL) {
+        const float x0 = row[0];
+        float s = 0.f;
+        for (int c = 1; c < d; ++c) s = fmaf(row[c], row[c], s);
+        const float inv_s2 = 1.f / (p.a_scalar * p.a_scalar);
+        return 0.5f * x0 * x0 * inv_s2 + 0.5f * fast_exp(-x0) * s + 0.5f * (float)(d - 1) * x0;
+    }
+    float u = 0.f;
+    for (int c = 0; c < d; ++c) {
+        const float a = p.a ? p.a[c] : p.a_scalar;
+        const float t = row[c] - (p.b ? p.b[c] : p.b_scalar);
+        u = fmaf(a * t, t, u);
+    }
+    return u;
+}
+
+// Coalesced wave-tile IO: rows r0 .. r0+63 of a row-major (n, d) array <-> tile[64][stride].
+// `rev` stores column c of the array at tile column d-1-c (latent side of a flow with an odd number of
+// reversals, see latent_col).
+__device__ __forceinline__ void tile_load(float* __restrict__ tile, int stride, const float* __restrict__ src,
+                                          int64_t r0, int64_t n, int d, bool rev = false) {
+    const int lane = threadIdx.x & 63;
+    const int64_t rows = n - r0 < 64 ? n - r0 : 64;
+    const int total = (int)rows * d;
+    const float* s = src + r0 * d;
+    for (int i = lane; i < 64 * d; i += kWave) {
+        const int r = i / d, c = i - r * d;
+        tile[r * stride + (rev ? d - 1 - c : c)] = i < total ? s[i] : 0.f;  // rows beyond n: zeros
+    }
+}
+
+__device__ __forceinline__ void tile_store(const float* __restrict__ tile, int stride, float* __restrict__ dst,
+                                           int64_t r0, int64_t n, int d, bool rev = false) {
+    const int lane = threadIdx.x & 63;
+    const int64_t rows = n - r0 < 64 ? n - r0 : 64;
+    const int total = (int)rows * d;
+    float* o = dst + r0 * d;
+    for (int i = lane; i < total; i += kWave) {
+        const int r = i / d, c = i - r * d;
+        o[i] = tile[r * stride + (rev ? d - 1 - c : c)];
+    }
+}
+
+}  // namespace nfmc

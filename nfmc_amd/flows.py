@@ -1,0 +1,214 @@
+"""Host-side flow objects: the surface nfmc uses from `torchflows`, backed by the
+HIP kernels of libnfmc_hip.so.
+
+    Flow(RealNVP(event_shape, n_layers=2, conditioner_kwargs={'n_hidden': .., 'n_layers': ..}))
+    flow.sample(n, return_log_prob=False, no_grad=False)    jump.py:205, imh.py:128,221
+    flow.log_prob(x)                                         jump.py:218, imh.py:214
+    flow.bijection.forward(x) -> (z, logdet)                 tess.py:113
+    flow.bijection.inverse(z) -> (x, logdet)                 neutra.py:60,122
+    flow.bijection.layers, .event_shape                      test/test_flow_kwargs.py:18
+    flow.to(device), .get_device(), .state_dict(), .load_state_dict(), .parameters()
+    flow.fit(x_train, x_val=..., ...), flow.variational_fit(log_prob_fn, ...)   (training: flow_training.py)
+
+torchflows itself is absent from the reference tree and unpinned (pyproject.toml:23), so the RealNVP
+here follows the build's own spec (DESIGN.md "RealNVP spec", restated on CPU in oracle/flow.py).
+The parameters are ordinary `nn.Parameter`s; `packed(device)` lays them out for the kernels
+(include/nfmc_hip.h, NfmcRealNVP) and is cached until a parameter changes.
+"""
+import ctypes as C
+import math
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import hip
+
+MIN_SCALE = 1e-3
+
+
+def default_hidden(d_a: int) -> int:
+    return max(4, int(3 * math.log10(max(d_a, 1))))
+
+
+class ElementwiseAffine(nn.Module):
+    """z = exp(log_scale) * x + shift."""
+
+    def __init__(self, d):
+        super().__init__()
+        self.log_scale = nn.Parameter(torch.zeros(d))
+        self.shift = nn.Parameter(torch.zeros(d))
+
+
+class ReversePermutation(nn.Module):
+    """z[j] = x[d-1-j]; folded into the kernels' index arithmetic, never materialised."""
+
+
+class AffineCoupling(nn.Module):
+    """Half-split affine coupling; `conditioner` is the MLP d_a -> H (tanh) x n_layers -> 2 d_b."""
+
+    def __init__(self, d, n_hidden=None, n_layers=2):
+        super().__init__()
+        self.d_a = d // 2
+        self.d_b = d - self.d_a
+        self.n_hidden = default_hidden(self.d_a) if n_hidden is None else int(n_hidden)
+        self.n_layers = int(n_layers)
+        if self.n_layers < 1:
+            raise ValueError('conditioner needs at least one hidden layer')
+        dims = [self.d_a] + [self.n_hidden] * self.n_layers + [2 * self.d_b]
+        self.conditioner = nn.ModuleList([nn.Linear(dims[i], dims[i + 1]) for i in range(len(dims) - 1)])
+
+
+class RealNVP(nn.Module):
+    """[ElementwiseAffine] + n_layers x [ReversePermutation, AffineCoupling] + [ElementwiseAffine]."""
+
+    def __init__(self, event_shape, n_layers: int = 2, conditioner_kwargs: Optional[dict] = None, **kwargs):
+        super().__init__()
+        if isinstance(event_shape, int):
+            event_shape = (event_shape,)
+        self.event_shape = tuple(int(s) for s in event_shape)
+        self.d = int(math.prod(self.event_shape))
+        ck = dict(conditioner_kwargs or {})
+        if 'n_hidden' in kwargs:
+            ck.setdefault('n_hidden', kwargs['n_hidden'])
+        self.n_coupling = int(n_layers)
+        layers = [ElementwiseAffine(self.d)]
+        for _ in range(self.n_coupling):
+            layers += [ReversePermutation(), AffineCoupling(self.d, ck.get('n_hidden'), ck.get('n_layers', 2))]
+        layers.append(ElementwiseAffine(self.d))
+        self.layers = nn.ModuleList(layers)
+        self._pack_cache = None
+
+    # ------------------------------------------------------------------ packing for the kernels
+    @property
+    def couplings(self):
+        return [m for m in self.layers if isinstance(m, AffineCoupling)]
+
+    @property
+    def n_hidden(self):
+        c = self.couplings
+        return c[0].n_hidden if c else 4
+
+    @property
+    def n_hidden_layers(self):
+        c = self.couplings
+        return c[0].n_layers if c else 1
+
+    def _version_key(self, device):
+        return (str(device),) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def packed(self, device):
+        """(NfmcRealNVP struct, keep-alive tensors) on `device`; rebuilt only when a parameter changed."""
+        key = self._version_key(device)
+        if self._pack_cache is not None and self._pack_cache[0] == key:
+            return self._pack_cache[1]
+        lib = hip.lib()
+        d, H, nhl = self.d, self.n_hidden, self.n_hidden_layers
+        hp = int(lib.nfmc_realnvp_padded_hidden(H))
+        stride = int(lib.nfmc_realnvp_layer_floats(d, H, nhl))
+        d_a, d_b = d // 2, d - d // 2
+        with torch.no_grad():
+            blobs = []
+            for cpl in self.couplings:
+                lin = list(cpl.conditioner)
+                parts = []
+                w1t = torch.zeros(d_a, hp)
+                w1t[:, :H] = lin[0].weight.detach().float().cpu().t()
+                b1 = torch.zeros(hp)
+                b1[:H] = lin[0].bias.detach().float().cpu()
+                parts += [w1t.reshape(-1), b1]
+                for l in lin[1:-1]:
+                    wt = torch.zeros(hp, hp)
+                    wt[:H, :H] = l.weight.detach().float().cpu().t()
+                    bh = torch.zeros(hp)
+                    bh[:H] = l.bias.detach().float().cpu()
+                    parts += [wt.reshape(-1), bh]
+                w3 = torch.zeros(2 * d_b, hp)
+                w3[:, :H] = lin[-1].weight.detach().float().cpu()
+                parts += [w3.reshape(-1), lin[-1].bias.detach().float().cpu()]
+                blob = torch.cat(parts)
+                assert blob.numel() == stride, (blob.numel(), stride)
+                blobs.append(blob)
+            weights = (torch.cat(blobs) if blobs else torch.zeros(1)).to(device)
+            ea0, ea1 = self.layers[0], self.layers[-1]
+            keep = [weights] + [t.detach().float().contiguous().to(device)
+                                for t in (ea0.log_scale, ea0.shift, ea1.log_scale, ea1.shift)]
+        st = hip.NfmcRealNVP(d, self.n_coupling, H, nhl, MIN_SCALE, 0, hip.ptr(keep[1]), hip.ptr(keep[2]),
+                             hip.ptr(keep[3]), hip.ptr(keep[4]), hip.ptr(keep[0]), stride)
+        self._pack_cache = (key, (st, keep))
+        return self._pack_cache[1]
+
+    # ------------------------------------------------------------------ bijection API
+    def _prep(self, v):
+        dev = hip.require_gpu()
+        n = v.shape[0]
+        return dev, n, v.detach().to(dev, torch.float32).reshape(n, self.d).contiguous()
+
+    def forward(self, x):
+        """x -> (z, log|det dz/dx|)  [HIP kernel nfmc_realnvp_forward_f32]."""
+        dev, n, xf = self._prep(x)
+        st, _keep = self.packed(dev)
+        z = torch.empty_like(xf)
+        ld = torch.empty(n, dtype=torch.float32, device=dev)
+        hip.check(hip.lib().nfmc_realnvp_forward_f32(C.byref(st), hip.ptr(xf), n, hip.ptr(z), hip.ptr(ld), None,
+                                                     hip.stream()), 'nfmc_realnvp_forward_f32')
+        return z.reshape(n, *self.event_shape), ld
+
+    def inverse(self, z):
+        """z -> (x, log|det dx/dz|)  [HIP kernel nfmc_realnvp_inverse_f32]."""
+        dev, n, zf = self._prep(z)
+        st, _keep = self.packed(dev)
+        x = torch.empty_like(zf)
+        ld = torch.empty(n, dtype=torch.float32, device=dev)
+        hip.check(hip.lib().nfmc_realnvp_inverse_f32(C.byref(st), hip.ptr(zf), n, hip.ptr(x), hip.ptr(ld), None, None,
+                                                     hip.stream()), 'nfmc_realnvp_inverse_f32')
+        return x.reshape(n, *self.event_shape), ld
+
+
+class Flow(nn.Module):
+    """`torchflows.Flow` stand-in over a bijection with a standard-normal base."""
+
+    def __init__(self, bijection: RealNVP):
+        super().__init__()
+        self.bijection = bijection
+        self._sample_calls = 0
+        self.seed = None  # native-stream seed for sample(); drawn from torch's global RNG on first use
+
+    @property
+    def event_shape(self):
+        return self.bijection.event_shape
+
+    def get_device(self):
+        return next(self.parameters()).device
+
+    def log_prob(self, x):
+        dev, n, xf = self.bijection._prep(x)
+        st, _keep = self.bijection.packed(dev)
+        lp = torch.empty(n, dtype=torch.float32, device=dev)
+        hip.check(hip.lib().nfmc_realnvp_forward_f32(C.byref(st), hip.ptr(xf), n, None, None, hip.ptr(lp),
+                                                     hip.stream()), 'nfmc_realnvp_forward_f32')
+        return lp
+
+    def sample(self, n, return_log_prob=False, no_grad=False, rng=None):
+        """x ~ q (inverse pass of in-kernel z ~ N(0, I)); optionally log q(x).  `rng`: hip.NfmcRng override."""
+        dev = hip.require_gpu()
+        st, _keep = self.bijection.packed(dev)
+        if rng is None:
+            if self.seed is None:
+                self.seed = int(torch.randint(0, 2 ** 62, ()).item())
+            rng = hip.make_rng(self.seed, 0, self._sample_calls)
+            self._sample_calls += 1
+        x = torch.empty(n, self.bijection.d, dtype=torch.float32, device=dev)
+        lq = torch.empty(n, dtype=torch.float32, device=dev) if return_log_prob else None
+        hip.check(hip.lib().nfmc_realnvp_inverse_f32(C.byref(st), None, n, hip.ptr(x), None, hip.ptr(lq),
+                                                     C.byref(rng), hip.stream()), 'nfmc_realnvp_inverse_f32')
+        x = x.reshape(n, *self.event_shape)
+        return (x, lq) if return_log_prob else x
+
+    def fit(self, x_train, x_val=None, **kwargs):
+        from .flow_training import fit as _fit
+        return _fit(self, x_train, x_val, **kwargs)
+
+    def variational_fit(self, log_prob_fn, **kwargs):
+        from .flow_training import variational_fit as _vfit
+        return _vfit(self, log_prob_fn, **kwargs)

@@ -1,0 +1,202 @@
+"""ctypes binding of libnfmc_hip.so (include/nfmc_hip.h).  No torch types cross the boundary:
+tensors are passed as raw device pointers (`tensor.data_ptr()`), work is enqueued on the
+caller's current HIP stream.
+
+The library is REQUIRED: importing a sampler on a machine where it cannot be loaded raises
+(there is no CPU or eager-PyTorch fallback for the hot path).
+"""
+import ctypes as C
+import os
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libnfmc_hip.so')
+
+OK, EINVAL, ESHAPE, EALIGN, EUNSUPPORTED, ESCRATCH = 0, -1, -2, -3, -4, -5
+POT_QUADRATIC, POT_FUNNEL = 0, 1
+TAG_NOISE, TAG_ACCEPT, TAG_LATENT, TAG_JUMP = 0, 1, 2, 3
+CNT_ACCEPTED, CNT_ATTEMPTED, CNT_NONFINITE, CNT_WORDS = 0, 1, 2, 4
+MAX_STEPS_PER_CALL = 512
+
+c_fp = C.c_void_p  # all device pointers travel as void*
+
+
+class NfmcPotential(C.Structure):
+    _fields_ = [('kind', C.c_int32), ('reserved', C.c_int32), ('a', c_fp), ('b', c_fp),
+                ('a_scalar', C.c_float), ('b_scalar', C.c_float)]
+
+
+class NfmcRng(C.Structure):
+    _fields_ = [('seed', C.c_uint64), ('chain_offset', C.c_uint64), ('step0', C.c_uint32), ('reserved', C.c_uint32),
+                ('replay_normals', c_fp), ('replay_uniforms', c_fp)]
+
+
+class NfmcStats(C.Structure):
+    _fields_ = [('sum_x', c_fp), ('sum_x2', c_fp), ('counters', c_fp), ('scratch', c_fp),
+                ('scratch_bytes', C.c_int64)]
+
+
+class NfmcMalaArgs(C.Structure):
+    _fields_ = [('x', c_fp), ('n', C.c_int64), ('d', C.c_int32), ('n_steps', C.c_int32),
+                ('step_size', C.c_float), ('adjust', C.c_int32), ('inv_mass_diag', c_fp),
+                ('pot', NfmcPotential), ('rng', NfmcRng), ('stats', NfmcStats),
+                ('samples', c_fp), ('masks_out', c_fp), ('log_ratio_out', c_fp)]
+
+
+class NfmcHmcArgs(C.Structure):
+    _fields_ = [('x', c_fp), ('n', C.c_int64), ('d', C.c_int32), ('n_steps', C.c_int32),
+                ('step_size', C.c_float), ('n_leapfrog', C.c_int32), ('adjust', C.c_int32), ('reserved', C.c_int32),
+                ('inv_mass_diag', c_fp), ('pot', NfmcPotential), ('rng', NfmcRng), ('stats', NfmcStats),
+                ('samples', c_fp), ('masks_out', c_fp), ('log_ratio_out', c_fp)]
+
+
+class NfmcRealNVP(C.Structure):
+    _fields_ = [('d', C.c_int32), ('n_coupling', C.c_int32), ('n_hidden', C.c_int32), ('n_hidden_layers', C.c_int32),
+                ('min_scale', C.c_float), ('reserved', C.c_int32),
+                ('ea0_log_scale', c_fp), ('ea0_shift', c_fp), ('ea1_log_scale', c_fp), ('ea1_shift', c_fp),
+                ('weights', c_fp), ('layer_stride', C.c_int64)]
+
+
+class NfmcFlowMhArgs(C.Structure):
+    _fields_ = [('x', c_fp), ('logq', c_fp), ('n', C.c_int64), ('n_steps', C.c_int32), ('logq_cached', C.c_int32),
+                ('adjusted', C.c_int32), ('reserved', C.c_int32), ('flow', NfmcRealNVP), ('pot', NfmcPotential),
+                ('rng', NfmcRng), ('stats', NfmcStats), ('samples', c_fp), ('masks_out', c_fp),
+                ('log_ratio_out', c_fp)]
+
+
+class NfmcNeutraHmcArgs(C.Structure):
+    _fields_ = [('z', c_fp), ('n', C.c_int64), ('n_steps', C.c_int32), ('n_leapfrog', C.c_int32),
+                ('step_size', C.c_float), ('adjust', C.c_int32), ('inv_mass_diag', c_fp),
+                ('flow', NfmcRealNVP), ('pot', NfmcPotential), ('rng', NfmcRng), ('stats', NfmcStats),
+                ('samples', c_fp), ('masks_out', c_fp), ('log_ratio_out', c_fp)]
+
+
+class NfmcSelectArgs(C.Structure):
+    _fields_ = [('x', c_fp), ('x_prime', c_fp), ('n', C.c_int64), ('d', C.c_int32), ('n_carry', C.c_int32),
+                ('log_ratio', c_fp), ('uniforms', c_fp), ('carry', c_fp * 2), ('carry_prime', c_fp * 2),
+                ('rng', NfmcRng), ('rng_tag', C.c_int32), ('reserved', C.c_int32), ('stats', NfmcStats),
+                ('mask_out', c_fp)]
+
+
+class NfmcLimits(C.Structure):
+    _fields_ = [('abi_version', C.c_int32), ('max_d_sampler', C.c_int32), ('max_d_flow', C.c_int32),
+                ('max_hidden_valu', C.c_int32), ('max_hidden', C.c_int32), ('max_steps_per_call', C.c_int32)]
+
+
+# every symbol include/nfmc_hip.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ('nfmc_stats_scratch_bytes', C.c_int64, [C.c_int32]),
+    ('nfmc_mala_steps_f32', C.c_int, [C.POINTER(NfmcMalaArgs), c_fp]),
+    ('nfmc_hmc_steps_f32', C.c_int, [C.POINTER(NfmcHmcArgs), c_fp]),
+    ('nfmc_realnvp_padded_hidden', C.c_int32, [C.c_int32]),
+    ('nfmc_realnvp_layer_floats', C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    ('nfmc_realnvp_forward_f32', C.c_int, [C.POINTER(NfmcRealNVP), c_fp, C.c_int64, c_fp, c_fp, c_fp, c_fp]),
+    ('nfmc_realnvp_inverse_f32', C.c_int, [C.POINTER(NfmcRealNVP), c_fp, C.c_int64, c_fp, c_fp, c_fp,
+                                           C.POINTER(NfmcRng), c_fp]),
+    ('nfmc_flow_mh_steps_f32', C.c_int, [C.POINTER(NfmcFlowMhArgs), c_fp]),
+    ('nfmc_neutra_hmc_steps_f32', C.c_int, [C.POINTER(NfmcNeutraHmcArgs), c_fp]),
+    ('nfmc_neutra_potential_grad_f32', C.c_int, [C.POINTER(NfmcRealNVP), C.POINTER(NfmcPotential), c_fp, C.c_int64,
+                                                 c_fp, c_fp, c_fp]),
+    ('nfmc_mh_accept_select_f32', C.c_int, [C.POINTER(NfmcSelectArgs), c_fp]),
+    ('nfmc_langevin_propose_f32', C.c_int, [c_fp, c_fp, c_fp, C.c_float, C.c_int64, C.c_int32, C.POINTER(NfmcRng),
+                                            c_fp, c_fp]),
+    ('nfmc_langevin_log_ratio_f32', C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, C.c_float, C.c_int64,
+                                              C.c_int32, c_fp, c_fp]),
+    ('nfmc_moments_update_f32', C.c_int, [c_fp, C.c_int64, C.c_int32, C.POINTER(NfmcStats), c_fp]),
+    ('nfmc_philox_normals_f32', C.c_int, [C.POINTER(NfmcRng), C.c_int32, C.c_int64, C.c_int32, c_fp, c_fp]),
+    ('nfmc_philox_uniforms_f32', C.c_int, [C.POINTER(NfmcRng), C.c_int32, C.c_int64, c_fp, c_fp]),
+    ('nfmc_limits', C.c_int, [C.POINTER(NfmcLimits)]),
+    ('nfmc_error_string', C.c_char_p, [C.c_int]),
+]
+
+_lib = None
+
+
+def lib():
+    """Load the library (once).  Raises if it is missing: the hot path has no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                'nfmc_amd: %s is missing. Build it with `python -m nfmc_amd.build` (needs hipcc); the MI355X '
+                'path has no CPU/eager fallback.' % LIB_PATH)
+        handle = C.CDLL(LIB_PATH)
+        for name, restype, argtypes in SYMBOLS:
+            fn = getattr(handle, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    """Map a return code to the reference's error channels: ValueError for argument errors
+    (the reference's only error type, langevin.py:111), RuntimeError for HIP errors."""
+    if rc == 0:
+        return
+    msg = lib().nfmc_error_string(rc).decode()
+    if rc < 0:
+        raise ValueError('%s: %s (code %d)' % (what, msg, rc))
+    raise RuntimeError('%s: HIP error %d: %s' % (what, rc, msg))
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError('nfmc_amd needs a ROCm GPU (MI355X / gfx950); torch.cuda.is_available() is False. '
+                           'There is no CPU fallback for the hot path.')
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+def ptr(t, dtype=torch.float32):
+    """Device pointer of a contiguous CUDA tensor of `dtype` (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise ValueError('expected a GPU tensor')
+    if t.dtype != dtype:
+        raise ValueError('expected dtype %s, got %s' % (dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError('expected a contiguous tensor')
+    return C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def limits():
+    out = NfmcLimits()
+    check(lib().nfmc_limits(C.byref(out)), 'nfmc_limits')
+    return out
+
+
+class DeviceStats:
+    """Device-resident accumulators behind NfmcStats (fp64 sums, u64 counters, scratch slab)."""
+
+    def __init__(self, d, device):
+        self.d = d
+        self.sum_x = torch.zeros(d, dtype=torch.float64, device=device)
+        self.sum_x2 = torch.zeros(d, dtype=torch.float64, device=device)
+        self.counters = torch.zeros(CNT_WORDS, dtype=torch.int64, device=device)
+        nbytes = int(lib().nfmc_stats_scratch_bytes(d))
+        self.scratch = torch.empty(nbytes // 8, dtype=torch.float64, device=device)
+
+    def struct(self):
+        return NfmcStats(ptr(self.sum_x, torch.float64), ptr(self.sum_x2, torch.float64),
+                         ptr(self.counters, torch.int64), ptr(self.scratch, torch.float64),
+                         self.scratch.numel() * 8)
+
+    def zero_(self):
+        self.sum_x.zero_()
+        self.sum_x2.zero_()
+        self.counters.zero_()
+
+
+def null_stats():
+    return NfmcStats(None, None, None, None, 0)
+
+
+def make_rng(seed, chain_offset, step0, replay_normals=None, replay_uniforms=None):
+    return NfmcRng(int(seed) & 0xFFFFFFFFFFFFFFFF, int(chain_offset), int(step0) & 0xFFFFFFFF, 0,
+                   ptr(replay_normals), ptr(replay_uniforms))

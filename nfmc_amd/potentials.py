@@ -1,0 +1,154 @@
+"""Closed-form potential descriptors: callables (usable as `target` exactly like the reference's
+`target(x) -> (n,)` callables, nfmc/sample.py:35-37) that ALSO describe themselves to the HIP kernels,
+so U and grad U are evaluated in-kernel instead of by `torch.autograd.grad` (langevin.py:66-68).
+
+The reference's own potential objects live in the absent third-party package `potentials`
+(nfmc/sample.py:17); `SumOfSquares` is the README/test potential (README.md:45-46, test/util.py:4-5),
+`Funnel` is the build's C4 potential.
+
+`recognize(target, event_shape)` lets plain Python callables such as the README's
+`lambda x: torch.sum(x**2, dim=1)` take the fused path: it probes the callable on a few points,
+fits U = sum_j a_j (x_j - b_j)^2 + c and accepts it only if the fit reproduces the callable (and its
+autograd gradient) on fresh points at several scales to 1e-5 relative.
+"""
+import ctypes as C
+import math
+from typing import Optional, Sequence, Tuple, Union
+
+import torch
+
+from . import hip
+
+
+class Potential:
+    """Base: `event_shape`, `__call__(x) -> (n,)` in torch ops, `descriptor(device)` for the kernels."""
+
+    event_shape: Tuple[int, ...]
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        raise NotImplementedError
+
+    def descriptor(self, device) -> hip.NfmcPotential:
+        raise NotImplementedError
+
+    @property
+    def event_size(self):
+        return int(math.prod(self.event_shape))
+
+
+class QuadraticPotential(Potential):
+    """U(x) = sum_j a_j (x_j - b_j)^2 with per-coordinate or scalar a, b."""
+
+    def __init__(self, event_shape, a=1.0, b=0.0):
+        if isinstance(event_shape, int):
+            event_shape = (event_shape,)
+        self.event_shape = tuple(event_shape)
+        d = self.event_size
+        self.a = self._norm(a, d)
+        self.b = self._norm(b, d)
+        self._dev = {}
+
+    @staticmethod
+    def _norm(v, d):
+        if isinstance(v, (int, float)):
+            return float(v)
+        t = torch.as_tensor(v, dtype=torch.float32).reshape(-1)
+        if t.numel() == 1:
+            return float(t)
+        if t.numel() != d:
+            raise ValueError('potential parameter must be a scalar or have event_size entries')
+        return t.contiguous()
+
+    def __call__(self, x):
+        n = x.shape[0]
+        xf = x.reshape(n, -1)
+        a = self.a if isinstance(self.a, float) else self.a.to(xf)
+        b = self.b if isinstance(self.b, float) else self.b.to(xf)
+        return torch.sum(a * (xf - b) ** 2, dim=-1)
+
+    def descriptor(self, device):
+        key = str(device)
+        if key not in self._dev:
+            self._dev[key] = tuple(None if isinstance(v, float) else v.to(device) for v in (self.a, self.b))
+        da, db = self._dev[key]
+        return hip.NfmcPotential(hip.POT_QUADRATIC, 0, hip.ptr(da), hip.ptr(db),
+                                 self.a if isinstance(self.a, float) else 0.0,
+                                 self.b if isinstance(self.b, float) else 0.0)
+
+
+class SumOfSquares(QuadraticPotential):
+    """U(x) = sum x^2: the reference's "standard Gaussian potential" (target N(0, I/2))."""
+
+    def __init__(self, event_shape):
+        super().__init__(event_shape, 1.0, 0.0)
+
+
+class DiagonalGaussian(QuadraticPotential):
+    """U(x) = sum (x - mu)^2 / (2 sigma^2) (normalising constant dropped, as MH ratios ignore it)."""
+
+    def __init__(self, event_shape, mu=0.0, sigma=1.0):
+        s = torch.as_tensor(sigma, dtype=torch.float32)
+        super().__init__(event_shape, (1.0 / (2.0 * s * s)) if s.numel() > 1 else 1.0 / (2.0 * float(s) ** 2), mu)
+
+
+class Funnel(Potential):
+    """U(x) = x_0^2/(2 s^2) + sum_{i>=1} [ x_i^2 / (2 e^{x_0}) + x_0/2 ]  (Neal's funnel, s = 3)."""
+
+    def __init__(self, event_shape, scale: float = 3.0):
+        if isinstance(event_shape, int):
+            event_shape = (event_shape,)
+        self.event_shape = tuple(event_shape)
+        self.scale = float(scale)
+
+    def __call__(self, x):
+        n = x.shape[0]
+        xf = x.reshape(n, -1)
+        x0 = xf[:, 0]
+        return x0 ** 2 / (2 * self.scale ** 2) + 0.5 * torch.exp(-x0) * torch.sum(xf[:, 1:] ** 2, dim=-1) \
+            + 0.5 * (xf.shape[1] - 1) * x0
+
+    def descriptor(self, device):
+        return hip.NfmcPotential(hip.POT_FUNNEL, 0, None, None, self.scale, 0.0)
+
+
+def recognize(target, event_shape, rtol: float = 1e-5) -> Optional[Potential]:
+    """Return a QuadraticPotential equal to `target`, or None.  Never guesses: any probe mismatch -> None."""
+    if isinstance(target, Potential):
+        return target
+    d = int(math.prod(event_shape))
+    try:
+        with torch.no_grad():
+            g = torch.Generator().manual_seed(0x5EED)
+            z = torch.zeros(1, *event_shape, dtype=torch.float64)
+            c0 = target(z).reshape(-1).double()
+            eye = torch.eye(d, dtype=torch.float64).reshape(d, *event_shape)
+            up = target(eye).reshape(-1).double()
+            um = target(-eye).reshape(-1).double()
+            if not (torch.isfinite(c0).all() and torch.isfinite(up).all() and torch.isfinite(um).all()):
+                return None
+            # U(t e_j) = a_j t^2 - 2 a_j b_j t + (c0)  =>  a_j = (U+ + U- - 2 c0)/2, a_j b_j = (U- - U+)/4
+            a = (up + um - 2 * c0) / 2
+            ab = (um - up) / 4
+            b = torch.where(a > 0, ab / torch.where(a > 0, a, torch.ones_like(a)), torch.zeros_like(a))
+            const = c0 - (a * b * b).sum()
+            if not torch.isfinite(a).all() or not torch.isfinite(b).all() or (a < 0).any():
+                return None
+            for scale in (0.1, 1.0, 7.0):
+                x = scale * torch.randn(8, *event_shape, generator=g, dtype=torch.float64)
+                want = target(x).reshape(-1).double()
+                got = (a * (x.reshape(8, -1) - b) ** 2).sum(-1) + const
+                if not torch.allclose(got, want, rtol=rtol, atol=rtol * (1 + want.abs().max())):
+                    return None
+        # gradient check through autograd (catches targets that detach / are piecewise)
+        x = torch.randn(4, *event_shape, generator=g, dtype=torch.float64).requires_grad_(True)
+        gr, = torch.autograd.grad(target(x).sum(), x)
+        want_g = (2 * a * (x.detach().reshape(4, -1) - b)).reshape(x.shape)
+        if not torch.allclose(gr, want_g, rtol=rtol, atol=rtol * (1 + want_g.abs().max())):
+            return None
+    except Exception:
+        return None
+
+    def simplify(v):
+        return float(v[0]) if bool((v == v[0]).all()) else v.float()
+
+    return QuadraticPotential(tuple(event_shape), simplify(a), simplify(b))

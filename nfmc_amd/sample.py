@@ -1,0 +1,131 @@
+"""Public entry points `sample()` / `create_sampler()` with the reference's signature and keyword
+plumbing (nfmc/sample.py:20-30, 243-314) for the strategies on this build's path:
+
+    mala, ula, hmc, uhmc                                  (inner samplers)
+    imh / fixed_imh, jump_mala, jump_ula, jump_hmc, jump_uhmc, neutra_hmc
+
+Other reference strategies (mh, ess, nuts, adaptive_imh, jump_mh, jump_ess, neutra_mh, tess, dlmc) are
+outside the path and raise ValueError naming what is supported.
+"""
+from typing import Optional, Tuple, Union
+
+import torch
+
+from .containers import MCMCOutput, NFMCKernel, Sampler
+from .flows import Flow
+from .potentials import Potential
+from .samplers.imh import FixedIMH, IMHKernel, IMHParameters
+from .samplers.jump import JumpHMC, JumpMALA, JumpNFMCParameters, JumpUHMC, JumpULA
+from .samplers.mcmc import HMC, MALA, UHMC, ULA, HMCKernel, HMCParameters, LangevinKernel, LangevinParameters
+from .samplers.neutra import NeuTraHMC, NeuTraKernel, NeuTraParameters
+from .util import create_flow_object, get_supported_samplers
+
+
+def create_sampler(target: callable,
+                   event_shape: Optional[Union[torch.Size, Tuple[int]]] = None,
+                   flow: Optional[Union[str, Flow]] = 'realnvp',
+                   strategy: str = "imh",
+                   negative_log_likelihood: callable = None,
+                   kernel_kwargs: Optional[dict] = None,
+                   param_kwargs: Optional[dict] = None,
+                   inner_kernel_kwargs: Optional[dict] = None,
+                   inner_param_kwargs: Optional[dict] = None,
+                   device: torch.device = None,
+                   flow_kwargs: Optional[dict] = None) -> Sampler:
+    """nfmc/sample.py:20-240.  `device` is accepted for signature compatibility; the chain state and the
+    flow always live on the current ROCm device."""
+    flow_kwargs = flow_kwargs or {}
+    kernel_kwargs = kernel_kwargs or {}
+    param_kwargs = param_kwargs or {'n_iterations': 100}
+    inner_kernel_kwargs = inner_kernel_kwargs or {}
+    inner_param_kwargs = dict(inner_param_kwargs or {})
+
+    if flow is not None and not isinstance(flow, str):
+        event_shape = flow.event_shape
+    elif isinstance(target, Potential):
+        event_shape = target.event_shape
+    event_shape = tuple(event_shape)
+    event_size = int(torch.prod(torch.as_tensor(event_shape)))
+
+    if strategy == "hmc":
+        return HMC(event_shape, target, HMCKernel(event_size=event_size, **kernel_kwargs), HMCParameters(**param_kwargs))
+    if strategy == "uhmc":
+        return UHMC(event_shape, target, HMCKernel(event_size=event_size, **kernel_kwargs), HMCParameters(**param_kwargs))
+    if strategy == "mala":
+        return MALA(event_shape, target, LangevinKernel(event_size=event_size, **kernel_kwargs),
+                    LangevinParameters(**param_kwargs))
+    if strategy == "ula":
+        return ULA(event_shape, target, LangevinKernel(event_size=event_size, **kernel_kwargs),
+                   LangevinParameters(**param_kwargs))
+
+    if strategy in ("imh", "fixed_imh", "jump_mala", "jump_ula", "jump_hmc", "jump_uhmc", "neutra_hmc"):
+        if flow is None:
+            raise ValueError("Flow object must be provided")
+        if isinstance(flow, str):
+            flow_object = create_flow_object(flow_string=flow, event_shape=event_shape, **flow_kwargs)
+        elif hasattr(flow, 'sample') and hasattr(flow, 'log_prob'):
+            flow_object = flow
+        else:
+            raise ValueError(f"Unknown type for normalizing flow: {type(flow)}")
+        if strategy in ("imh", "fixed_imh"):
+            return FixedIMH(event_shape, target, IMHKernel(event_shape, flow=flow_object), IMHParameters(**param_kwargs))
+        if strategy in ('jump_mala', 'jump_ula'):
+            cls = JumpMALA if strategy == 'jump_mala' else JumpULA
+            return cls(event_shape, target, kernel=NFMCKernel(event_shape, flow=flow_object),
+                       params=JumpNFMCParameters(**param_kwargs),
+                       inner_kernel=LangevinKernel(event_size=event_size, **inner_kernel_kwargs),
+                       inner_params=LangevinParameters(**inner_param_kwargs))
+        if strategy in ('jump_hmc', 'jump_uhmc'):
+            if strategy == 'jump_hmc' and 'n_iterations' not in inner_param_kwargs:
+                inner_param_kwargs['n_iterations'] = 5  # sample.py:161-162
+            cls = JumpHMC if strategy == 'jump_hmc' else JumpUHMC
+            return cls(event_shape, target, kernel=NFMCKernel(event_shape, flow=flow_object),
+                       params=JumpNFMCParameters(**param_kwargs),
+                       inner_kernel=HMCKernel(event_size=event_size, **inner_kernel_kwargs),
+                       inner_params=HMCParameters(**inner_param_kwargs))
+        if strategy == 'neutra_hmc':
+            return NeuTraHMC(event_shape, target, HMCKernel(event_size=event_size, **inner_kernel_kwargs),
+                             HMCParameters(**inner_param_kwargs), NeuTraKernel(event_shape, flow=flow_object),
+                             NeuTraParameters(**param_kwargs))
+    raise ValueError(f"Unsupported sampling strategy: {strategy} (this build covers {get_supported_samplers()})")
+
+
+def sample(target: Union[callable, Potential],
+           event_shape: Optional[Union[torch.Size, Tuple[int, ...]]] = None,
+           flow: Optional[Union[str, Flow]] = 'realnvp',
+           strategy: str = "imh",
+           n_iterations: int = 100,
+           n_warmup_iterations: int = 100,
+           n_chains: int = 100,
+           x0: torch.Tensor = None,
+           warmup: bool = False,
+           show_progress: bool = True,
+           sampling_time_limit_seconds: Union[float, int] = None,
+           warmup_time_limit_seconds: Union[float, int] = None,
+           **kwargs) -> MCMCOutput:
+    """nfmc/sample.py:243-314."""
+    if flow == 'None':
+        flow = None
+    if flow is not None and not isinstance(flow, str):
+        event_shape = flow.event_shape
+    elif isinstance(target, Potential):
+        event_shape = target.event_shape
+    seed = kwargs.pop('seed', None)
+    shard = kwargs.pop('shard', None)
+    if 'param_kwargs' not in kwargs:
+        kwargs['param_kwargs'] = {}
+    kwargs['param_kwargs'] = {**kwargs['param_kwargs'],
+                              **dict(n_iterations=n_iterations, n_warmup_iterations=n_warmup_iterations)}
+    sampler = create_sampler(target=target, event_shape=event_shape, flow=flow, strategy=strategy, **kwargs)
+    sampler.seed = seed
+    sampler.shard = shard
+    if x0 is None:
+        x0 = torch.randn(size=(n_chains, *event_shape))  # drawn after flow construction, sample.py:304-305
+    if warmup:
+        warmup_output = sampler.warmup(x0=x0, show_progress=show_progress, time_limit_seconds=warmup_time_limit_seconds)
+        if warmup_output.samples is not None:
+            flat = warmup_output.samples_device.flatten(0, 1)
+            x0 = flat[torch.randperm(len(flat), device=flat.device)][:x0.shape[0]]
+        else:
+            x0 = warmup_output.running_samples.last_sample
+    return sampler.sample(x0=x0, show_progress=show_progress, time_limit_seconds=sampling_time_limit_seconds)

@@ -1,0 +1,112 @@
+"""Shared host logic of the samplers: target resolution, run state on the device, noise bookkeeping."""
+import ctypes as C
+import math
+import time
+from typing import Optional
+
+import torch
+
+from .. import hip
+from ..potentials import Potential, recognize
+
+
+def resolve_target(target, event_shape, fuse='auto') -> Optional[Potential]:
+    """A closed-form descriptor for `target`, or None (-> split path: torch autograd for U, grad U)."""
+    if isinstance(target, Potential):
+        return target
+    if fuse in (False, 'never'):
+        return None
+    return recognize(target, event_shape)
+
+
+class Replay:
+    """Recorded noise for parity tests: `normals` (T, n, d) and `uniforms` (T, n) on the device, consumed in
+    transition order (one normal field and one uniform vector per transition; unadjusted transitions take
+    no uniforms, exactly like the reference's draw order -- SURVEY.md App. A.3)."""
+
+    def __init__(self, normals, uniforms, device):
+        self.normals = torch.as_tensor(normals, dtype=torch.float32).to(device).contiguous()
+        self.normals = self.normals.reshape(self.normals.shape[0], self.normals.shape[1], -1)
+        self.uniforms = None
+        if uniforms is not None and torch.as_tensor(uniforms).numel() > 0:
+            self.uniforms = torch.as_tensor(uniforms, dtype=torch.float32).to(device).contiguous()
+        self.i_n = 0
+        self.i_u = 0
+
+    def take(self, k, with_uniforms=True):
+        nz = self.normals[self.i_n:self.i_n + k]
+        assert nz.shape[0] == k, 'replay noise exhausted'
+        self.i_n += k
+        un = None
+        if with_uniforms:
+            un = self.uniforms[self.i_u:self.i_u + k]
+            assert un.shape[0] == k, 'replay uniforms exhausted'
+            self.i_u += k
+        return nz, un
+
+
+class Run:
+    """Device-side state of one `sample()` call."""
+
+    def __init__(self, sampler, x0):
+        self.dev = hip.require_gpu()
+        hip.lib()
+        self.n = int(x0.shape[0])
+        self.event_shape = tuple(x0.shape[1:])
+        self.d = int(math.prod(self.event_shape)) if self.event_shape else 1
+        shard = sampler.shard
+        self.shard = shard
+        if shard is not None:
+            lo, hi = shard.bounds(self.n)
+            x0 = x0[lo:hi]
+            self.chain_offset = lo
+            self.n_global = self.n
+            self.n = hi - lo
+        else:
+            self.chain_offset = 0
+            self.n_global = self.n
+        self.x = x0.detach().to(self.dev, torch.float32).reshape(self.n, self.d).contiguous().clone()
+        self.stats = hip.DeviceStats(self.d, self.dev)
+        if sampler.seed is None:
+            seed = int(torch.randint(0, 2 ** 62, ()).item())
+            if shard is not None:
+                seed = shard.broadcast_int(seed)
+        else:
+            seed = int(sampler.seed)
+        self.seed = seed
+        self.replay = None
+        if sampler.replay is not None:
+            normals, uniforms = sampler.replay
+            self.replay = Replay(normals, uniforms, self.dev)
+        self.t0 = time.time()
+
+    def rng(self, step0, k=0, adjusted=True):
+        """NfmcRng for a launch of k transitions starting at transition `step0`."""
+        if self.replay is not None:
+            nz, un = self.replay.take(k, with_uniforms=adjusted)
+            self._keep = (nz, un)
+            return hip.make_rng(self.seed, self.chain_offset, step0, nz, un)
+        return hip.make_rng(self.seed, self.chain_offset, step0)
+
+    def sync(self):
+        torch.cuda.synchronize(self.dev)
+
+    def elapsed(self):
+        self.sync()
+        return time.time() - self.t0
+
+
+def chunks(total, limit=hip.MAX_STEPS_PER_CALL):
+    done = 0
+    while done < total:
+        k = min(limit, total - done)
+        yield done, k
+        done += k
+
+
+def imd_tensor(kernel, dev):
+    """inv_mass_diag on the device, or None when it is all ones (the kernels' scalar fast path)."""
+    imd = kernel.inv_mass_diag
+    if imd is None or bool((imd == 1).all()):
+        return None
+    return imd.detach().to(dev, torch.float32).contiguous()

@@ -1,0 +1,118 @@
+"""Independent Metropolis-Hastings with the flow as proposal (nfmc/algorithms/sampling/nfmc/imh.py,
+`FixedIMH`): all iterations run inside `nfmc_flow_mh_steps_f32` with the per-chain log q(x) cached on
+the device (imh.py:214,233)."""
+import time
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+from tqdm import tqdm
+
+from .. import hip
+from ..containers import MCMCOutput, NFMCKernel, NFMCParameters, Sampler
+from .common import Run, chunks, resolve_target
+from .jump import flow_is_native, launch_flow_mh, split_flow_mh
+
+
+@dataclass
+class IMHKernel(NFMCKernel):
+    pass
+
+
+@dataclass
+class IMHParameters(NFMCParameters):
+    train_distribution: str = 'uniform'
+    adaptation_dropoff: float = 0.9999
+    warmup_fit_kwargs: dict = None
+
+    def __post_init__(self):
+        super().__post_init__()
+        if self.train_distribution not in ['bounded_geom_approx', 'bounded_geom', 'uniform']:
+            raise ValueError
+        if self.warmup_fit_kwargs is None:
+            self.warmup_fit_kwargs = {
+                'early_stopping': True,
+                'early_stopping_threshold': 50,
+                'keep_best_weights': True,
+                'n_samples': 1,
+                'n_epochs': 500,
+                'lr': 0.05,
+                'check_for_divergences': True
+            }
+
+
+class AbstractIMH(Sampler):
+    def __init__(self, event_shape, target, kernel: Optional[IMHKernel] = None,
+                 params: Optional[IMHParameters] = None):
+        if kernel is None:
+            kernel = IMHKernel(event_shape)
+        if params is None:
+            params = IMHParameters()
+        super().__init__(event_shape, target, kernel, params)
+
+    def warmup(self, x0, show_progress: bool = True, time_limit_seconds=None) -> MCMCOutput:
+        """imh.py:60-75: variational fit of the flow to the target, then one flow sample as state."""
+        self.kernel.flow.variational_fit(lambda v: -self.target(v), **self.params.warmup_fit_kwargs,
+                                         show_progress=show_progress, time_limit_seconds=time_limit_seconds)
+        out = MCMCOutput(event_shape=tuple(x0.shape[1:]), store_samples=self.params.store_samples)
+        out.running_samples.add(self.kernel.flow.sample(x0.shape[0]).detach())
+        return out
+
+    @property
+    def name(self):
+        return "Abstract IMH"
+
+
+class FixedIMH(AbstractIMH):
+    @property
+    def name(self):
+        return "Fixed IMH"
+
+    def sample(self, x0, show_progress: bool = True, time_limit_seconds=None) -> MCMCOutput:
+        """imh.py:200-255 on the device."""
+        run = Run(self, x0)
+        n, d, event_shape = run.n, run.d, run.event_shape
+        out = MCMCOutput(event_shape, store_samples=self.params.store_samples)
+        flow = self.kernel.flow
+        T = int(self.params.n_iterations)
+        pot = resolve_target(self.target, event_shape)
+        fused = pot is not None and flow_is_native(flow)
+        buf = torch.empty(T, n, d, dtype=torch.float32, device=run.dev) if (self.params.store_samples and T > 0) else None
+        logq = torch.empty(n, dtype=torch.float32, device=run.dev)
+        t0 = time.time()
+        done = 0
+        limit = hip.MAX_STEPS_PER_CALL if (time_limit_seconds is None and not show_progress) else 16
+        bar = tqdm(total=T, desc=self.name, disable=not show_progress)
+        if not fused:
+            logq.copy_(flow.log_prob(run.x.reshape(n, *event_shape)).detach().to(run.dev, torch.float32))  # imh.py:214
+        while done < T:
+            if time_limit_seconds is not None:
+                run.sync()
+                if time.time() - t0 >= time_limit_seconds:
+                    break
+            k = min(limit, T - done) if fused else 1
+            view = buf[done:done + k] if buf is not None else None
+            if fused:
+                launch_flow_mh(run, flow, pot, logq, k, done, done > 0, True, run.stats.struct(), view)
+            else:
+                split_flow_mh(run, flow, self.target, event_shape, done, True, run.stats.struct(), logq=logq)
+                if view is not None:
+                    view[0].copy_(run.x)
+            done += k
+            bar.update(k)
+        bar.close()
+        run.sync()
+        cnt = run.stats.counters.cpu()
+        st = out.statistics
+        st.update_counters(n_target_calls=2 * n * done, n_accepted_trajectories=int(cnt[hip.CNT_ACCEPTED]),
+                           n_attempted_trajectories=int(cnt[hip.CNT_ATTEMPTED]))
+        st.n_nonfinite_log_ratios = int(cnt[hip.CNT_NONFINITE])
+        st.absorb_device_sums(run.stats.sum_x.reshape(event_shape), run.stats.sum_x2.reshape(event_shape), n * done)
+        if buf is not None and done > 0:
+            out.running_samples.add(buf[:done].reshape(done, n, *event_shape))
+        out.running_samples.last_sample = run.x.reshape(n, *event_shape).clone()
+        st.update_elapsed_time(time.time() - t0)
+        out.kernel = self.kernel
+        if run.shard is not None:
+            run.shard.merge_statistics(st)
+        return out

@@ -1,0 +1,291 @@
+"""Jump NFMC: K inner MCMC transitions, then one independent-MH "jump" proposed by the flow
+(nfmc/algorithms/sampling/nfmc/jump.py).  On the device an outer iteration is two kinds of launch:
+the fused inner kernel (K transitions, state in registers) and `nfmc_flow_mh_steps_f32`
+(flow.sample + flow.log_prob + 2 target calls + MH test + masked update + moments in one kernel).
+"""
+import ctypes as C
+import time
+from copy import deepcopy
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+from tqdm import tqdm
+
+from .. import hip
+from ..containers import MCMCKernel, MCMCOutput, MCMCParameters, MCMCStatistics, NFMCKernel, NFMCParameters, Sampler
+from ..flows import RealNVP
+from ..tuning import train_val_split
+from ..util import metropolis_acceptance_log_ratio
+from .common import Run, chunks, resolve_target
+from .mcmc import HMC, MALA, UHMC, ULA
+
+
+@dataclass
+class JumpNFMCParameters(NFMCParameters):
+    adjusted_jumps: bool = True
+    fit_nf: bool = False
+    warmup_fit_kwargs: dict = None
+    n_jumps_before_training: int = 10
+
+    def __post_init__(self):
+        super().__post_init__()
+        if self.warmup_fit_kwargs is None:
+            self.warmup_fit_kwargs = {
+                'early_stopping': True,
+                'early_stopping_threshold': 50,
+                'keep_best_weights': True,
+                'n_samples': 1,
+                'n_epochs': 500,
+                'lr': 0.05
+            }
+
+
+@dataclass
+class JumpNFMCStatistics(MCMCStatistics):
+    n_accepted_jumps: int = 0
+    n_attempted_jumps: int = 0
+
+    @property
+    def jump_acceptance_rate(self):
+        if self.n_attempted_jumps == 0:
+            return torch.nan
+        return self.n_accepted_jumps / self.n_attempted_jumps
+
+    def update_counters(self, n_accepted_jumps: int = 0, n_attempted_jumps: int = 0, **kwargs):
+        super().update_counters(**kwargs)
+        self.n_accepted_jumps = int(self.n_accepted_jumps + n_accepted_jumps)
+        self.n_attempted_jumps = int(self.n_attempted_jumps + n_attempted_jumps)
+
+    def __repr__(self):
+        return (f"MCMC acc-rate: {self.acceptance_rate:.2f}, "
+                f"Jump acc-rate: {self.jump_acceptance_rate:.2f}, "
+                f"kcalls/s: {self.calls_per_second / 1000:.2f}, "
+                f"kgrads/s: {self.grads_per_second / 1000:.2f}, "
+                f"divergences: {self.n_divergences}")
+
+    def as_dict(self):
+        return {**super().as_dict(), 'jump_acceptance_rate': self.jump_acceptance_rate}
+
+
+class JumpNFMCOutput(MCMCOutput):
+    def __init__(self, event_shape, *args, **kwargs):
+        kwargs['statistics'] = JumpNFMCStatistics(event_shape)
+        super().__init__(event_shape, *args, **kwargs)
+
+
+def flow_is_native(flow) -> bool:
+    """True when the flow is the build's RealNVP within the fused kernels' limits."""
+    bij = getattr(flow, 'bijection', None)
+    if not isinstance(bij, RealNVP):
+        return False
+    lim = hip.limits()
+    return bij.d <= lim.max_d_flow and bij.n_hidden <= lim.max_hidden_valu
+
+
+def launch_flow_mh(run: Run, flow, pot, logq, k, step0, cached, adjusted, stats_struct, samples=None,
+                   masks_out=None, log_ratio_out=None):
+    a = hip.NfmcFlowMhArgs()
+    st, _keep = flow.bijection.packed(run.dev)
+    a.x, a.logq, a.n, a.n_steps = hip.ptr(run.x), hip.ptr(logq), run.n, k
+    a.logq_cached = 1 if cached else 0
+    a.adjusted = 1 if adjusted else 0
+    a.flow = st
+    a.pot = pot.descriptor(run.dev)
+    a.rng = run.rng(step0, k, adjusted=adjusted)
+    a.stats = stats_struct
+    a.samples = hip.ptr(samples) if samples is not None else None
+    a.masks_out = hip.ptr(masks_out, torch.uint8) if masks_out is not None else None
+    a.log_ratio_out = hip.ptr(log_ratio_out) if log_ratio_out is not None else None
+    hip.check(hip.lib().nfmc_flow_mh_steps_f32(C.byref(a), hip.stream()), 'nfmc_flow_mh_steps_f32')
+
+
+def split_flow_mh(run: Run, flow, target, event_shape, step, adjusted, stats_struct, logq=None):
+    """One flow-proposal MH transition for an arbitrary target / foreign flow object
+    (jump.py:205-231, imh.py:221-233): flow passes through the flow's own API, target calls in torch on
+    the GPU, test + masked update + moments in nfmc_mh_accept_select_f32."""
+    n, d = run.n, run.d
+    with torch.no_grad():
+        if flow_is_native(flow):
+            rng = hip.make_rng(run.seed, run.chain_offset, step)
+            if run.replay is not None:
+                nz, un = run.replay.take(1, with_uniforms=adjusted)
+                x_prime, ld = flow.bijection.inverse(nz[0].reshape(n, *event_shape))
+                zz = nz[0]
+                f_xp = (-0.5 * (zz * zz).sum(-1) - 0.5 * d * 1.8378770664093453) - ld
+                unif = un[0].contiguous() if un is not None else None
+            else:
+                x_prime, f_xp = flow.sample(n, return_log_prob=True, rng=rng)
+                unif = None
+        else:
+            x_prime, f_xp = flow.sample(n, return_log_prob=True)
+            unif = None
+        x_prime = x_prime.detach().to(run.dev, torch.float32).reshape(n, d).contiguous()
+        f_xp = f_xp.detach().to(run.dev, torch.float32).contiguous()
+        lr = None
+        f_x = None
+        if adjusted:
+            u_x = target(run.x.reshape(n, *event_shape)).reshape(-1)
+            u_xp = target(x_prime.reshape(n, *event_shape)).reshape(-1)
+            f_x = logq if logq is not None else flow.log_prob(run.x.reshape(n, *event_shape))
+            f_x = f_x.detach().to(run.dev, torch.float32).contiguous()
+            lr = metropolis_acceptance_log_ratio(-u_x, -u_xp, f_x, f_xp).float().contiguous()
+    st = hip.NfmcSelectArgs()
+    st.x, st.x_prime, st.n, st.d = hip.ptr(run.x), hip.ptr(x_prime), n, d
+    st.log_ratio = hip.ptr(lr) if lr is not None else None
+    st.uniforms = hip.ptr(unif) if unif is not None else None
+    st.n_carry = 0
+    if logq is not None and adjusted:
+        st.n_carry = 1
+        st.carry[0] = hip.ptr(logq)
+        st.carry_prime[0] = hip.ptr(f_xp)
+    st.rng = hip.make_rng(run.seed, run.chain_offset, step)
+    st.rng_tag = hip.TAG_JUMP
+    st.stats = stats_struct
+    st.mask_out = None
+    hip.check(hip.lib().nfmc_mh_accept_select_f32(C.byref(st), hip.stream()), 'nfmc_mh_accept_select_f32')
+
+
+class JumpNFMC(Sampler):
+    """Requires a flow with an efficient inverse (and forward, for adjusted jumps)."""
+
+    def __init__(self, event_shape, target, inner_sampler: Sampler, kernel: NFMCKernel = None,
+                 params: JumpNFMCParameters = None):
+        if kernel is None:
+            kernel = NFMCKernel(event_shape)
+        if params is None:
+            params = JumpNFMCParameters()
+        super().__init__(event_shape, target, kernel, params)
+        self.inner_sampler = inner_sampler
+
+    @property
+    def name(self):
+        return 'Jump MCMC'
+
+    def warmup(self, x0, show_progress: bool = True, time_limit_seconds=None) -> MCMCOutput:
+        """jump.py:104-154: tune the inner sampler, then MLE-fit the flow on its samples (rollback on ValueError)."""
+        inner_limit = 0.7 * time_limit_seconds if time_limit_seconds is not None else None
+        t0 = time.time()
+        self.inner_sampler.params.store_samples = True
+        self.inner_sampler.shard = self.shard
+        warmup_output = self.inner_sampler.warmup(x0, show_progress=show_progress, time_limit_seconds=inner_limit)
+        x_train, x_val = train_val_split(warmup_output.samples_device, train_pct=self.params.train_pct,
+                                         max_train_size=self.params.max_train_size,
+                                         max_val_size=self.params.max_val_size, shard=self.shard)
+        flow_params = deepcopy(self.kernel.flow.state_dict())
+        fit_limit = time_limit_seconds - (time.time() - t0) if time_limit_seconds is not None else None
+        try:
+            self.kernel.flow.fit(x_train=x_train, x_val=x_val,
+                                 **{**self.params.flow_fit_kwargs,
+                                    **dict(show_progress=show_progress, time_limit_seconds=fit_limit)})
+        except ValueError:
+            self.kernel.flow.load_state_dict(flow_params)
+        return warmup_output
+
+    def sample(self, x0, show_progress: bool = True, time_limit_seconds=None) -> MCMCOutput:
+        """jump.py:156-246 on the device."""
+        inner = self.inner_sampler
+        if not inner.params.store_samples:
+            raise ValueError("Inner sampler in jump HMC must store samples")
+        run = Run(self, x0)
+        n, d, event_shape = run.n, run.d, run.event_shape
+        out = JumpNFMCOutput(event_shape, store_samples=self.params.store_samples)
+        flow = self.kernel.flow
+        T, K = int(self.params.n_iterations), int(inner.params.n_iterations)
+        pot = resolve_target(self.target, event_shape, getattr(inner, 'fuse', 'auto'))
+        fused = pot is not None and flow_is_native(flow)
+        inner._cur_run = run
+
+        buf = torch.empty(T * (K + 1), n, d, dtype=torch.float32, device=run.dev) if self.params.store_samples else None
+        fit_buf = torch.empty(K, n, d, dtype=torch.float32, device=run.dev) if (self.params.fit_nf and buf is None) else None
+        logq = torch.empty(n, dtype=torch.float32, device=run.dev)
+        jump_counters = torch.zeros(hip.CNT_WORDS, dtype=torch.int64, device=run.dev)
+        jstats = run.stats.struct()
+        jstats.counters = hip.ptr(jump_counters, torch.int64)
+
+        t0 = time.time()
+        done = 0
+        bar = tqdm(range(T), desc='Jump MCMC', disable=not show_progress)
+        for i in bar:
+            if time_limit_seconds is not None:
+                run.sync()
+                if time.time() - t0 >= time_limit_seconds:
+                    break
+            base = i * (K + 1)
+            inner_view = buf[base:base + K] if buf is not None else fit_buf
+            # ---- K inner transitions (jump.py:178)
+            if pot is not None:
+                for off, k in chunks(K):
+                    view = inner_view[off:off + k] if inner_view is not None else None
+                    inner._launch(run, pot, k, base + off, view)
+            else:
+                for off in range(K):
+                    inner._split_step(run, base + off, inner_view[off:off + 1] if inner_view is not None else None)
+            # ---- optional refit on this iteration's inner samples (jump.py:193-201)
+            if self.params.fit_nf and i >= self.params.n_jumps_before_training:
+                x_train, x_val = train_val_split(inner_view.reshape(K, n, *event_shape),
+                                                 train_pct=self.params.train_pct,
+                                                 max_train_size=self.params.max_train_size,
+                                                 max_val_size=self.params.max_val_size, shard=self.shard)
+                flow.fit(x_train=x_train, x_val=x_val, **self.params.flow_fit_kwargs)
+            # ---- the jump (jump.py:205-243)
+            jview = buf[base + K:base + K + 1] if buf is not None else None
+            if fused:
+                launch_flow_mh(run, flow, pot, logq, 1, base + K, False, self.params.adjusted_jumps, jstats, jview)
+            else:
+                split_flow_mh(run, flow, self.target, event_shape, base + K, self.params.adjusted_jumps, jstats)
+                if jview is not None:
+                    jview[0].copy_(run.x)
+            done = i + 1
+            if show_progress:
+                run.sync()
+                bar.set_postfix_str(f'acc {int(run.stats.counters[hip.CNT_ACCEPTED])}/'
+                                    f'{int(run.stats.counters[hip.CNT_ATTEMPTED])}')
+        run.sync()
+        inner._cur_run = None
+        cnt = run.stats.counters.cpu()
+        jc = jump_counters.cpu()
+        calls, grads = inner._counts(n, K * done)
+        st = out.statistics
+        st.update_counters(n_accepted_trajectories=int(cnt[hip.CNT_ACCEPTED]),
+                           n_attempted_trajectories=int(cnt[hip.CNT_ATTEMPTED]), n_divergences=0,
+                           n_target_calls=calls + (2 * n * done if self.params.adjusted_jumps else 0),
+                           n_target_gradient_calls=grads,
+                           n_accepted_jumps=int(jc[hip.CNT_ACCEPTED]), n_attempted_jumps=n * done)
+        st.n_nonfinite_log_ratios = int(cnt[hip.CNT_NONFINITE]) + int(jc[hip.CNT_NONFINITE])
+        st.absorb_device_sums(run.stats.sum_x.reshape(event_shape), run.stats.sum_x2.reshape(event_shape),
+                              n * done * (K + 1))
+        if buf is not None and done > 0:
+            out.running_samples.add(buf[:done * (K + 1)].reshape(done * (K + 1), n, *event_shape))
+        out.running_samples.last_sample = run.x.reshape(n, *event_shape).clone()
+        st.update_elapsed_time(time.time() - t0)
+        out.kernel = self.kernel
+        if run.shard is not None:
+            run.shard.merge_statistics(st)
+        return out
+
+
+def _make(inner_cls):
+    class _Jump(JumpNFMC):
+        def __init__(self, event_shape, target, kernel: NFMCKernel = None, params: JumpNFMCParameters = None,
+                     inner_kernel: MCMCKernel = None, inner_params: MCMCParameters = None):
+            super().__init__(event_shape, target, inner_cls(event_shape, target, inner_kernel, inner_params),
+                             kernel, params)
+
+    return _Jump
+
+
+class JumpHMC(_make(HMC)):
+    pass
+
+
+class JumpUHMC(_make(UHMC)):
+    pass
+
+
+class JumpMALA(_make(MALA)):
+    pass
+
+
+class JumpULA(_make(ULA)):
+    pass

@@ -1,0 +1,409 @@
+"""Inner MCMC samplers: Langevin (MALA/ULA) and HMC/UHMC, with the reference's kernel/parameter
+dataclasses (nfmc/algorithms/sampling/mcmc/{base,langevin,hmc}.py).
+
+`sample()` runs all `n_iterations` transitions inside HIP kernels (nfmc_mala_steps_f32 /
+nfmc_hmc_steps_f32) when the target is a closed-form potential; `propose()` -- the reference's plug-in
+seam (mcmc/base.py:27-34) -- stays callable and serves arbitrary Python targets: U and grad U come from
+torch autograd on the GPU, proposal / log-ratio / accept-select / moments from the HIP kernels.
+"""
+import ctypes as C
+import math
+import time
+from copy import deepcopy
+from dataclasses import dataclass
+from typing import Any, Dict, Optional, Tuple, Union
+
+import torch
+from tqdm import tqdm
+
+from .. import hip
+from ..containers import MCMCKernel, MCMCOutput, MCMCParameters, Sampler
+from ..tuning import DualAveraging, DualAveragingParams
+from .common import Run, chunks, imd_tensor, resolve_target
+
+
+@dataclass
+class MetropolisKernel(MCMCKernel):
+    event_size: int
+    inv_mass_diag: torch.Tensor = None
+    step_size: float = 0.01
+    da: DualAveraging = None
+    da_params: DualAveragingParams = None
+
+    def __post_init__(self):
+        super().__post_init__()
+        if self.inv_mass_diag is None:
+            self.inv_mass_diag = torch.ones(self.event_size)
+        elif tuple(self.inv_mass_diag.shape) != (self.event_size,):
+            raise ValueError
+        if self.da_params is None:
+            self.da_params = DualAveragingParams()
+        if self.da is None:
+            self.da = DualAveraging(self.step_size, self.da_params)
+
+
+@dataclass
+class MetropolisParameters(MCMCParameters):
+    tune_inv_mass_diag: bool = True
+    tune_step_size: bool = True
+    adjustment: bool = True
+    imd_adjustment: float = 1e-3
+
+
+@dataclass
+class LangevinKernel(MetropolisKernel):
+    event_size: int
+    step_size: Optional[float] = None
+
+    def __post_init__(self):
+        if self.step_size is None:
+            self.step_size = self.event_size ** (-1 / 3)  # langevin.py:16-18
+        super().__post_init__()
+
+    def __repr__(self):
+        return (f'log step: {math.log(self.step_size):.2f}, '
+                f'mass norm: {torch.max(torch.abs(self.inv_mass_diag)):.2f}')
+
+
+@dataclass
+class LangevinParameters(MetropolisParameters):
+    pass
+
+
+@dataclass
+class HMCKernel(MetropolisKernel):
+    event_size: int
+    n_leapfrog_steps: int = 20
+
+    def __repr__(self):
+        return (f'log step: {math.log(self.step_size):.2f}, '
+                f'leapfrogs: {self.n_leapfrog_steps}, '
+                f'mass norm: {torch.max(torch.abs(self.inv_mass_diag)):.2f}')
+
+
+@dataclass
+class HMCParameters(MetropolisParameters):
+    pass
+
+
+def _value_and_grad(target, x, event_shape):
+    """U(x), grad U(x) by autograd on the GPU (the reference's recipe, langevin.py:66-70)."""
+    with torch.enable_grad():
+        xr = x.detach().reshape(x.shape[0], *event_shape).clone().requires_grad_(True)
+        u = target(xr)
+        g, = torch.autograd.grad(u.sum(), xr)
+    return u.detach().reshape(-1).float().contiguous(), g.detach().reshape(x.shape).float().contiguous()
+
+
+class MCMCSampler(Sampler):
+    fuse = 'auto'  # 'auto': probe plain callables for a closed form (potentials.recognize); False: never
+
+    def __init__(self, event_shape, target, kernel: MCMCKernel, params: MCMCParameters,
+                 data_transform=lambda v: v):
+        super().__init__(event_shape, target, kernel, params)
+        self.data_transform = data_transform
+
+    @property
+    def name(self):
+        return "Generic MCMC"
+
+    def propose(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, int, int, int]:
+        raise NotImplementedError
+
+    def update_kernel(self, data: Dict[str, Any]):
+        raise NotImplementedError
+
+    # ---- fused launch of k transitions; implemented by Langevin / HMC
+    def _launch(self, run: Run, pot, k, step0, samples, masks_out=None, log_ratio_out=None):
+        raise NotImplementedError
+
+    def _counts(self, n, k):
+        raise NotImplementedError
+
+    def warmup(self, x0, show_progress: bool = True, time_limit_seconds=None) -> MCMCOutput:
+        # mcmc/base.py:39-54
+        with torch.no_grad():
+            warmup_copy = deepcopy(self)
+        warmup_copy.params.tuning_mode()
+        warmup_copy.params.n_iterations = self.params.n_warmup_iterations
+        out = warmup_copy.sample(x0, show_progress=show_progress, time_limit_seconds=time_limit_seconds)
+        self.kernel = warmup_copy.kernel
+        new_params = warmup_copy.params
+        new_params.n_iterations = self.params.n_iterations
+        self.params = new_params
+        self.params.sampling_mode()
+        return out
+
+    def sample(self, x0, show_progress: bool = True, time_limit_seconds=None) -> MCMCOutput:
+        """mcmc/base.py:56-102 on the device."""
+        run = Run(self, x0)
+        step0 = 0
+        n, d = run.n, run.d
+        event_shape = run.event_shape
+        out = MCMCOutput(event_shape, store_samples=self.params.store_samples)
+        out.statistics.data_transform = self.data_transform
+        K = int(self.params.n_iterations)
+        pot = resolve_target(self.target, event_shape, self.fuse)
+        buf = torch.empty(K, n, d, dtype=torch.float32, device=run.dev) if (self.params.store_samples and K > 0) else None
+        run.stats.zero_()
+        t0 = time.time()
+        done = 0
+        label = f'{self.name} (tuning)' if self.params.tuning else self.name
+        bar = tqdm(total=K, desc=label, disable=not show_progress)
+        stepwise = self.params.tuning or pot is None
+        limit = 1 if stepwise else (hip.MAX_STEPS_PER_CALL if time_limit_seconds is None and not show_progress else 32)
+        while done < K:
+            if time_limit_seconds is not None:
+                run.sync()
+                if time.time() - t0 > time_limit_seconds:
+                    break
+            k = min(limit, K - done)
+            view = buf[done:done + k] if buf is not None else None
+            if pot is not None:
+                mask_buf = torch.empty(k, n, dtype=torch.uint8, device=run.dev) if self.params.tuning else None
+                self._launch(run, pot, k, step0 + done, view, masks_out=mask_buf)
+                mask = mask_buf[-1].bool() if mask_buf is not None else None
+            else:
+                mask = self._split_step(run, step0 + done, view)
+            if self.params.tuning:
+                with torch.no_grad():
+                    self.update_kernel({'x': run.x.reshape(n, *event_shape), 'mask': mask})
+            done += k
+            bar.update(k)
+        bar.close()
+        run.sync()
+        cnt = run.stats.counters.cpu()
+        calls, grads = self._counts(n, done)
+        out.statistics.update_counters(n_target_calls=calls, n_target_gradient_calls=grads, n_divergences=0,
+                                       n_accepted_trajectories=int(cnt[hip.CNT_ACCEPTED]),
+                                       n_attempted_trajectories=int(cnt[hip.CNT_ATTEMPTED]))
+        out.statistics.n_nonfinite_log_ratios = int(cnt[hip.CNT_NONFINITE])
+        out.statistics.absorb_device_sums(run.stats.sum_x.reshape(event_shape), run.stats.sum_x2.reshape(event_shape),
+                                          n * done)
+        rs = out.running_samples
+        if buf is not None and done > 0:
+            rs.add(buf[:done].reshape(done, n, *event_shape))
+        rs.last_sample = run.x.reshape(n, *event_shape).clone()
+        out.statistics.update_elapsed_time(time.time() - t0)
+        out.kernel = self.kernel
+        self._cur_run = None
+        if run.shard is not None:
+            run.shard.merge_statistics(out.statistics)
+        return out
+
+    # ---- one transition through the propose() seam (arbitrary targets)
+    def _split_step(self, run: Run, step, sample_view):
+        n, d = run.n, run.d
+        self._cur_run, self._cur_step = run, step
+        x_prime, mask_or_lr, n_calls, n_grads, n_divs = self.propose(run.x)
+        st = hip.NfmcSelectArgs()
+        st.x, st.x_prime, st.n, st.d = hip.ptr(run.x), hip.ptr(x_prime), n, d
+        st.n_carry = 0
+        lr = self._last_log_ratio
+        st.log_ratio = hip.ptr(lr) if lr is not None else None
+        un = self._last_uniforms
+        st.uniforms = hip.ptr(un) if un is not None else None
+        st.rng = hip.make_rng(run.seed, run.chain_offset, step)
+        st.rng_tag = hip.TAG_ACCEPT
+        st.stats = run.stats.struct()
+        mask = torch.empty(n, dtype=torch.uint8, device=run.dev)
+        st.mask_out = hip.ptr(mask, torch.uint8)
+        hip.check(hip.lib().nfmc_mh_accept_select_f32(C.byref(st), hip.stream()), 'nfmc_mh_accept_select_f32')
+        if sample_view is not None:
+            sample_view[0].copy_(run.x)
+        return mask.bool()
+
+
+class MetropolisSampler(MCMCSampler):
+    def update_kernel(self, data: Dict[str, Any]):
+        """mcmc/base.py:142-161: EMA of the per-coordinate variance + dual-averaging step size."""
+        x = data['x']
+        mask = data['mask']
+        n_chains = x.shape[0]
+        if n_chains > 1 and self.params.tune_inv_mass_diag:
+            var = torch.var(x.flatten(1, -1), dim=0).to(self.kernel.inv_mass_diag)
+            self.kernel.inv_mass_diag = (self.params.imd_adjustment * var
+                                         + (1 - self.params.imd_adjustment) * self.kernel.inv_mass_diag)
+        if self.params.tune_step_size and self.params.adjustment:
+            acc_rate = torch.mean(mask.float())
+            error = self.kernel.da_params.target_acceptance_rate - float(acc_rate)
+            self.kernel.da.step(error)
+            self.kernel.step_size = self.kernel.da.value
+
+
+class Langevin(MetropolisSampler):
+    def __init__(self, event_shape, target, kernel: Optional[LangevinKernel] = None,
+                 params: Optional[LangevinParameters] = None):
+        if kernel is None:
+            kernel = LangevinKernel(event_size=int(torch.prod(torch.as_tensor(event_shape))))
+        if params is None:
+            params = LangevinParameters()
+        super().__init__(event_shape, target, kernel, params)
+
+    @property
+    def name(self):
+        return 'LMC'
+
+    def _counts(self, n, k):
+        per = 2 * n if self.params.adjustment else n  # langevin.py:116-120
+        return per * k, per * k
+
+    def _launch(self, run, pot, k, step0, samples, masks_out=None, log_ratio_out=None):
+        a = hip.NfmcMalaArgs()
+        a.x, a.n, a.d, a.n_steps = hip.ptr(run.x), run.n, run.d, k
+        a.step_size = float(self.kernel.step_size)
+        a.adjust = 1 if self.params.adjustment else 0
+        imd = imd_tensor(self.kernel, run.dev)
+        a.inv_mass_diag = hip.ptr(imd)
+        a.pot = pot.descriptor(run.dev)
+        a.rng = run.rng(step0, k, adjusted=self.params.adjustment)
+        a.stats = run.stats.struct()
+        a.samples = hip.ptr(samples) if samples is not None else None
+        a.masks_out = hip.ptr(masks_out, torch.uint8) if masks_out is not None else None
+        a.log_ratio_out = hip.ptr(log_ratio_out) if log_ratio_out is not None else None
+        hip.check(hip.lib().nfmc_mala_steps_f32(C.byref(a), hip.stream()), 'nfmc_mala_steps_f32')
+
+    def propose(self, x):
+        """langevin.py:61-122 for an arbitrary target: autograd U/grad U + HIP proposal and log-ratio.
+        Returns (x_prime, mask, n_calls, n_grads, n_divergences); mask is evaluated lazily by the
+        accept-select kernel when called from `sample()`."""
+        dev = hip.require_gpu()
+        n = x.shape[0]
+        xf = x.detach().to(dev, torch.float32).reshape(n, -1).contiguous()
+        d = xf.shape[1]
+        run = getattr(self, '_cur_run', None)
+        step = getattr(self, '_cur_step', 0)
+        seed = run.seed if run is not None else (self.seed or 0)
+        off = run.chain_offset if run is not None else 0
+        h = float(self.kernel.step_size)
+        imd = imd_tensor(self.kernel, dev)
+        lib = hip.lib()
+        u, g = _value_and_grad(self.target, xf, self.event_shape)
+        x_prime = torch.empty_like(xf)
+        nz = un = None
+        if run is not None and run.replay is not None:
+            nz, un = run.replay.take(1, with_uniforms=self.params.adjustment)
+        rng = hip.make_rng(seed, off, step, nz, None)
+        hip.check(lib.nfmc_langevin_propose_f32(hip.ptr(xf), hip.ptr(g), hip.ptr(imd), h, n, d, C.byref(rng),
+                                                hip.ptr(x_prime), hip.stream()), 'nfmc_langevin_propose_f32')
+        n_calls = n_grads = n
+        self._last_log_ratio = None
+        self._last_uniforms = un[0].contiguous() if un is not None else None
+        mask = torch.ones(n, dtype=torch.bool, device=dev)
+        if self.params.adjustment:
+            up, gp = _value_and_grad(self.target, x_prime, self.event_shape)
+            lr = torch.empty(n, dtype=torch.float32, device=dev)
+            hip.check(lib.nfmc_langevin_log_ratio_f32(hip.ptr(xf), hip.ptr(x_prime), hip.ptr(u), hip.ptr(up),
+                                                      hip.ptr(g), hip.ptr(gp), hip.ptr(imd), h, n, d, hip.ptr(lr),
+                                                      hip.stream()), 'nfmc_langevin_log_ratio_f32')
+            self._last_log_ratio = lr
+            n_calls += n
+            n_grads += n
+            if run is None:  # stand-alone use of the seam: evaluate the mask here
+                unif = torch.empty(n, dtype=torch.float32, device=dev)
+                hip.check(lib.nfmc_philox_uniforms_f32(C.byref(rng), hip.TAG_ACCEPT, n, hip.ptr(unif), hip.stream()),
+                          'nfmc_philox_uniforms_f32')
+                mask = torch.log(unif) < lr
+        return x_prime, mask, n_calls, n_grads, 0
+
+
+class MALA(Langevin):
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.params.adjustment = True
+
+
+class ULA(Langevin):
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.params.adjustment = False
+
+
+class HMC(MetropolisSampler):
+    def __init__(self, event_shape, target, kernel: Optional[HMCKernel] = None,
+                 params: Optional[HMCParameters] = None):
+        if kernel is None:
+            kernel = HMCKernel(event_size=int(torch.prod(torch.as_tensor(event_shape))))
+        if params is None:
+            params = HMCParameters()
+        super().__init__(event_shape, target, kernel, params)
+
+    @property
+    def name(self):
+        return "HMC"
+
+    def _counts(self, n, k):
+        grads = 2 * self.kernel.n_leapfrog_steps * n  # hmc.py:122-125
+        calls = grads + (2 * n if self.params.adjustment else 0)
+        return calls * k, grads * k
+
+    def _launch(self, run, pot, k, step0, samples, masks_out=None, log_ratio_out=None):
+        a = hip.NfmcHmcArgs()
+        a.x, a.n, a.d, a.n_steps = hip.ptr(run.x), run.n, run.d, k
+        a.step_size = float(self.kernel.step_size)
+        a.n_leapfrog = int(self.kernel.n_leapfrog_steps)
+        a.adjust = 1 if self.params.adjustment else 0
+        imd = imd_tensor(self.kernel, run.dev)
+        a.inv_mass_diag = hip.ptr(imd)
+        a.pot = pot.descriptor(run.dev)
+        a.rng = run.rng(step0, k, adjusted=self.params.adjustment)
+        a.stats = run.stats.struct()
+        a.samples = hip.ptr(samples) if samples is not None else None
+        a.masks_out = hip.ptr(masks_out, torch.uint8) if masks_out is not None else None
+        a.log_ratio_out = hip.ptr(log_ratio_out) if log_ratio_out is not None else None
+        hip.check(hip.lib().nfmc_hmc_steps_f32(C.byref(a), hip.stream()), 'nfmc_hmc_steps_f32')
+
+    def propose(self, x):
+        """hmc.py:96-126 for an arbitrary target: leapfrog with autograd gradients on the GPU."""
+        dev = hip.require_gpu()
+        n = x.shape[0]
+        xf = x.detach().to(dev, torch.float32).reshape(n, -1).contiguous()
+        d = xf.shape[1]
+        run = getattr(self, '_cur_run', None)
+        step = getattr(self, '_cur_step', 0)
+        seed = run.seed if run is not None else (self.seed or 0)
+        off = run.chain_offset if run is not None else 0
+        h = float(self.kernel.step_size)
+        m = self.kernel.inv_mass_diag.to(dev, torch.float32)
+        lib = hip.lib()
+        nz = un = None
+        if run is not None and run.replay is not None:
+            nz, un = run.replay.take(1, with_uniforms=self.params.adjustment)
+            noise = nz[0]
+        else:
+            noise = torch.empty(n, d, dtype=torch.float32, device=dev)
+            rng = hip.make_rng(seed, off, step)
+            hip.check(lib.nfmc_philox_normals_f32(C.byref(rng), hip.TAG_NOISE, n, d, hip.ptr(noise), hip.stream()),
+                      'nfmc_philox_normals_f32')
+        p = noise * (1 / m.sqrt())
+        p0 = p
+        q = xf
+        for _ in range(self.kernel.n_leapfrog_steps):
+            p = p - h / 2 * _value_and_grad(self.target, q, self.event_shape)[1]
+            q = q + h * (p * m)
+            p = p - h / 2 * _value_and_grad(self.target, q, self.event_shape)[1]
+        L = self.kernel.n_leapfrog_steps
+        n_grads = 2 * L * n
+        n_calls = n_grads
+        self._last_log_ratio = None
+        self._last_uniforms = un[0].contiguous() if un is not None else None
+        mask = torch.ones(n, dtype=torch.bool, device=dev)
+        if self.params.adjustment:
+            with torch.no_grad():
+                h0 = self.target(xf.reshape(n, *self.event_shape)).reshape(-1) + 0.5 * (p0 ** 2 * m).sum(-1)
+                h1 = self.target(q.reshape(n, *self.event_shape)).reshape(-1) + 0.5 * (p ** 2 * m).sum(-1)
+            self._last_log_ratio = (h0 - h1).float().contiguous()
+            n_calls += 2 * n
+            if run is None:
+                unif = torch.empty(n, dtype=torch.float32, device=dev)
+                rng = hip.make_rng(seed, off, step)
+                hip.check(lib.nfmc_philox_uniforms_f32(C.byref(rng), hip.TAG_ACCEPT, n, hip.ptr(unif), hip.stream()),
+                          'nfmc_philox_uniforms_f32')
+                mask = torch.log(unif) < self._last_log_ratio
+        return q.contiguous(), mask, n_calls, n_grads, 0
+
+
+class UHMC(HMC):
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.params.adjustment = False

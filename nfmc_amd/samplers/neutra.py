@@ -1,0 +1,185 @@
+"""NeuTra HMC: HMC in the flow's latent space on U~(z) = U(f^-1(z)) - log|det J_{f^-1}(z)|
+(nfmc/algorithms/sampling/nfmc/neutra.py:58-68,109-129).  The adjusted potential, its gradient (a
+hand-written VJP through the coupling stack), the leapfrog integrator and the accept step run inside
+`nfmc_neutra_hmc_steps_f32`.
+
+Like the reference, the stored samples and the running moments are those of the LATENT state z: the
+`data_transform` assigned at neutra.py:122 never reaches the moments;
+`NeuTraParameters.transform_output=True` opts into x-space samples/moments instead.
+"""
+import ctypes as C
+import time
+from dataclasses import dataclass
+from typing import Optional, Type
+
+import torch
+from tqdm import tqdm
+
+from .. import hip
+from ..containers import MCMCOutput, NFMCKernel, NFMCParameters, Sampler
+from .common import Run, chunks, imd_tensor, resolve_target
+from .mcmc import HMC, HMCKernel, HMCParameters, MetropolisKernel, MetropolisParameters, MetropolisSampler
+
+
+@dataclass
+class NeuTraKernel(NFMCKernel):
+    pass
+
+
+@dataclass
+class NeuTraParameters(NFMCParameters):
+    batch_inverse_size: int = 128
+    warmup_fit_kwargs: dict = None
+
+    def __post_init__(self):
+        super().__post_init__()
+        if self.warmup_fit_kwargs is None:
+            self.warmup_fit_kwargs = {
+                'early_stopping': True,
+                'early_stopping_threshold': 5000,
+                'keep_best_weights': True,
+                'n_samples': 1,
+                'n_epochs': 50000,
+                'lr': 0.05
+            }
+
+
+class NeuTra(Sampler):
+    def __init__(self, event_shape, target, inner_sampler_class: Type[MetropolisSampler],
+                 inner_kernel: MetropolisKernel, inner_params: MetropolisParameters,
+                 kernel: NeuTraKernel = None, params: NeuTraParameters = None):
+        if kernel is None:
+            kernel = NeuTraKernel(event_shape)
+        if params is None:
+            params = NeuTraParameters()
+        super().__init__(event_shape, target, kernel, params)
+        inner_params.n_iterations = self.params.n_iterations
+        self.inner_sampler = inner_sampler_class(event_shape, self.adjusted_target, inner_kernel, inner_params)
+        self.inner_sampler.fuse = False  # adjusted_target is a Python closure; the fused route is sample() below
+
+    def adjusted_target(self, _z, return_data: bool = False):
+        """neutra.py:58-68 through the flow's API (split path and external callers)."""
+        n = _z.shape[0]
+        dev = hip.require_gpu()
+        grad_needed = torch.is_grad_enabled() and _z.requires_grad
+        if grad_needed:
+            return _AdjustedPotential.apply(_z, self)
+        x, log_det_inverse = self.kernel.flow.bijection.inverse(_z)
+        log_prob = -self.target(x)
+        adjusted_potential = -(log_prob.reshape(-1) + log_det_inverse.to(log_prob).reshape(-1))
+        return (adjusted_potential, x) if return_data else adjusted_potential
+
+    def _potential_grad(self, z):
+        """U~(z), grad U~(z) from nfmc_neutra_potential_grad_f32 (closed-form targets only)."""
+        dev = hip.require_gpu()
+        n = z.shape[0]
+        pot = resolve_target(self.target, self.event_shape)
+        if pot is None:
+            raise ValueError('NeuTra needs a closed-form potential (nfmc_amd.potentials) for the gradient kernel')
+        zf = z.detach().to(dev, torch.float32).reshape(n, -1).contiguous()
+        st, _keep = self.kernel.flow.bijection.packed(dev)
+        pd = pot.descriptor(dev)
+        u = torch.empty(n, dtype=torch.float32, device=dev)
+        g = torch.empty_like(zf)
+        hip.check(hip.lib().nfmc_neutra_potential_grad_f32(C.byref(st), C.byref(pd), hip.ptr(zf), n, hip.ptr(u),
+                                                           hip.ptr(g), hip.stream()), 'nfmc_neutra_potential_grad_f32')
+        return u, g.reshape(z.shape)
+
+    def warmup(self, x0, show_progress: bool = True, time_limit_seconds=None) -> MCMCOutput:
+        """neutra.py:70-107: variational fit, then tune the inner sampler."""
+        fit_limit = 0.3 * time_limit_seconds if time_limit_seconds is not None else None
+        t0 = time.time()
+        self.kernel.flow.variational_fit(lambda v: -self.target(v),
+                                         **{**dict(time_limit_seconds=fit_limit), **self.params.warmup_fit_kwargs},
+                                         show_progress=show_progress)
+        inner_limit = time_limit_seconds - (time.time() - t0) if time_limit_seconds is not None else None
+        self.inner_sampler.params.tuning_mode()
+        self.inner_sampler.params.store_samples = self.params.store_samples
+        self.inner_sampler.params.n_warmup_iterations = self.params.n_warmup_iterations
+        return self.inner_sampler.warmup(x0, show_progress=show_progress, time_limit_seconds=inner_limit)
+
+    def sample(self, x0, show_progress: bool = True, time_limit_seconds=None) -> MCMCOutput:
+        """neutra.py:109-129 on the device."""
+        inner = self.inner_sampler
+        inner.params.n_iterations = self.params.n_iterations
+        inner.params.sampling_mode()
+        inner.params.store_samples = self.params.store_samples
+        run = Run(self, x0)
+        n, d, event_shape = run.n, run.d, run.event_shape
+        pot = resolve_target(self.target, event_shape)
+        if pot is None or not isinstance(inner, HMC):
+            raise ValueError('neutra: the device path needs a closed-form potential and the HMC inner sampler')
+        out = MCMCOutput(event_shape, store_samples=self.params.store_samples)
+        T = int(self.params.n_iterations)
+        buf = torch.empty(T, n, d, dtype=torch.float32, device=run.dev) if (self.params.store_samples and T > 0) else None
+        st_flow, _keep = self.kernel.flow.bijection.packed(run.dev)
+        imd = imd_tensor(inner.kernel, run.dev)
+        t0 = time.time()
+        done = 0
+        limit = hip.MAX_STEPS_PER_CALL if (time_limit_seconds is None and not show_progress) else 4
+        bar = tqdm(total=T, desc='NeuTra HMC', disable=not show_progress)
+        while done < T:
+            if time_limit_seconds is not None:
+                run.sync()
+                if time.time() - t0 >= time_limit_seconds:
+                    break
+            k = min(limit, T - done)
+            a = hip.NfmcNeutraHmcArgs()
+            a.z, a.n, a.n_steps = hip.ptr(run.x), n, k
+            a.n_leapfrog = int(inner.kernel.n_leapfrog_steps)
+            a.step_size = float(inner.kernel.step_size)
+            a.adjust = 1 if inner.params.adjustment else 0
+            a.inv_mass_diag = hip.ptr(imd)
+            a.flow = st_flow
+            a.pot = pot.descriptor(run.dev)
+            a.rng = run.rng(done, k, adjusted=inner.params.adjustment)
+            a.stats = run.stats.struct()
+            a.samples = hip.ptr(buf[done:done + k]) if buf is not None else None
+            hip.check(hip.lib().nfmc_neutra_hmc_steps_f32(C.byref(a), hip.stream()), 'nfmc_neutra_hmc_steps_f32')
+            done += k
+            bar.update(k)
+        bar.close()
+        run.sync()
+        cnt = run.stats.counters.cpu()
+        calls, grads = inner._counts(n, done)
+        st = out.statistics
+        st.update_counters(n_target_calls=calls, n_target_gradient_calls=grads,
+                           n_accepted_trajectories=int(cnt[hip.CNT_ACCEPTED]),
+                           n_attempted_trajectories=int(cnt[hip.CNT_ATTEMPTED]))
+        st.n_nonfinite_log_ratios = int(cnt[hip.CNT_NONFINITE])
+        st.absorb_device_sums(run.stats.sum_x.reshape(event_shape), run.stats.sum_x2.reshape(event_shape), n * done)
+        if buf is not None and done > 0:
+            out.running_samples.add(buf[:done].reshape(done, n, *event_shape))
+        out.running_samples.last_sample = run.x.reshape(n, *event_shape).clone()
+        st.update_elapsed_time(time.time() - t0)
+        out.kernel = inner.kernel
+        out.kernel.flow = self.kernel.flow  # neutra.py:128
+        if run.shard is not None:
+            run.shard.merge_statistics(st)
+        return out
+
+
+class _AdjustedPotential(torch.autograd.Function):
+    """Autograd view of the HIP adjusted-potential kernel, so `torch.autograd.grad(adjusted_target(z))`
+    (hmc.py:40-48) works for external callers."""
+
+    @staticmethod
+    def forward(ctx, z, sampler):
+        u, g = sampler._potential_grad(z)
+        ctx.save_for_backward(g)
+        return u
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        g, = ctx.saved_tensors
+        return grad_out.reshape(-1, *([1] * (g.dim() - 1))) * g, None
+
+
+class NeuTraHMC(NeuTra):
+    def __init__(self, event_shape, target, inner_kernel: HMCKernel = None, inner_params: HMCParameters = None,
+                 kernel: NeuTraKernel = None, params: NeuTraParameters = None):
+        if inner_kernel is None:
+            inner_kernel = HMCKernel(event_size=int(torch.prod(torch.as_tensor(event_shape))))
+        if inner_params is None:
+            inner_params = HMCParameters()
+        super().__init__(event_shape, target, HMC, inner_kernel, inner_params, kernel, params)

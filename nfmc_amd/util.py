@@ -1,0 +1,63 @@
+"""Flow-spec strings and the Metropolis log-ratio (nfmc/util.py:189-215, 218-281, 382-392).
+
+Only the `realnvp` family is on this build's path; the reference's other ~59 architecture names live in
+torchflows and raise a clear error here instead of silently mapping to something else.
+"""
+import json
+from typing import Dict, List
+
+FLOW_NAMES: Dict[str, List[str]] = {
+    'realnvp': ['realnvp', 'real_nvp', 'rnvp'],  # nfmc/util.py:6
+}
+
+
+def is_flow_supported(flow_name: str):
+    return any(flow_name in v for v in FLOW_NAMES.values())
+
+
+def get_supported_normalizing_flows(synonyms: bool = True):
+    if synonyms:
+        return sorted({n for v in FLOW_NAMES.values() for n in v})
+    return sorted(FLOW_NAMES.keys())
+
+
+def parse_flow_string(flow_string: str):
+    """`<flow_name>%<json>` or `<flow_name>` (nfmc/util.py:189-215)."""
+    if flow_string is None:
+        return {'name': None, 'kwargs': {}, 'hash': hash('None')}
+    if '%' not in flow_string:
+        return {'name': flow_string, 'kwargs': {}, 'hash': hash(flow_string)}
+    flow_name = flow_string.split('%')[0]
+    kwargs = json.loads(flow_string.split('%')[1])
+    return {'name': flow_name, 'kwargs': kwargs, 'hash': hash(flow_name + str(kwargs))}
+
+
+def create_flow_object(flow_string: str, event_shape, **kwargs):
+    """nfmc/util.py:218-281,379 for the realnvp branch."""
+    from .flows import Flow, RealNVP
+    data = parse_flow_string(flow_string)
+    name = data['name']
+    kwargs.update(data['kwargs'])
+    if not isinstance(name, str):
+        raise ValueError
+    if not is_flow_supported(name):
+        raise ValueError(f"flow '{name}' is outside this build's path (supported: {get_supported_normalizing_flows()})")
+    return Flow(RealNVP(event_shape, **kwargs))
+
+
+def metropolis_acceptance_log_ratio(log_prob_target_curr, log_prob_target_prime, log_prob_proposal_curr,
+                                    log_prob_proposal_prime):
+    """log [ p(x') g(x|x') / (p(x) g(x'|x)) ]  (nfmc/util.py:382-392)."""
+    return log_prob_target_prime - log_prob_target_curr + log_prob_proposal_curr - log_prob_proposal_prime
+
+
+def get_supported_mcmc_samplers() -> List[str]:
+    return ['hmc', 'uhmc', 'ula', 'mala']
+
+
+def get_supported_nfmc_samplers() -> List[str]:
+    return ['imh', 'fixed_imh', 'jump_mala', 'jump_ula', 'jump_hmc', 'jump_uhmc', 'neutra_hmc']
+
+
+def get_supported_samplers() -> List[str]:
+    return get_supported_mcmc_samplers() + get_supported_nfmc_samplers()

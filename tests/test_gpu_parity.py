@@ -1,0 +1,434 @@
+"""GPU parity: the HIP path (through the C ABI, via the nfmc_amd samplers) against
+  (1) the golden vectors recorded from the reference itself (tests/golden), in replay mode, and
+  (2) the CPU oracle on seeded inputs, in replay and in native-Philox mode.
+
+Tolerances (fp32 path; kernels contract to FMA and use the gfx950 hardware log/exp/sin/cos):
+  states / moments   atol 3e-5 on O(1) values
+  log-ratios         atol 2e-4 (sums of d terms of O(1..30))
+  counters           exact, except chains whose |log u - log ratio| < 1e-4 (accept decision ill-conditioned)
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, golden_flow
+
+pytestmark = pytest.mark.gpu
+
+ATOL = 3e-5
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'GPU tests need a ROCm device'
+    return torch.device('cuda', 0)
+
+
+def _noise(fx):
+    nz = fx['noise/normals'] if fx['noise/normals'].ndim > 1 else None
+    un = fx['noise/uniforms'] if fx['noise/uniforms'].ndim > 1 else None
+    return nz, un
+
+
+def _check_out(out, fx, jump=False, atol=ATOL):
+    np.testing.assert_allclose(out.samples.numpy().reshape(fx['exp/samples'].shape), fx['exp/samples'], atol=atol, rtol=0)
+    np.testing.assert_allclose(out.statistics.running_first_moment.numpy(), fx['exp/first_moment'], atol=atol, rtol=0)
+    np.testing.assert_allclose(out.statistics.running_second_moment.numpy(), fx['exp/second_moment'], atol=atol, rtol=0)
+    c = fx['exp/counters']
+    st = out.statistics
+    assert (st.n_accepted_trajectories, st.n_attempted_trajectories, st.n_divergences, st.n_target_calls,
+            st.n_target_gradient_calls) == tuple(int(v) for v in c)
+    if jump:
+        assert (st.n_accepted_jumps, st.n_attempted_jumps) == tuple(int(v) for v in fx['exp/jump_counters'])
+
+
+def _amd_flow(fx, d, n_layers=2, n_hidden=None, cond_layers=2):
+    from nfmc_amd.flows import Flow, RealNVP
+    ck = {'n_layers': cond_layers}
+    if n_hidden is not None:
+        ck['n_hidden'] = n_hidden
+    f = Flow(RealNVP((d,), n_layers=n_layers, conditioner_kwargs=ck))
+    f.load_state_dict({k[len('flow/'):]: torch.from_numpy(v) for k, v in fx.items() if k.startswith('flow/')})
+    return f
+
+
+# ------------------------------------------------------------------------------------------ native streams
+def test_philox_streams_match_oracle(dev):
+    from nfmc_amd import hip
+    from oracle import philox
+    n, d, seed, step, off = 1000, 37, 0x1234567890ABCDEF, 77, 5000
+    rng = hip.make_rng(seed, off, step)
+    out = torch.empty(n, d, device=dev)
+    for tag in (philox.TAG_NOISE, philox.TAG_LATENT):
+        hip.check(hip.lib().nfmc_philox_normals_f32(C.byref(rng), tag, n, d, hip.ptr(out), hip.stream()), 'normals')
+        want = philox.normal_field(seed, np.arange(off, off + n), step, d, tag)
+        np.testing.assert_allclose(out.cpu().numpy(), want, atol=4e-6, rtol=0)
+    u = torch.empty(n, device=dev)
+    hip.check(hip.lib().nfmc_philox_uniforms_f32(C.byref(rng), philox.TAG_ACCEPT, n, hip.ptr(u), hip.stream()), 'unif')
+    np.testing.assert_array_equal(u.cpu().numpy(), philox.accept_uniform(seed, np.arange(off, off + n), step))
+    hip.check(hip.lib().nfmc_philox_uniforms_f32(C.byref(rng), philox.TAG_JUMP, n, hip.ptr(u), hip.stream()), 'unif')
+    np.testing.assert_array_equal(u.cpu().numpy(), philox.jump_uniform(seed, np.arange(off, off + n), step))
+
+
+# ------------------------------------------------------------------------------------------ golden: inner samplers
+@pytest.mark.parametrize('name,cls,pot', [('mala_d6', 'MALA', 'sumsq'), ('mala_d7_mass', 'MALA', 'sumsq'),
+                                          ('ula_d6', 'ULA', 'sumsq'), ('mala_funnel_d5', 'MALA', 'funnel')])
+def test_langevin_golden(dev, name, cls, pot):
+    from nfmc_amd.samplers import mcmc
+    from nfmc_amd.potentials import SumOfSquares, Funnel
+    fx = load_golden(name)
+    d = fx['x0'].shape[1]
+    target = SumOfSquares((d,)) if pot == 'sumsq' else Funnel((d,), 3.0)
+    kern = mcmc.LangevinKernel(event_size=d, step_size=float(fx['step_size']),
+                               inv_mass_diag=torch.from_numpy(fx['inv_mass_diag']))
+    s = getattr(mcmc, cls)((d,), target, kern, mcmc.LangevinParameters(n_iterations=fx['exp/samples'].shape[0]))
+    s.replay = _noise(fx)
+    out = s.sample(torch.from_numpy(fx['x0']), show_progress=False)
+    _check_out(out, fx)
+
+
+@pytest.mark.parametrize('name,cls', [('hmc_d5', 'HMC'), ('hmc_d6_mass', 'HMC'), ('uhmc_d5', 'UHMC')])
+def test_hmc_golden(dev, name, cls):
+    from nfmc_amd.samplers import mcmc
+    from nfmc_amd.potentials import SumOfSquares
+    fx = load_golden(name)
+    d = fx['x0'].shape[1]
+    kern = mcmc.HMCKernel(event_size=d, step_size=float(fx['step_size']), n_leapfrog_steps=int(fx['n_leapfrog']),
+                          inv_mass_diag=torch.from_numpy(fx['inv_mass_diag']))
+    s = getattr(mcmc, cls)((d,), SumOfSquares((d,)), kern, mcmc.HMCParameters(n_iterations=fx['exp/samples'].shape[0]))
+    s.replay = _noise(fx)
+    out = s.sample(torch.from_numpy(fx['x0']), show_progress=False)
+    _check_out(out, fx)
+
+
+def test_langevin_golden_python_callable_split_path(dev):
+    """Arbitrary Python target (fuse disabled): autograd U/grad U + HIP proposal/log-ratio/select kernels."""
+    from nfmc_amd.samplers import mcmc
+    fx = load_golden('mala_d7_mass')
+    d = fx['x0'].shape[1]
+    kern = mcmc.LangevinKernel(event_size=d, step_size=float(fx['step_size']),
+                               inv_mass_diag=torch.from_numpy(fx['inv_mass_diag']))
+    s = mcmc.MALA((d,), lambda x: torch.sum(x ** 2, dim=-1), kern,
+                  mcmc.LangevinParameters(n_iterations=fx['exp/samples'].shape[0]))
+    s.fuse = False
+    s.replay = _noise(fx)
+    out = s.sample(torch.from_numpy(fx['x0']), show_progress=False)
+    _check_out(out, fx)
+
+
+def test_hmc_golden_python_callable_split_path(dev):
+    from nfmc_amd.samplers import mcmc
+    fx = load_golden('hmc_d6_mass')
+    d = fx['x0'].shape[1]
+    kern = mcmc.HMCKernel(event_size=d, step_size=float(fx['step_size']), n_leapfrog_steps=int(fx['n_leapfrog']),
+                          inv_mass_diag=torch.from_numpy(fx['inv_mass_diag']))
+    s = mcmc.HMC((d,), lambda x: torch.sum(x ** 2, dim=-1), kern, mcmc.HMCParameters(n_iterations=fx['exp/samples'].shape[0]))
+    s.fuse = False
+    s.replay = _noise(fx)
+    out = s.sample(torch.from_numpy(fx['x0']), show_progress=False)
+    _check_out(out, fx)
+
+
+# ------------------------------------------------------------------------------------------ golden: flow samplers
+def test_jump_mala_golden(dev):
+    from nfmc_amd.samplers import jump, mcmc
+    from nfmc_amd.containers import NFMCKernel
+    from nfmc_amd.potentials import SumOfSquares
+    fx = load_golden('jump_mala_d6')
+    d = 6
+    s = jump.JumpMALA((d,), SumOfSquares((d,)), NFMCKernel((d,), flow=_amd_flow(fx, d)),
+                      jump.JumpNFMCParameters(n_iterations=int(fx['n_outer'])),
+                      mcmc.LangevinKernel(event_size=d, step_size=float(fx['step_size'])),
+                      mcmc.LangevinParameters(n_iterations=int(fx['n_inner'])))
+    s.replay = _noise(fx)
+    out = s.sample(torch.from_numpy(fx['x0']), show_progress=False)
+    _check_out(out, fx, jump=True)
+
+
+def test_jump_hmc_golden(dev):
+    from nfmc_amd.samplers import jump, mcmc
+    from nfmc_amd.containers import NFMCKernel
+    from nfmc_amd.potentials import SumOfSquares
+    fx = load_golden('jump_hmc_d8')
+    d = 8
+    flow = _amd_flow(fx, d, int(fx['flow_n_layers']), int(fx['flow_n_hidden']), int(fx['flow_cond_layers']))
+    s = jump.JumpHMC((d,), SumOfSquares((d,)), NFMCKernel((d,), flow=flow),
+                     jump.JumpNFMCParameters(n_iterations=int(fx['n_outer'])),
+                     mcmc.HMCKernel(event_size=d, step_size=float(fx['step_size']), n_leapfrog_steps=int(fx['n_leapfrog'])),
+                     mcmc.HMCParameters(n_iterations=int(fx['n_inner'])))
+    s.replay = _noise(fx)
+    out = s.sample(torch.from_numpy(fx['x0']), show_progress=False)
+    _check_out(out, fx, jump=True)
+
+
+@pytest.mark.parametrize('name,d,nl', [('imh_d6', 6, 2), ('imh_d7_odd', 7, 3)])
+def test_imh_golden(dev, name, d, nl):
+    from nfmc_amd.samplers import imh
+    from nfmc_amd.potentials import SumOfSquares
+    fx = load_golden(name)
+    s = imh.FixedIMH((d,), SumOfSquares((d,)), imh.IMHKernel((d,), flow=_amd_flow(fx, d, nl)),
+                     imh.IMHParameters(n_iterations=int(fx['n_iterations'])))
+    s.replay = _noise(fx)
+    out = s.sample(torch.from_numpy(fx['x0']), show_progress=False)
+    _check_out(out, fx)
+
+
+def test_imh_golden_python_callable_split_path(dev):
+    from nfmc_amd.samplers import imh
+    fx = load_golden('imh_d6')
+    d = 6
+    s = imh.FixedIMH((d,), lambda x: torch.sum(x ** 4, dim=-1) ** 0.5 * 0 + torch.sum(x ** 2, dim=-1),
+                     imh.IMHKernel((d,), flow=_amd_flow(fx, d, 2)), imh.IMHParameters(n_iterations=int(fx['n_iterations'])))
+    s.replay = _noise(fx)
+    import nfmc_amd.samplers.imh as m
+    orig = m.resolve_target
+    m.resolve_target = lambda *a, **k: None   # force the split path
+    try:
+        out = s.sample(torch.from_numpy(fx['x0']), show_progress=False)
+    finally:
+        m.resolve_target = orig
+    _check_out(out, fx)
+
+
+# ------------------------------------------------------------------------------------------ flow known answers
+FLOW_CASES = [(6, 2, None, 2), (7, 3, 5, 3), (25, 2, None, 2), (64, 2, None, 2), (64, 4, 16, 2), (100, 3, 7, 1),
+              (8, 1, 32, 2), (256, 2, 4, 2), (2, 2, 4, 2), (3, 5, 9, 2)]
+
+
+@pytest.mark.parametrize('d,nl,nh,cl', FLOW_CASES)
+def test_flow_matches_oracle_and_known_answers(dev, d, nl, nh, cl):
+    from nfmc_amd.flows import Flow, RealNVP
+    from oracle import flow as oflow
+    ck = {'n_layers': cl}
+    if nh is not None:
+        ck['n_hidden'] = nh
+    torch.manual_seed(d * 100 + nl)
+    of = oflow.perturb_(oflow.Flow(oflow.RealNVP((d,), n_layers=nl, conditioner_kwargs=ck)), 7, 0.4, 0.8)
+    f = Flow(RealNVP((d,), n_layers=nl, conditioner_kwargs=ck))
+    f.load_state_dict(of.state_dict())
+    n = 333
+    x = torch.randn(n, d)
+    with torch.no_grad():
+        z_o, ld_o = of.bijection.forward(x)
+        xi_o, ldi_o = of.bijection.inverse(x)
+        lp_o = of.log_prob(x)
+    z, ld = f.bijection.forward(x)
+    np.testing.assert_allclose(z.cpu().numpy(), z_o.numpy(), atol=5e-5, rtol=1e-5)
+    np.testing.assert_allclose(ld.cpu().numpy(), ld_o.numpy(), atol=1e-4, rtol=1e-5)
+    xi, ldi = f.bijection.inverse(x)
+    np.testing.assert_allclose(xi.cpu().numpy(), xi_o.numpy(), atol=5e-5, rtol=2e-5)
+    np.testing.assert_allclose(ldi.cpu().numpy(), ldi_o.numpy(), atol=1e-4, rtol=1e-5)
+    np.testing.assert_allclose(f.log_prob(x).cpu().numpy(), lp_o.numpy(), atol=2e-4, rtol=1e-5)
+    # (1) inverse(forward(x)) == x ; (2) logdets cancel
+    xr, ldr = f.bijection.inverse(z)
+    np.testing.assert_allclose(xr.cpu().numpy(), x.numpy(), atol=5e-5, rtol=1e-5)
+    np.testing.assert_allclose((ld + ldr).cpu().numpy(), 0, atol=1e-4)
+    # (5) sample's log-prob equals log_prob of the returned x
+    xs, lq = f.sample(n, return_log_prob=True)
+    np.testing.assert_allclose(f.log_prob(xs).cpu().numpy(), lq.cpu().numpy(), atol=3e-4, rtol=1e-5)
+    assert len(f.bijection.layers) == 2 + 2 * nl
+
+
+def test_flow_identity_is_standard_normal(dev):
+    from nfmc_amd.flows import Flow, RealNVP
+    d = 12
+    f = Flow(RealNVP((d,)))
+    with torch.no_grad():
+        for p in f.parameters():
+            p.zero_()
+    x = torch.randn(50, d)
+    want = -0.5 * (x ** 2).sum(-1) - 0.5 * d * np.log(2 * np.pi)
+    np.testing.assert_allclose(f.log_prob(x).cpu().numpy(), want.numpy(), atol=2e-5)
+    z, ld = f.bijection.forward(x)
+    np.testing.assert_allclose(z.cpu().numpy(), x.numpy(), atol=1e-6)
+    np.testing.assert_allclose(ld.cpu().numpy(), 0, atol=1e-6)
+
+
+def test_flow_logdet_is_jacobian_slogdet(dev):
+    """(3): logdet_forward equals slogdet of the autograd Jacobian of the CPU restatement (d <= 8)."""
+    from nfmc_amd.flows import Flow, RealNVP
+    from oracle import flow as oflow
+    d = 6
+    torch.manual_seed(3)
+    of = oflow.perturb_(oflow.Flow(oflow.RealNVP((d,), n_layers=3)), 11, 0.5)
+    f = Flow(RealNVP((d,), n_layers=3))
+    f.load_state_dict(of.state_dict())
+    x = torch.randn(5, d)
+    _, ld = f.bijection.forward(x)
+    for i in range(5):
+        J = torch.autograd.functional.jacobian(lambda v: of.bijection.forward(v[None])[0][0], x[i])
+        np.testing.assert_allclose(float(ld[i]), float(torch.linalg.slogdet(J)[1]), atol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------ native mode vs oracle
+def _flips_ok(tr_lr, tr_lu, got_masks, want_masks, tol=1e-4):
+    """mask disagreements are allowed only where the oracle's test was within `tol` of a tie"""
+    bad = got_masks != want_masks
+    if not bad.any():
+        return True
+    margin = (torch.stack(tr_lu) - torch.stack(tr_lr)).abs().numpy()
+    return bool((margin[bad] < tol).all())
+
+
+@pytest.mark.parametrize('d,n,k', [(64, 300, 12), (25, 257, 8), (128, 130, 6)])
+def test_mala_native_stream_matches_oracle(dev, d, n, k):
+    from nfmc_amd.samplers import mcmc
+    from nfmc_amd.potentials import SumOfSquares
+    from oracle import samplers as osamp, potentials as opot
+    torch.manual_seed(5)
+    x0 = torch.randn(n, d)
+    seed = 4242
+    s = mcmc.MALA((d,), SumOfSquares((d,)), None, mcmc.LangevinParameters(n_iterations=k))
+    s.seed = seed
+    out = s.sample(x0, show_progress=False)
+    tr = osamp.mcmc_sample(x0, opot.sum_squares, 'langevin', k, d ** (-1 / 3), noise=osamp.PhiloxNoise(seed))
+    got = out.samples.reshape(k, n, d)
+    want = tr.stacked()
+    same = (got - want).abs().amax(dim=(0, 2)) < 1e-4
+    assert same.float().mean() > 0.98          # a near-tie flip changes the whole later trajectory of that chain
+    np.testing.assert_allclose(got[:, same].numpy(), want[:, same].numpy(), atol=1e-4, rtol=0)
+    assert abs(out.statistics.n_accepted_trajectories - tr.n_accepted) <= max(2, int(0.01 * n * k))
+
+
+def test_hmc_native_stream_matches_oracle(dev):
+    from nfmc_amd.samplers import mcmc
+    from nfmc_amd.potentials import SumOfSquares
+    from oracle import samplers as osamp, potentials as opot
+    d, n, k, L, h = 32, 200, 5, 7, 0.07
+    torch.manual_seed(6)
+    x0 = torch.randn(n, d)
+    s = mcmc.HMC((d,), SumOfSquares((d,)), mcmc.HMCKernel(event_size=d, n_leapfrog_steps=L, step_size=h),
+                 mcmc.HMCParameters(n_iterations=k))
+    s.seed = 99
+    out = s.sample(x0, show_progress=False)
+    tr = osamp.mcmc_sample(x0, opot.sum_squares, 'hmc', k, h, n_leapfrog=L, noise=osamp.PhiloxNoise(99))
+    got, want = out.samples.reshape(k, n, d), tr.stacked()
+    same = (got - want).abs().amax(dim=(0, 2)) < 1e-4
+    assert same.float().mean() > 0.98
+    np.testing.assert_allclose(got[:, same].numpy(), want[:, same].numpy(), atol=1e-4, rtol=0)
+
+
+def test_jump_mala_native_stream_matches_oracle(dev):
+    from nfmc_amd.samplers import jump, mcmc
+    from nfmc_amd.containers import NFMCKernel
+    from nfmc_amd.flows import Flow, RealNVP
+    from nfmc_amd.potentials import SumOfSquares
+    from oracle import samplers as osamp, potentials as opot, flow as oflow
+    d, n, T, K = 16, 192, 3, 5
+    torch.manual_seed(8)
+    of = oflow.perturb_(oflow.Flow(oflow.RealNVP((d,))), 5, 0.2, 0.7071)
+    f = Flow(RealNVP((d,)))
+    f.load_state_dict(of.state_dict())
+    x0 = 0.7 * torch.randn(n, d)
+    s = jump.JumpMALA((d,), SumOfSquares((d,)), NFMCKernel((d,), flow=f), jump.JumpNFMCParameters(n_iterations=T),
+                      None, mcmc.LangevinParameters(n_iterations=K))
+    s.seed = 31337
+    out = s.sample(x0, show_progress=False)
+    tr = osamp.jump_sample(x0, opot.sum_squares, of, 'langevin', T, K, d ** (-1 / 3), noise=osamp.PhiloxNoise(31337))
+    got, want = out.samples.reshape(T * (K + 1), n, d), tr.stacked()
+    same = (got - want).abs().amax(dim=(0, 2)) < 2e-4
+    assert same.float().mean() > 0.97
+    assert out.statistics.n_attempted_jumps == n * T
+    assert abs(out.statistics.n_accepted_jumps - tr.n_accepted_jumps) <= max(2, int(0.02 * n * T))
+    assert out.statistics.n_accepted_jumps > 0.1 * n * T   # the scaled flow proposes well: jumps do get accepted
+
+
+# ------------------------------------------------------------------------------------------ size-independent properties
+def test_moments_of_sum_squares_target_large(dev):
+    """U = sum x^2 => N(0, I/2): mean 0, variance 0.5 (README.md:45-46) at n=65536, d=64."""
+    from nfmc_amd import sample
+    from nfmc_amd.potentials import SumOfSquares
+    d, n = 64, 65536
+    torch.manual_seed(0)
+    out = sample(SumOfSquares((d,)), strategy='mala', n_chains=n, n_iterations=300, show_progress=False,
+                 x0=torch.randn(n, d) * 0.7071, param_kwargs={'store_samples': False})
+    assert out.samples is None
+    assert abs(float(out.mean.abs().max())) < 3e-3
+    np.testing.assert_allclose(out.variance.numpy(), 0.5, rtol=4e-3)
+    assert 0.4 < out.statistics.acceptance_rate < 0.9
+
+
+def test_run_twice_is_bitwise_identical(dev):
+    from nfmc_amd import sample
+    from nfmc_amd.potentials import SumOfSquares
+    d, n = 64, 4096
+    x0 = torch.randn(n, d, generator=torch.Generator().manual_seed(1))
+    outs = []
+    for _ in range(2):
+        o = sample(SumOfSquares((d,)), strategy='jump_mala', n_iterations=3, show_progress=False, x0=x0, seed=7,
+                   inner_param_kwargs={'n_iterations': 20}, param_kwargs={'store_samples': False})
+        outs.append(o)
+    assert torch.equal(outs[0].running_samples.last_sample, outs[1].running_samples.last_sample)
+    assert torch.equal(outs[0].statistics.expectations['first_moment'].total, outs[1].statistics.expectations['first_moment'].total)
+    assert outs[0].statistics.n_accepted_trajectories == outs[1].statistics.n_accepted_trajectories
+
+
+def test_sharded_chains_equal_single_run(dev):
+    """Global-chain-id keyed noise: simulating rows [lo, hi) alone equals the slice of the full run."""
+    from nfmc_amd.samplers import mcmc
+    from nfmc_amd.potentials import SumOfSquares
+    from nfmc_amd.dist import Shard
+    d, n, k = 64, 1000, 10
+    x0 = torch.randn(n, d, generator=torch.Generator().manual_seed(2))
+    full = mcmc.MALA((d,), SumOfSquares((d,)), None, mcmc.LangevinParameters(n_iterations=k, store_samples=False))
+    full.seed = 5
+    a = full.sample(x0, show_progress=False).running_samples.last_sample
+    parts = []
+    for r in range(3):
+        s = mcmc.MALA((d,), SumOfSquares((d,)), None, mcmc.LangevinParameters(n_iterations=k, store_samples=False))
+        s.seed = 5
+        s.shard = Shard(rank=r, world=3)
+        s.shard.merge_statistics = lambda st: st
+        parts.append(s.sample(x0, show_progress=False).running_samples.last_sample)
+    assert torch.equal(torch.cat(parts), a)
+
+
+# ------------------------------------------------------------------------------------------ API shape tests (reference test/)
+@pytest.mark.parametrize('strategy', ['mala', 'ula', 'hmc', 'uhmc', 'imh', 'jump_mala', 'jump_ula', 'jump_hmc', 'jump_uhmc'])
+def test_sample_api_shapes(dev, strategy):
+    """mirror of test/test_samplers.py:175-249 + test_moment_estimation.py:31-49 for the path's strategies."""
+    from nfmc_amd import sample
+    torch.manual_seed(0)
+    n_iterations, n_chains, event_shape = 3, 20, (10,)
+    out = sample(lambda x: torch.sum(x ** 2, dim=1), event_shape=event_shape, strategy=strategy, n_chains=n_chains,
+                 n_iterations=n_iterations, n_warmup_iterations=3, show_progress=False,
+                 inner_param_kwargs={'n_iterations': 4} if 'jump' in strategy else None)
+    k = n_iterations * 5 if 'jump' in strategy else n_iterations
+    assert out.samples.shape == (k, n_chains, *event_shape)
+    assert torch.isfinite(out.samples).all()
+    for m in (out.mean, out.second_moment, out.variance):
+        assert m.shape == event_shape and m.isfinite().all()
+
+
+def test_custom_event_shape(dev):
+    """test/test_custom_shapes.py: 2-D events are flattened row-major."""
+    from nfmc_amd import sample
+    out = sample(lambda x: torch.sum(x ** 2, dim=(1, 2)), event_shape=(8, 8), strategy='jump_hmc', n_chains=7,
+                 n_iterations=2, show_progress=False)
+    assert out.samples.shape == (2 * 6, 7, 8, 8)
+    out = sample(lambda x: torch.sum(x ** 2, dim=(1, 2)), event_shape=(8, 8), strategy='imh', n_chains=7,
+                 n_iterations=2, show_progress=False)
+    assert out.samples.shape == (2, 7, 8, 8)
+
+
+def test_no_sample_storing(dev):
+    """test/test_no_sample_storing.py."""
+    from nfmc_amd.sample import create_sampler
+    for strategy in ['mala', 'hmc', 'imh', 'jump_mala']:
+        s = create_sampler(target=lambda x: torch.sum(x ** 2, dim=-1), event_shape=(10,), strategy=strategy,
+                           param_kwargs={'store_samples': False})
+        out = s.sample(torch.randn(20, 10), show_progress=False, time_limit_seconds=5.0)
+        assert out.samples is None
+        assert out.running_samples.last_sample.shape == (20, 10)
+
+
+def test_flow_kwargs(dev):
+    """test/test_flow_kwargs.py."""
+    from nfmc_amd import sample
+    t = lambda x: torch.sum(x ** 2, dim=-1)
+    basic = sample(event_shape=(100,), target=t, flow='realnvp', strategy='imh', n_iterations=3, show_progress=False)
+    adv = sample(event_shape=(100,), target=t, flow='realnvp%{"n_layers": 10}', strategy='imh', n_iterations=3,
+                 show_progress=False)
+    assert len(adv.kernel.flow.bijection.layers) > len(basic.kernel.flow.bijection.layers)
