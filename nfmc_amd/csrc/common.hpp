@@ -14,6 +14,9 @@ constexpr int kWave = 64;
 constexpr int kBlock = 256;          // 4 waves per workgroup
 constexpr int kWavesPerBlock = kBlock / kWave;
 constexpr int kMaxGrid = 2048;       // 256 CUs x 8 workgroups; larger problems grid-stride
+#ifndef NFMC_WPE
+#define NFMC_WPE 1
+#endif
 constexpr int kStatTail = 4;         // per-workgroup scratch tail: accepted, nonfinite, 2 spare
 
 // RNG stream tags (oracle/philox.py)
@@ -74,10 +77,23 @@ __device__ __forceinline__ float fast_exp(float v) { return __builtin_amdgcn_exp
 // ------------------------------------------------------------------------------------------------
 // Butterfly all-reduce over the LPC consecutive lanes that share one chain.  fp add is commutative,
 // so every lane of the group ends with the bitwise same sum: the accept decision needs no broadcast.
+// Steps inside a 16-lane row are DPP moves on the VALU (quad_perm for xor 1/2, row_half_mirror and
+// row_mirror pair the already-uniform halves for 8 and 16 lanes); only 32/64-lane groups go through the
+// LDS crossbar (ds_bpermute).
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false);
+    return v + __int_as_float(moved);
+}
+
 template <int LPC>
 __device__ __forceinline__ float group_allreduce(float v) {
-#pragma unroll
-    for (int m = 1; m < LPC; m <<= 1) v += __shfl_xor(v, m, kWave);
+    if constexpr (LPC >= 2) v = dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]  : lane ^ 1
+    if constexpr (LPC >= 4) v = dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]  : lane ^ 2
+    if constexpr (LPC >= 8) v = dpp_add<0x141>(v);  // row_half_mirror      : i <-> 7 - i
+    if constexpr (LPC >= 16) v = dpp_add<0x140>(v); // row_mirror           : i <-> 15 - i
+    if constexpr (LPC >= 32) v += __shfl_xor(v, 16, kWave);
+    if constexpr (LPC >= 64) v += __shfl_xor(v, 32, kWave);
     return v;
 }
 
@@ -244,13 +260,26 @@ __device__ __forceinline__ void block_stats_flush(const float (&sx)[CPL], const 
     }
 }
 
-// scratch (nblocks, 2*dp + kStatTail) -> stats (+=); one workgroup.
-static __global__ void stats_finish_kernel(const double* __restrict__ scratch, int nblocks, int dp, int d, NfmcStats st,
-                                    unsigned long long attempted) {
+// scratch (nblocks, 2*dp + kStatTail) -> stats (+=).  Workgroup b owns 32 columns; its 256 threads are
+// 32 columns x 8 row-slices (loads coalesced across columns, 8 independent chains per column), and the 8
+// partials of a column are added in slice order, so the result does not depend on timing.
+constexpr int kFinishCols = 32, kFinishSlices = 8;
+static __global__ void __launch_bounds__(kBlock) stats_finish_kernel(const double* __restrict__ scratch, int nblocks,
+                                                                     int dp, int d, NfmcStats st,
+                                                                     unsigned long long attempted) {
+    __shared__ double part[kFinishSlices][kFinishCols];
     const int width = 2 * dp + kStatTail;
-    for (int t = threadIdx.x; t < width; t += blockDim.x) {
-        double s = 0.0;
-        for (int b = 0; b < nblocks; ++b) s += scratch[(size_t)b * width + t];
+    const int col = threadIdx.x % kFinishCols, slice = threadIdx.x / kFinishCols;
+    const int t = blockIdx.x * kFinishCols + col;
+    double s = 0.0;
+    if (t < width)
+        for (int b = slice; b < nblocks; b += kFinishSlices) s += scratch[(size_t)b * width + t];
+    part[slice][col] = s;
+    __syncthreads();
+    if (slice == 0 && t < width) {
+        s = 0.0;
+#pragma unroll
+        for (int k = 0; k < kFinishSlices; ++k) s += part[k][col];
         if (t < dp) {
             if (t < d) st.sum_x[t] += s;
         } else if (t < 2 * dp) {
@@ -263,6 +292,8 @@ static __global__ void stats_finish_kernel(const double* __restrict__ scratch, i
         }
     }
 }
+
+inline int stats_finish_grid(int dp) { return (2 * dp + kStatTail + kFinishCols - 1) / kFinishCols; }
 
 inline int64_t stats_scratch_doubles(int dp) { return (int64_t)kMaxGrid * (2 * dp + kStatTail); }
 

@@ -88,7 +88,7 @@ struct AcceptUniform {
 
 // ------------------------------------------------------------------------------------------------
 template <int CPL, int LPC, template <int, int, bool> class Pot, bool FAST>
-__global__ void __launch_bounds__(kBlock) mala_kernel(NfmcMalaArgs a, float sqrt2h, int64_t tiles) {
+__global__ void __launch_bounds__(kBlock, NFMC_WPE) mala_kernel(NfmcMalaArgs a, float sqrt2h, int64_t tiles) {
     constexpr int CPW = kWave / LPC;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane % LPC, cw = lane / LPC;
@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(kBlock) mala_kernel(NfmcMalaArgs a, float sqrt
 
 // ------------------------------------------------------------------------------------------------
 template <int CPL, int LPC, template <int, int, bool> class Pot, bool FAST>
-__global__ void __launch_bounds__(kBlock) hmc_kernel(NfmcHmcArgs a, int64_t tiles) {
+__global__ void __launch_bounds__(kBlock, NFMC_WPE) hmc_kernel(NfmcHmcArgs a, int64_t tiles) {
     constexpr int CPW = kWave / LPC;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane % LPC, cw = lane / LPC;
@@ -256,7 +256,7 @@ struct Cfg {
 };
 
 // (CPL, LPC) instantiated below, ordered by capacity CPL*LPC.
-static const Cfg kCfgs[] = {{4, 1}, {4, 2}, {4, 4}, {4, 8}, {8, 8}, {16, 4}, {16, 8}, {16, 16}, {16, 32}, {16, 64}};
+static const Cfg kCfgs[] = {{4, 1}, {4, 2}, {4, 4}, {4, 8}, {4, 16}, {8, 8}, {16, 4}, {16, 8}, {16, 16}, {16, 32}, {16, 64}};
 
 static Cfg choose_cfg(int d, bool fast_ok) {
     // NFMC_SAMPLER_CFG="cpl,lpc" overrides (tuning)
@@ -299,7 +299,7 @@ static bool fast_path(const Args* a, const Cfg& c) {
 }
 
 #define NFMC_FOR_CFG(M)                                                                                             \
-    M(4, 1) M(4, 2) M(4, 4) M(4, 8) M(8, 8) M(16, 4) M(16, 8) M(16, 16) M(16, 32) M(16, 64)
+    M(4, 1) M(4, 2) M(4, 4) M(4, 8) M(4, 16) M(8, 8) M(16, 4) M(16, 8) M(16, 16) M(16, 32) M(16, 64)
 
 template <int CPL, int LPC>
 static int launch_mala(const NfmcMalaArgs& a, bool fast, int64_t tiles, int grid, float sqrt2h, hipStream_t st) {
@@ -359,7 +359,7 @@ extern "C" int nfmc_mala_steps_f32(const NfmcMalaArgs* args, nfmc_stream_t strea
 #undef M
     NFMC_HIP_CHECK_LAUNCH();
     if (a.stats.sum_x) {
-        hipLaunchKernelGGL(stats_finish_kernel, dim3(1), dim3(kBlock), 0, st, a.stats.scratch, grid, dp, a.d, a.stats,
+        hipLaunchKernelGGL(stats_finish_kernel, dim3(stats_finish_grid(dp)), dim3(kBlock), 0, st, a.stats.scratch, grid, dp, a.d, a.stats,
                            (unsigned long long)a.n * (unsigned long long)a.n_steps);
         NFMC_HIP_CHECK_LAUNCH();
     }
@@ -389,7 +389,7 @@ extern "C" int nfmc_hmc_steps_f32(const NfmcHmcArgs* args, nfmc_stream_t stream)
 #undef M
     NFMC_HIP_CHECK_LAUNCH();
     if (a.stats.sum_x) {
-        hipLaunchKernelGGL(stats_finish_kernel, dim3(1), dim3(kBlock), 0, st, a.stats.scratch, grid, dp, a.d, a.stats,
+        hipLaunchKernelGGL(stats_finish_kernel, dim3(stats_finish_grid(dp)), dim3(kBlock), 0, st, a.stats.scratch, grid, dp, a.d, a.stats,
                            (unsigned long long)a.n * (unsigned long long)a.n_steps);
         NFMC_HIP_CHECK_LAUNCH();
     }

@@ -11,7 +11,7 @@ import os
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libnfmc_hip.so')
+LIB_PATH = os.environ.get('NFMC_LIB', os.path.join(HERE, 'libnfmc_hip.so'))
 
 OK, EINVAL, ESHAPE, EALIGN, EUNSUPPORTED, ESCRATCH = 0, -1, -2, -3, -4, -5
 POT_QUADRATIC, POT_FUNNEL = 0, 1

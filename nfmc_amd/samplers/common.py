@@ -79,6 +79,13 @@ class Run:
             normals, uniforms = sampler.replay
             self.replay = Replay(normals, uniforms, self.dev)
         self.t0 = time.time()
+        self.kernel_events = None   # bench.py: list of (label, start_event, end_event) when kernel timing is on
+        if getattr(sampler, 'time_kernels', False):
+            self.kernel_events = []
+
+    def timed(self, label):
+        """Context manager recording HIP events on the launch stream around one kernel call."""
+        return _Timed(self, label)
 
     def rng(self, step0, k=0, adjusted=True):
         """NfmcRng for a launch of k transitions starting at transition `step0`."""
@@ -94,6 +101,23 @@ class Run:
     def elapsed(self):
         self.sync()
         return time.time() - self.t0
+
+
+class _Timed:
+    def __init__(self, run, label):
+        self.run, self.label = run, label
+
+    def __enter__(self):
+        if self.run.kernel_events is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record(torch.cuda.current_stream())
+        return self
+
+    def __exit__(self, *exc):
+        if self.run.kernel_events is not None:
+            self.e1.record(torch.cuda.current_stream())
+            self.run.kernel_events.append((self.label, self.e0, self.e1))
 
 
 def chunks(total, limit=hip.MAX_STEPS_PER_CALL):

@@ -97,7 +97,8 @@ def launch_flow_mh(run: Run, flow, pot, logq, k, step0, cached, adjusted, stats_
     a.samples = hip.ptr(samples) if samples is not None else None
     a.masks_out = hip.ptr(masks_out, torch.uint8) if masks_out is not None else None
     a.log_ratio_out = hip.ptr(log_ratio_out) if log_ratio_out is not None else None
-    hip.check(hip.lib().nfmc_flow_mh_steps_f32(C.byref(a), hip.stream()), 'nfmc_flow_mh_steps_f32')
+    with run.timed('flow_mh_steps'):
+        hip.check(hip.lib().nfmc_flow_mh_steps_f32(C.byref(a), hip.stream()), 'nfmc_flow_mh_steps_f32')
 
 
 def split_flow_mh(run: Run, flow, target, event_shape, step, adjusted, stats_struct, logq=None):
@@ -260,6 +261,7 @@ class JumpNFMC(Sampler):
         out.running_samples.last_sample = run.x.reshape(n, *event_shape).clone()
         st.update_elapsed_time(time.time() - t0)
         out.kernel = self.kernel
+        out.kernel_events = run.kernel_events
         if run.shard is not None:
             run.shard.merge_statistics(st)
         return out

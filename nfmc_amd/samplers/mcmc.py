@@ -261,7 +261,8 @@ class Langevin(MetropolisSampler):
         a.samples = hip.ptr(samples) if samples is not None else None
         a.masks_out = hip.ptr(masks_out, torch.uint8) if masks_out is not None else None
         a.log_ratio_out = hip.ptr(log_ratio_out) if log_ratio_out is not None else None
-        hip.check(hip.lib().nfmc_mala_steps_f32(C.byref(a), hip.stream()), 'nfmc_mala_steps_f32')
+        with run.timed('mala_steps'):
+            hip.check(hip.lib().nfmc_mala_steps_f32(C.byref(a), hip.stream()), 'nfmc_mala_steps_f32')
 
     def propose(self, x):
         """langevin.py:61-122 for an arbitrary target: autograd U/grad U + HIP proposal and log-ratio.
@@ -351,7 +352,8 @@ class HMC(MetropolisSampler):
         a.samples = hip.ptr(samples) if samples is not None else None
         a.masks_out = hip.ptr(masks_out, torch.uint8) if masks_out is not None else None
         a.log_ratio_out = hip.ptr(log_ratio_out) if log_ratio_out is not None else None
-        hip.check(hip.lib().nfmc_hmc_steps_f32(C.byref(a), hip.stream()), 'nfmc_hmc_steps_f32')
+        with run.timed('hmc_steps'):
+            hip.check(hip.lib().nfmc_hmc_steps_f32(C.byref(a), hip.stream()), 'nfmc_hmc_steps_f32')
 
     def propose(self, x):
         """hmc.py:96-126 for an arbitrary target: leapfrog with autograd gradients on the GPU."""

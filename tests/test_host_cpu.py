@@ -1,0 +1,275 @@
+"""CPU: host logic of nfmc_amd and the C-ABI library's symbol table (no compute calls without a GPU)."""
+import ctypes
+import os
+import re
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from nfmc_amd import hip
+    header = open(os.path.join(ROOT, 'include', 'nfmc_hip.h')).read()
+    declared = set(re.findall(r'\b(nfmc_[a-z0-9_]+)\s*\(', header))
+    assert declared, 'no declarations parsed'
+    handle = hip.lib()
+    for name in declared:
+        assert hasattr(handle, name), f'{name} declared in include/nfmc_hip.h but not exported'
+    assert declared == {s[0] for s in hip.SYMBOLS}, 'hip.SYMBOLS and the header disagree'
+    lim = hip.limits()
+    assert lim.abi_version == 1 and lim.max_d_sampler >= 256 and lim.max_steps_per_call == hip.MAX_STEPS_PER_CALL
+    assert hip.lib().nfmc_error_string(-5).decode().startswith('statistics scratch')
+    assert hip.lib().nfmc_stats_scratch_bytes(64) > 0 and hip.lib().nfmc_stats_scratch_bytes(5000) == 0
+    assert hip.lib().nfmc_realnvp_padded_hidden(5) == 8 and hip.lib().nfmc_realnvp_padded_hidden(100) == 128
+    assert hip.lib().nfmc_realnvp_layer_floats(64, 4, 2) == 32 * 4 + 4 + 16 + 4 + 64 * 4 + 64
+
+
+def test_struct_sizes_match_the_header():
+    """Compile a tiny C program against include/nfmc_hip.h and compare sizeof() with the ctypes mirrors."""
+    from nfmc_amd import hip
+    names = ['NfmcPotential', 'NfmcRng', 'NfmcStats', 'NfmcMalaArgs', 'NfmcHmcArgs', 'NfmcRealNVP', 'NfmcFlowMhArgs',
+             'NfmcNeutraHmcArgs', 'NfmcSelectArgs', 'NfmcLimits']
+    src = '#include <stdio.h>\n#include "nfmc_hip.h"\nint main(){' + ''.join(
+        f'printf("%zu\\n", sizeof({n}));' for n in names) + 'return 0;}'
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        c = os.path.join(td, 's.c')
+        open(c, 'w').write(src)
+        exe = os.path.join(td, 's')
+        subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), c, '-o', exe])
+        sizes = [int(v) for v in subprocess.check_output([exe]).split()]
+    for n, sz in zip(names, sizes):
+        assert ctypes.sizeof(getattr(hip, n)) == sz, n
+
+
+def test_samplers_fail_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from nfmc_amd import sample
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        sample(lambda x: torch.sum(x ** 2, dim=1), event_shape=(5,), strategy='mala', n_chains=4, n_iterations=2,
+               show_progress=False)
+    from nfmc_amd.flows import Flow, RealNVP
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        Flow(RealNVP((6,))).log_prob(torch.randn(3, 6))
+
+
+def test_product_does_not_import_the_oracle():
+    for root, _dirs, files in os.walk(os.path.join(ROOT, 'nfmc_amd')):
+        for f in files:
+            if f.endswith('.py'):
+                text = open(os.path.join(root, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', text, re.M), f
+
+
+@pytest.mark.parametrize('strategy', ['mala', 'ula', 'hmc', 'uhmc', 'imh', 'fixed_imh', 'jump_mala', 'jump_ula',
+                                      'jump_hmc', 'jump_uhmc', 'neutra_hmc'])
+def test_create_sampler_plumbing(strategy):
+    """nfmc/sample.py:20-240 keyword plumbing and defaults."""
+    from nfmc_amd.sample import create_sampler
+    s = create_sampler(lambda x: torch.sum(x ** 2, dim=-1), (10,), strategy=strategy,
+                       param_kwargs={'n_iterations': 7, 'store_samples': False})
+    assert s.params.n_iterations == 7 and s.params.store_samples is False
+    if strategy.startswith('jump_'):
+        inner = s.inner_sampler
+        assert inner.params.n_iterations == (5 if strategy == 'jump_hmc' else 100)   # sample.py:161-162, base.py:31
+        assert s.params.adjusted_jumps and not s.params.fit_nf and s.params.n_jumps_before_training == 10
+        assert inner.params.adjustment == (strategy in ('jump_mala', 'jump_hmc'))
+    if 'mala' in strategy or 'ula' in strategy:
+        k = s.inner_sampler.kernel if strategy.startswith('jump') else s.kernel
+        assert abs(k.step_size - 10 ** (-1 / 3)) < 1e-12                                  # langevin.py:16-18
+        assert torch.equal(k.inv_mass_diag, torch.ones(10))
+    if strategy in ('hmc', 'uhmc'):
+        assert s.kernel.n_leapfrog_steps == 20 and s.kernel.step_size == 0.01               # hmc.py:13, base.py:109
+    if strategy in ('imh', 'fixed_imh', 'neutra_hmc') or strategy.startswith('jump'):
+        assert len(s.kernel.flow.bijection.layers) == 6
+
+
+def test_unsupported_strategy_and_flow_are_errors():
+    from nfmc_amd.sample import create_sampler
+    with pytest.raises(ValueError, match='Unsupported sampling strategy'):
+        create_sampler(lambda x: x.sum(-1), (4,), strategy='dlmc')
+    with pytest.raises(ValueError, match="outside this build's path"):
+        create_sampler(lambda x: x.sum(-1), (4,), strategy='imh', flow='maf')
+    with pytest.raises(ValueError):
+        create_sampler(lambda x: x.sum(-1), (4,), strategy='imh', flow=None)
+
+
+def test_flow_strings():
+    """nfmc/util.py:189-215; test/test_flow_kwargs.py."""
+    from nfmc_amd.util import parse_flow_string, create_flow_object, metropolis_acceptance_log_ratio
+    from conftest import load_golden
+    fx = load_golden('util')
+    p = parse_flow_string('realnvp%{"n_layers": 10, "conditioner_kwargs": {"n_layers": 5, "n_hidden": 100}}')
+    assert p['name'] == 'realnvp' and p['kwargs']['n_layers'] == int(fx['parsed_n_layers'])
+    assert p['kwargs']['conditioner_kwargs']['n_hidden'] == int(fx['parsed_n_hidden'])
+    assert parse_flow_string('rnvp') == {'name': 'rnvp', 'kwargs': {}, 'hash': hash('rnvp')}
+    basic = create_flow_object('realnvp', (100,))
+    adv = create_flow_object('real_nvp%{"n_layers": 10, "conditioner_kwargs": {"n_layers": 5, "n_hidden": 100}}', (100,))
+    assert len(adv.bijection.layers) > len(basic.bijection.layers)
+    assert adv.bijection.n_hidden == 100 and adv.bijection.n_hidden_layers == 5
+    assert basic.event_shape == (100,)
+    a, b, c, d = (torch.tensor(v) for v in ([1.0, -2.0], [0.5, 3.0], [0.25, 0.0], [-1.0, 4.0]))
+    np.testing.assert_allclose(metropolis_acceptance_log_ratio(a, b, c, d).numpy(), fx['log_ratio'])
+
+
+def test_metropolization_sign_convention():
+    """test/test_metropolization.py:30."""
+    from nfmc_amd.util import metropolis_acceptance_log_ratio as r
+    t = lambda x: torch.sum(x ** 2, dim=-1)
+    q = lambda x: torch.sum(x ** 2 / (2 * 100 ** 2), dim=-1)
+    x0, x1 = torch.tensor([[-100.0, -100.0]]), torch.tensor([[0.0, 0.0]])
+    assert r(-t(x0), -t(x1), -q(x0), -q(x1)) > r(-q(x0), -q(x1), -t(x0), -t(x1))
+
+
+def test_flow_state_dict_is_interchangeable_with_the_oracle_flow():
+    from nfmc_amd.flows import Flow, RealNVP
+    from oracle import flow as oflow
+    a = Flow(RealNVP((9,), n_layers=3, conditioner_kwargs={'n_hidden': 6, 'n_layers': 3}))
+    b = oflow.Flow(oflow.RealNVP((9,), n_layers=3, conditioner_kwargs={'n_hidden': 6, 'n_layers': 3}))
+    assert list(a.state_dict().keys()) == list(b.state_dict().keys())
+    a.load_state_dict(b.state_dict())
+    assert a.event_shape == (9,) and a.get_device().type == 'cpu'
+
+
+def test_statistics_equal_the_reference_streaming_formula():
+    """MCMCExpectation (sums / n_seen) == the reference's running update (base.py:88-95) == oracle.Moments."""
+    from nfmc_amd.containers import MCMCStatistics
+    from oracle.samplers import Moments
+    torch.manual_seed(0)
+    st, mo = MCMCStatistics((5,)), Moments(1)
+    for k in (1, 3, 2):
+        x = torch.randn(k, 11, 5)
+        st.expectations.update(x)
+        mo.update(x)
+    np.testing.assert_allclose(st.running_first_moment.numpy(), mo.first.numpy(), atol=1e-6)
+    np.testing.assert_allclose(st.running_second_moment.numpy(), mo.second.numpy(), atol=1e-6)
+    np.testing.assert_allclose(st.running_variance.numpy(), mo.variance.numpy(), atol=1e-6)
+    st.update_counters(n_accepted_trajectories=3, n_attempted_trajectories=4)
+    assert st.acceptance_rate == 0.75
+
+
+def test_samples_store_semantics():
+    """thinning / max_samples / last_sample of base.py:234-263."""
+    from nfmc_amd.containers import MCMCSamples, MCMCOutput
+    s = MCMCSamples((2,), thinning=2, max_samples=3)
+    xs = torch.arange(7 * 4 * 2, dtype=torch.float32).reshape(7, 4, 2)
+    s.add(xs[:3])
+    s.add(xs[3])
+    s.add(xs[4:])
+    kept = [0, 2, 4, 6][-3:]
+    assert torch.equal(s.as_tensor(), xs[kept])
+    assert torch.equal(s.last_sample, xs[6]) and s.n_samples == 3
+    off = MCMCSamples((2,), store_samples=False)
+    off.add(xs[:2])
+    assert off.n_samples == 0 and torch.equal(off.last_sample, xs[1])
+    with pytest.raises(ValueError):
+        s.add(torch.zeros(4, 3))
+    o = MCMCOutput((2,), store_samples=False)
+    assert o.samples is None
+
+
+def test_train_val_split_matches_golden():
+    from nfmc_amd.tuning import train_val_split, DualAveraging, DualAveragingParams
+    from conftest import load_golden
+    fx = load_golden('train_val_split')
+    torch.manual_seed(19)
+    _ = torch.randn(5, 7, 3)  # the generator drew x before the permutation
+    tr, va = train_val_split(torch.from_numpy(fx['x']), 0.7, 16, 4)
+    np.testing.assert_array_equal(tr.numpy(), fx['train'])
+    np.testing.assert_array_equal(va.numpy(), fx['val'])
+    fx = load_golden('tuning')
+    da = DualAveraging(0.25, DualAveragingParams())
+    vals = []
+    for e in fx['da_errors']:
+        da.step(float(e))
+        vals.append(da.value)
+    np.testing.assert_allclose(vals, fx['da_values'], rtol=1e-12)
+
+
+def test_shard_bounds_cover_all_chains():
+    from nfmc_amd.dist import Shard
+    for n, w in [(10, 3), (262144, 8), (7, 8), (100, 1)]:
+        spans = [Shard(rank=r, world=w).bounds(n) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+        sizes = [b - a for a, b in spans]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def test_potential_recognition():
+    from nfmc_amd.potentials import recognize, SumOfSquares, Funnel
+    from oracle import potentials as opot
+    p = recognize(lambda x: torch.sum(x ** 2, dim=1), (25,))
+    assert p is not None and p.a == 1.0 and p.b == 0.0
+    p = recognize(lambda x: torch.sum((x - 1.5) ** 2 * torch.arange(1, 4.), dim=-1), (3,))
+    np.testing.assert_allclose(p.a.numpy(), [1, 2, 3], rtol=1e-6)
+    assert recognize(lambda x: torch.sum(x ** 4, dim=1), (5,)) is None
+    assert recognize(lambda x: torch.sum(x.abs(), dim=1), (5,)) is None
+    assert recognize(opot.funnel(3.0), (6,)) is None
+    x = torch.randn(7, 6)
+    np.testing.assert_allclose(Funnel((6,), 3.0)(x).numpy(), opot.funnel(3.0)(x).numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(SumOfSquares((6,))(x).numpy(), opot.sum_squares(x).numpy(), rtol=1e-6)
+
+
+GLOO_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+rank, world = int(sys.argv[2]), int(sys.argv[3])
+os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=sys.argv[4], RANK=str(rank), WORLD_SIZE=str(world))
+dist.init_process_group('gloo', rank=rank, world_size=world)
+from nfmc_amd.dist import Shard
+from nfmc_amd.samplers.jump import JumpNFMCStatistics
+from nfmc_amd.tuning import train_val_split
+sh = Shard()
+assert (sh.rank, sh.world) == (rank, world)
+# C2: statistics merge
+n, d = 10, 3
+x = torch.arange(n * d, dtype=torch.float32).reshape(n, d)
+lo, hi = sh.bounds(n)
+st = JumpNFMCStatistics((d,))
+st.expectations.update(x[lo:hi])
+st.update_counters(n_accepted_trajectories=hi - lo, n_attempted_trajectories=2 * (hi - lo), n_accepted_jumps=rank + 1,
+                   n_attempted_jumps=5, n_target_calls=7)
+sh.merge_statistics(st)
+assert torch.allclose(st.running_first_moment, x.mean(0)), st.running_first_moment
+assert torch.allclose(st.running_second_moment, (x ** 2).mean(0))
+assert st.n_accepted_trajectories == n and st.n_attempted_trajectories == 2 * n
+assert st.n_accepted_jumps == sum(range(1, world + 1)) and st.n_attempted_jumps == 5 * world and st.n_target_calls == 7 * world
+# seed broadcast
+assert sh.broadcast_int(1234 + rank) == 1234
+# C1: refit buffer all-gather, same rows on every rank
+torch.manual_seed(100 + rank)
+local = torch.randn(4, 6, d) + 10 * rank
+tr, va = train_val_split(local, 0.7, 6, 2, shard=sh)
+assert tr.shape == (5, d) and va.shape[0] <= 2, (tr.shape, va.shape)
+both = torch.cat([tr, va])
+gathered = [torch.empty_like(both) for _ in range(world)]
+dist.all_gather(gathered, both)
+assert all(torch.equal(g, gathered[0]) for g in gathered)
+assert (both.mean(1) > 5).any() and (both.mean(1) < 5).any()   # rows from both ranks
+dist.barrier()
+dist.destroy_process_group()
+print('ok', rank)
+'''
+
+
+def test_two_rank_gloo_collectives(tmp_path):
+    """N > 1 path on CPU: world_size 2, gloo, one process per rank (C1 all-gather, C2 all-reduce, seed bcast)."""
+    script = tmp_path / 'worker.py'
+    script.write_text(GLOO_WORKER)
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = str(s.getsockname()[1])
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(r), '2', port], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+        assert 'ok' in o
