@@ -263,21 +263,29 @@ __device__ __forceinline__ void block_stats_flush(const float (&sx)[CPL], const 
 // scratch (nblocks, 2*dp + kStatTail) -> stats (+=).  Workgroup b owns 32 columns; its 256 threads are
 // 32 columns x 8 row-slices (loads coalesced across columns, 8 independent chains per column), and the 8
 // partials of a column are added in slice order, so the result does not depend on timing.
-constexpr int kFinishCols = 32, kFinishSlices = 8;
-static __global__ void __launch_bounds__(kBlock) stats_finish_kernel(const double* __restrict__ scratch, int nblocks,
-                                                                     int dp, int d, NfmcStats st,
-                                                                     unsigned long long attempted) {
+constexpr int kFinishCols = 32, kFinishSlices = 32, kFinishBlock = kFinishCols * kFinishSlices;
+static __global__ void __launch_bounds__(kFinishBlock) stats_finish_kernel(const double* __restrict__ scratch,
+                                                                           int nblocks, int dp, int d, NfmcStats st,
+                                                                           unsigned long long attempted) {
     __shared__ double part[kFinishSlices][kFinishCols];
     const int width = 2 * dp + kStatTail;
     const int col = threadIdx.x % kFinishCols, slice = threadIdx.x / kFinishCols;
     const int t = blockIdx.x * kFinishCols + col;
-    double s = 0.0;
-    if (t < width)
-        for (int b = slice; b < nblocks; b += kFinishSlices) s += scratch[(size_t)b * width + t];
-    part[slice][col] = s;
+    double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;  // four loads in flight per thread, combined in fixed order
+    if (t < width) {
+        int b = slice;
+        for (; b + 3 * kFinishSlices < nblocks; b += 4 * kFinishSlices) {
+            p0 += scratch[(size_t)b * width + t];
+            p1 += scratch[(size_t)(b + kFinishSlices) * width + t];
+            p2 += scratch[(size_t)(b + 2 * kFinishSlices) * width + t];
+            p3 += scratch[(size_t)(b + 3 * kFinishSlices) * width + t];
+        }
+        for (; b < nblocks; b += kFinishSlices) p0 += scratch[(size_t)b * width + t];
+    }
+    part[slice][col] = (p0 + p1) + (p2 + p3);
     __syncthreads();
     if (slice == 0 && t < width) {
-        s = 0.0;
+        double s = 0.0;
 #pragma unroll
         for (int k = 0; k < kFinishSlices; ++k) s += part[k][col];
         if (t < dp) {

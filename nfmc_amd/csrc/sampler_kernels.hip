@@ -256,7 +256,7 @@ struct Cfg {
 };
 
 // (CPL, LPC) instantiated below, ordered by capacity CPL*LPC.
-static const Cfg kCfgs[] = {{4, 1}, {4, 2}, {4, 4}, {4, 8}, {4, 16}, {8, 8}, {16, 4}, {16, 8}, {16, 16}, {16, 32}, {16, 64}};
+static const Cfg kCfgs[] = {{4, 1}, {4, 2}, {4, 4}, {4, 8}, {8, 8}, {4, 16}, {16, 4}, {8, 16}, {16, 8}, {8, 32}, {16, 16}, {8, 64}, {16, 32}, {16, 64}};
 
 static Cfg choose_cfg(int d, bool fast_ok) {
     // NFMC_SAMPLER_CFG="cpl,lpc" overrides (tuning)
@@ -269,9 +269,9 @@ static Cfg choose_cfg(int d, bool fast_ok) {
     Cfg best = {0, 0};
     for (const Cfg& k : kCfgs) {
         if (k.cpl * k.lpc < d) continue;
-        if (best.cpl == 0 || k.cpl * k.lpc < best.cpl * best.lpc ||
-            (k.cpl * k.lpc == best.cpl * best.lpc && fast_ok && k.cpl > best.cpl))
-            best = k;
+        // smallest capacity wins; kCfgs lists equal capacities in order of measured preference
+        // (CPL = 8 keeps 4 waves/SIMD resident: 14.6 vs 12.8 G chain-steps/s at n=65536, d=64)
+        if (best.cpl == 0 || k.cpl * k.lpc < best.cpl * best.lpc) best = k;
     }
     return best;
 }
@@ -299,7 +299,8 @@ static bool fast_path(const Args* a, const Cfg& c) {
 }
 
 #define NFMC_FOR_CFG(M)                                                                                             \
-    M(4, 1) M(4, 2) M(4, 4) M(4, 8) M(4, 16) M(8, 8) M(16, 4) M(16, 8) M(16, 16) M(16, 32) M(16, 64)
+    M(4, 1) M(4, 2) M(4, 4) M(4, 8) M(4, 16) M(8, 8) M(16, 4) M(8, 16) M(16, 8) M(8, 32) M(16, 16) M(8, 64) M(16, 32) \
+        M(16, 64)
 
 template <int CPL, int LPC>
 static int launch_mala(const NfmcMalaArgs& a, bool fast, int64_t tiles, int grid, float sqrt2h, hipStream_t st) {
@@ -359,7 +360,7 @@ extern "C" int nfmc_mala_steps_f32(const NfmcMalaArgs* args, nfmc_stream_t strea
 #undef M
     NFMC_HIP_CHECK_LAUNCH();
     if (a.stats.sum_x) {
-        hipLaunchKernelGGL(stats_finish_kernel, dim3(stats_finish_grid(dp)), dim3(kBlock), 0, st, a.stats.scratch, grid, dp, a.d, a.stats,
+        hipLaunchKernelGGL(stats_finish_kernel, dim3(stats_finish_grid(dp)), dim3(kFinishBlock), 0, st, a.stats.scratch, grid, dp, a.d, a.stats,
                            (unsigned long long)a.n * (unsigned long long)a.n_steps);
         NFMC_HIP_CHECK_LAUNCH();
     }
@@ -389,7 +390,7 @@ extern "C" int nfmc_hmc_steps_f32(const NfmcHmcArgs* args, nfmc_stream_t stream)
 #undef M
     NFMC_HIP_CHECK_LAUNCH();
     if (a.stats.sum_x) {
-        hipLaunchKernelGGL(stats_finish_kernel, dim3(stats_finish_grid(dp)), dim3(kBlock), 0, st, a.stats.scratch, grid, dp, a.d, a.stats,
+        hipLaunchKernelGGL(stats_finish_kernel, dim3(stats_finish_grid(dp)), dim3(kFinishBlock), 0, st, a.stats.scratch, grid, dp, a.d, a.stats,
                            (unsigned long long)a.n * (unsigned long long)a.n_steps);
         NFMC_HIP_CHECK_LAUNCH();
     }

@@ -433,3 +433,86 @@ def test_flow_kwargs(dev):
     adv = sample(event_shape=(100,), target=t, flow='realnvp%{"n_layers": 10}', strategy='imh', n_iterations=3,
                  show_progress=False)
     assert len(adv.kernel.flow.bijection.layers) > len(basic.kernel.flow.bijection.layers)
+
+
+# ------------------------------------------------------------------------------------------ NeuTra (K5)
+@pytest.mark.parametrize('d,nl,nh,cl,pot', [(6, 2, None, 2, 'sumsq'), (7, 3, 5, 3, 'sumsq'), (16, 2, 16, 1, 'funnel'),
+                                             (64, 2, None, 2, 'sumsq'), (128, 2, 32, 2, 'funnel'), (9, 1, 8, 4, 'sumsq')])
+def test_neutra_potential_and_gradient_match_autograd(dev, d, nl, nh, cl, pot):
+    """(7): the hand-written VJP equals torch autograd through the CPU restatement of
+    NeuTra.adjusted_target (neutra.py:58-68)."""
+    from nfmc_amd import hip
+    from nfmc_amd.flows import Flow, RealNVP
+    from nfmc_amd.potentials import SumOfSquares, Funnel
+    from oracle import flow as oflow, potentials as opot, samplers as osamp
+    ck = {'n_layers': cl}
+    if nh is not None:
+        ck['n_hidden'] = nh
+    torch.manual_seed(d + nl)
+    of = oflow.perturb_(oflow.Flow(oflow.RealNVP((d,), n_layers=nl, conditioner_kwargs=ck)), 3, 0.4, 0.8)
+    f = Flow(RealNVP((d,), n_layers=nl, conditioner_kwargs=ck))
+    f.load_state_dict(of.state_dict())
+    target_cpu = opot.sum_squares if pot == 'sumsq' else opot.funnel(3.0)
+    target = SumOfSquares((d,)) if pot == 'sumsq' else Funnel((d,), 3.0)
+    n = 150
+    z = (0.6 * torch.randn(n, d)).requires_grad_(True)
+    u_ref = osamp.neutra_adjusted_target(of, target_cpu, (d,))(z)
+    g_ref, = torch.autograd.grad(u_ref.sum(), z)
+    st, _keep = f.bijection.packed(dev)
+    pd = target.descriptor(dev)
+    zd = z.detach().to(dev).contiguous()
+    u = torch.empty(n, device=dev)
+    g = torch.empty(n, d, device=dev)
+    hip.check(hip.lib().nfmc_neutra_potential_grad_f32(C.byref(st), C.byref(pd), hip.ptr(zd), n, hip.ptr(u), hip.ptr(g),
+                                                       hip.stream()), 'neutra_potential_grad')
+    scale = 1 + float(g_ref.abs().max())
+    np.testing.assert_allclose(u.cpu().numpy(), u_ref.detach().numpy(), atol=2e-4 * (1 + float(u_ref.abs().max())), rtol=0)
+    np.testing.assert_allclose(g.cpu().numpy(), g_ref.numpy(), atol=2e-4 * scale, rtol=0)
+
+
+def test_neutra_hmc_golden(dev):
+    from nfmc_amd.samplers import neutra, mcmc
+    from nfmc_amd.potentials import SumOfSquares
+    fx = load_golden('neutra_hmc_d6')
+    d = 6
+    s = neutra.NeuTraHMC((d,), SumOfSquares((d,)),
+                         mcmc.HMCKernel(event_size=d, n_leapfrog_steps=int(fx['n_leapfrog']), step_size=float(fx['step_size'])),
+                         mcmc.HMCParameters(), neutra.NeuTraKernel((d,), flow=_amd_flow(fx, d)),
+                         neutra.NeuTraParameters(n_iterations=int(fx['n_iterations'])))
+    s.replay = _noise(fx)
+    out = s.sample(torch.from_numpy(fx['x0']), show_progress=False)
+    _check_out(out, fx, atol=1e-4)
+
+
+def test_neutra_hmc_native_stream_matches_oracle(dev):
+    from nfmc_amd.samplers import neutra, mcmc
+    from nfmc_amd.flows import Flow, RealNVP
+    from nfmc_amd.potentials import Funnel
+    from oracle import flow as oflow, potentials as opot, samplers as osamp
+    d, n, T, L, h = 12, 130, 4, 5, 0.05
+    torch.manual_seed(12)
+    of = oflow.perturb_(oflow.Flow(oflow.RealNVP((d,), conditioner_kwargs={'n_hidden': 8})), 9, 0.3)
+    f = Flow(RealNVP((d,), conditioner_kwargs={'n_hidden': 8}))
+    f.load_state_dict(of.state_dict())
+    z0 = 0.5 * torch.randn(n, d)
+    imd = torch.linspace(0.8, 1.3, d)
+    s = neutra.NeuTraHMC((d,), Funnel((d,), 3.0), mcmc.HMCKernel(event_size=d, n_leapfrog_steps=L, step_size=h,
+                                                                 inv_mass_diag=imd.clone()),
+                         mcmc.HMCParameters(), neutra.NeuTraKernel((d,), flow=f), neutra.NeuTraParameters(n_iterations=T))
+    s.seed = 77
+    out = s.sample(z0, show_progress=False)
+    tr = osamp.neutra_hmc_sample(z0, opot.funnel(3.0), of, T, h, imd, L, noise=osamp.PhiloxNoise(77))
+    got, want = out.samples.reshape(T, n, d), tr.stacked()
+    same = (got - want).abs().amax(dim=(0, 2)) < 3e-4
+    assert same.float().mean() > 0.97
+    np.testing.assert_allclose(got[:, same].numpy(), want[:, same].numpy(), atol=3e-4, rtol=0)
+    assert abs(out.statistics.n_accepted_trajectories - tr.n_accepted) <= 4
+    assert out.statistics.n_target_calls == (2 * L + 2) * n * T and out.statistics.n_target_gradient_calls == 2 * L * n * T
+
+
+def test_neutra_sample_api(dev):
+    from nfmc_amd import sample
+    out = sample(lambda x: torch.sum(x ** 2, dim=1), event_shape=(10,), strategy='neutra_hmc', n_chains=20,
+                 n_iterations=3, show_progress=False, inner_kernel_kwargs={'n_leapfrog_steps': 4, 'step_size': 0.1})
+    assert out.samples.shape == (3, 20, 10) and torch.isfinite(out.samples).all()
+    assert out.mean.shape == (10,) and out.kernel.flow is not None
