@@ -516,3 +516,52 @@ def test_neutra_sample_api(dev):
                  n_iterations=3, show_progress=False, inner_kernel_kwargs={'n_leapfrog_steps': 4, 'step_size': 0.1})
     assert out.samples.shape == (3, 20, 10) and torch.isfinite(out.samples).all()
     assert out.mean.shape == (10,) and out.kernel.flow is not None
+
+
+# ------------------------------------------------------------------------------------------ warmup (f1)
+def test_mala_warmup_tuning_golden(dev):
+    """MCMCSampler.warmup + MetropolisSampler.update_kernel (mcmc/base.py:39-54,142-161) against the reference."""
+    from nfmc_amd.samplers import mcmc
+    from nfmc_amd.potentials import SumOfSquares
+    fx = load_golden('tuning')
+    d = 5
+    s = mcmc.MALA((d,), SumOfSquares((d,)), mcmc.LangevinKernel(event_size=d),
+                  mcmc.LangevinParameters(n_iterations=6, n_warmup_iterations=6))
+    s.replay = _noise(fx)
+    out = s.warmup(torch.from_numpy(fx['x0']), show_progress=False)
+    _check_out(out, fx)
+    np.testing.assert_allclose(s.kernel.step_size, float(fx['tuned_step_size']), rtol=1e-5)
+    np.testing.assert_allclose(s.kernel.inv_mass_diag.numpy(), fx['tuned_inv_mass_diag'], atol=1e-6)
+    assert s.params.tuning is False and s.params.n_iterations == 6
+
+
+@pytest.mark.parametrize('strategy', ['mala', 'hmc', 'imh', 'neutra_hmc'])
+def test_warmup_api(dev, strategy):
+    """test/test_warmup.py: warmup with store_samples=False returns last_sample only."""
+    from nfmc_amd.sample import create_sampler
+    torch.manual_seed(0)
+    s = create_sampler(target=lambda x: torch.sum(x ** 2, dim=-1), event_shape=(10,), strategy=strategy,
+                       param_kwargs={'store_samples': False, 'n_warmup_iterations': 5},
+                       inner_kernel_kwargs={'n_leapfrog_steps': 3} if strategy == 'neutra_hmc' else None)
+    if hasattr(s.params, 'warmup_fit_kwargs') and s.params.warmup_fit_kwargs:
+        s.params.warmup_fit_kwargs.update(n_epochs=20, n_samples=64)
+    out = s.warmup(torch.randn(20, 10), show_progress=False, time_limit_seconds=20.0)
+    assert out.samples is None
+    assert out.running_samples.last_sample.shape == (20, 10)
+
+
+def test_jump_warmup_then_sample_improves_jump_acceptance(dev):
+    """JumpNFMC.warmup (jump.py:104-154): tune the inner sampler, MLE-fit the flow on its samples; afterwards
+    the jumps of the hot path are accepted far more often than with the untrained flow."""
+    from nfmc_amd import sample
+    from nfmc_amd.potentials import SumOfSquares
+    torch.manual_seed(0)
+    d, n = 8, 512
+    kw = dict(strategy='jump_mala', n_chains=n, n_iterations=4, show_progress=False,
+              inner_param_kwargs={'n_iterations': 20}, param_kwargs={'store_samples': False}, seed=3)
+    cold = sample(SumOfSquares((d,)), **kw)
+    torch.manual_seed(0)
+    warm = sample(SumOfSquares((d,)), warmup=True, n_warmup_iterations=100, **kw)
+    assert warm.statistics.jump_acceptance_rate > cold.statistics.jump_acceptance_rate + 0.2
+    assert warm.statistics.jump_acceptance_rate > 0.4
+    np.testing.assert_allclose(warm.variance.numpy(), 0.5, atol=0.08)
