@@ -140,8 +140,9 @@ def recognize(target, event_shape, rtol: float = 1e-5) -> Optional[Potential]:
                 if not torch.allclose(got, want, rtol=rtol, atol=rtol * (1 + want.abs().max())):
                     return None
         # gradient check through autograd (catches targets that detach / are piecewise)
-        x = torch.randn(4, *event_shape, generator=g, dtype=torch.float64).requires_grad_(True)
-        gr, = torch.autograd.grad(target(x).sum(), x)
+        with torch.enable_grad():
+            x = torch.randn(4, *event_shape, generator=g, dtype=torch.float64).requires_grad_(True)
+            gr, = torch.autograd.grad(target(x).sum(), x)
         want_g = (2 * a * (x.detach().reshape(4, -1) - b)).reshape(x.shape)
         if not torch.allclose(gr, want_g, rtol=rtol, atol=rtol * (1 + want_g.abs().max())):
             return None

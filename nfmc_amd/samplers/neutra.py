@@ -73,7 +73,9 @@ class NeuTra(Sampler):
         """U~(z), grad U~(z) from nfmc_neutra_potential_grad_f32 (closed-form targets only)."""
         dev = hip.require_gpu()
         n = z.shape[0]
-        pot = resolve_target(self.target, self.event_shape)
+        if getattr(self, '_pot_cache', None) is None or self._pot_cache[0] is not self.target:
+            self._pot_cache = (self.target, resolve_target(self.target, self.event_shape))
+        pot = self._pot_cache[1]
         if pot is None:
             raise ValueError('NeuTra needs a closed-form potential (nfmc_amd.potentials) for the gradient kernel')
         zf = z.detach().to(dev, torch.float32).reshape(n, -1).contiguous()
