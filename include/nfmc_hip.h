@@ -144,7 +144,8 @@ typedef struct {
     int64_t layer_stride;     /* floats between consecutive coupling layers */
 } NfmcRealNVP;
 
-/* HP: n_hidden padded to the kernels' width (4, 8, 16, 32, then multiples of 32); padding is zero-filled. */
+/* HP: n_hidden padded to the kernels' width (4, 8, 16, 32 on the VALU path; 64 or 128 on the matrix-core path,
+ * whose blob also carries every matrix in both orientations: csrc/mfma_device.hpp); 0 = unsupported. */
 int32_t nfmc_realnvp_padded_hidden(int32_t n_hidden);
 int64_t nfmc_realnvp_layer_floats(int32_t d, int32_t n_hidden, int32_t n_hidden_layers);
 
@@ -198,7 +199,12 @@ typedef struct {
     float* samples;
     uint8_t* masks_out;
     float* log_ratio_out;
+    float* scratch;           /* matrix-core path (n_hidden > 32) only: >= nfmc_neutra_scratch_bytes(...) bytes */
+    int64_t scratch_bytes;
 } NfmcNeutraHmcArgs;
+
+/* 0 for the VALU path (n_hidden <= 32); 4 (n, d) tiles + 2 (n,) vectors for the matrix-core path. */
+int64_t nfmc_neutra_scratch_bytes(int64_t n, int32_t d, int32_t n_hidden);
 
 int nfmc_neutra_hmc_steps_f32(const NfmcNeutraHmcArgs* args, nfmc_stream_t stream);
 

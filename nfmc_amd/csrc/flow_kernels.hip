@@ -8,7 +8,7 @@
 // masked state + cached-log-q update, counters, streaming moments, sample store.
 //
 // One wave per workgroup, one chain per lane, the (64, d) tiles of the wave in LDS (flow_device.hpp).
-#include "flow_device.hpp"
+#include "mfma_device.hpp"
 
 namespace nfmc {
 
@@ -254,12 +254,15 @@ using namespace nfmc;
 
 extern "C" int32_t nfmc_realnvp_padded_hidden(int32_t n_hidden) {
     if (n_hidden <= 0) return 0;
-    return n_hidden <= 32 ? hp_bucket(n_hidden) : ((n_hidden + 31) & ~31);
+    if (n_hidden <= 32) return hp_bucket(n_hidden);
+    return n_hidden <= 64 ? 64 : (n_hidden <= 128 ? 128 : 0);
 }
 
 extern "C" int64_t nfmc_realnvp_layer_floats(int32_t d, int32_t n_hidden, int32_t n_hidden_layers) {
     if (d <= 0 || n_hidden <= 0 || n_hidden_layers <= 0) return 0;
     const int64_t hp = nfmc_realnvp_padded_hidden(n_hidden);
+    if (hp == 0) return 0;
+    if (hp > 32) return mfma_layer_floats(d, (int)hp, n_hidden_layers);
     const int64_t d_a = d / 2, d_b = d - d_a;
     return d_a * hp + hp + (int64_t)(n_hidden_layers - 1) * (hp * hp + hp) + 2 * d_b * hp + 2 * d_b;
 }

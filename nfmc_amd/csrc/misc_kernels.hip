@@ -285,7 +285,7 @@ extern "C" int nfmc_limits(NfmcLimits* out) {
     out->max_d_sampler = 1024;
     out->max_d_flow = 512;
     out->max_hidden_valu = 32;
-    out->max_hidden = 256;
+    out->max_hidden = 128;
     out->max_steps_per_call = NFMC_MAX_STEPS_PER_CALL;
     return NFMC_OK;
 }

@@ -12,7 +12,7 @@
 //
 // Adjacent leapfrog half-steps evaluate grad U~ at the same z; the value is computed once and reused
 // (bitwise what the reference's two evaluations return), counters still report the reference's 2L(+2).
-#include "flow_device.hpp"
+#include "mfma_device.hpp"
 
 namespace nfmc {
 
@@ -404,8 +404,14 @@ using namespace nfmc;
         default: { constexpr int HP = 32; CALL; } break; \
     }
 
+extern "C" int64_t nfmc_neutra_scratch_bytes(int64_t n, int32_t d, int32_t n_hidden) {
+    if (n <= 0 || d <= 0 || n_hidden <= 32) return 0;
+    return (4 * n * (int64_t)d + 2 * n) * (int64_t)sizeof(float);
+}
+
 extern "C" int nfmc_neutra_potential_grad_f32(const NfmcRealNVP* flow, const NfmcPotential* pot, const float* z,
                                               int64_t n, float* u_out, float* grad_out, nfmc_stream_t stream) {
+    if (flow && flow->n_hidden > 32) return nfmc_neutra_potential_grad_mfma_f32(flow, pot, z, n, u_out, grad_out, stream);
     int rc = check_flow_neutra(flow);
     if (rc) return rc;
     if (!pot || !z || n <= 0) return NFMC_EINVAL;
@@ -426,6 +432,14 @@ extern "C" int nfmc_neutra_potential_grad_f32(const NfmcRealNVP* flow, const Nfm
 extern "C" int nfmc_neutra_hmc_steps_f32(const NfmcNeutraHmcArgs* args, nfmc_stream_t stream) {
     if (!args) return NFMC_EINVAL;
     NfmcNeutraHmcArgs a = *args;
+    if (a.flow.n_hidden > 32) {
+        if (!a.z || a.n <= 0 || a.n_steps <= 0 || a.n_leapfrog <= 0 || !(a.step_size > 0.f)) return NFMC_EINVAL;
+        if (a.n_steps > NFMC_MAX_STEPS_PER_CALL) return NFMC_ESHAPE;
+        if (a.pot.kind != NFMC_POT_QUADRATIC && a.pot.kind != NFMC_POT_FUNNEL) return NFMC_EUNSUPPORTED;
+        if (a.stats.sum_x && (!a.stats.sum_x2 || !a.stats.counters || !a.stats.scratch)) return NFMC_EINVAL;
+        if (a.adjust && (a.rng.replay_normals != nullptr) != (a.rng.replay_uniforms != nullptr)) return NFMC_EINVAL;
+        return nfmc_neutra_hmc_steps_mfma_f32(&a, a.scratch, a.scratch_bytes, stream);
+    }
     int rc = check_flow_neutra(&a.flow);
     if (rc) return rc;
     if (!a.z || a.n <= 0 || a.n_steps <= 0 || a.n_leapfrog <= 0 || !(a.step_size > 0.f)) return NFMC_EINVAL;

@@ -1,0 +1,555 @@
+// K5 on the matrix cores: adjusted potential U~(z) = U(f^-1(z)) - logdet_inv(z), its gradient, and the
+// NeuTra-HMC leapfrog around it, for RealNVP conditioners of width 33..128 (BASELINE config 4: d = 128,
+// n_hidden = 128).  Layout and GEMM scheme: mfma_device.hpp.  Replaces neutra.py:58-68 + hmc.py:40-77,96-126.
+//
+// One trajectory = n_leapfrog launches of `neutra_leapfrog_mfma_kernel`; the first also draws the
+// momentum and records H0, the last also does the Hamiltonian test, the masked update and the statistics.
+// Between launches zq / p / grad live in caller-supplied scratch (HBM): 3 tiles read + 3 written per
+// leapfrog = 6*4*d bytes per chain against ~0.5 MFLOP of conditioner GEMMs -- compute bound by >10x.
+#include "mfma_device.hpp"
+
+namespace nfmc {
+
+// ---- closed-form potential and gradient in C layout (tile position = coordinate of x)
+template <int TD>
+__device__ __forceinline__ float potential_value_grad_c(const f32x16 (&x)[TD], f32x16 (&g)[TD], const NfmcPotential& p,
+                                                        int half, int lane) {
+    constexpr int d = 32 * TD;
+    if (p.kind == NFMC_POT_FUNNEL) {
+        const float x0 = __shfl(x[0][0], lane & 31, kWave);  // coordinate 0 = tile 0, reg 0, half 0
+        float s = 0.f;
+#pragma unroll
+        for (int m = 0; m < TD; ++m)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) s = fmaf(x[m][t], (m == 0 && t == 0 && half == 0) ? 0.f : x[m][t], s);
+        s = pair_sum(s);
+        const float inv_s2 = 1.f / (p.a_scalar * p.a_scalar);
+        const float e = fast_exp(-x0);
+        const float hd = 0.5f * (float)(d - 1);
+#pragma unroll
+        for (int m = 0; m < TD; ++m)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) g[m][t] = x[m][t] * e;
+        if (half == 0) g[0][0] = x0 * inv_s2 - 0.5f * e * s + hd;
+        return 0.5f * x0 * x0 * inv_s2 + 0.5f * e * s + hd * x0;
+    }
+    float u = 0.f;
+#pragma unroll
+    for (int m = 0; m < TD; ++m) {
+        f32x16 a, b;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            a[t] = p.a_scalar;
+            b[t] = p.b_scalar;
+        }
+        if (p.a) a = vec_tile(p.a, m, half);
+        if (p.b) b = vec_tile(p.b, m, half);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const float dlt = x[m][t] - b[t];
+            u = fmaf(a[t] * dlt, dlt, u);
+            g[m][t] = 2.f * a[t] * dlt;
+        }
+    }
+    return pair_sum(u);
+}
+
+// ---- inverse coupling layer, forward sweep (v -> y): returns this lane's share of the layer's logdet_inverse
+template <int TD, int TH, int NHL, bool REV>
+__device__ __forceinline__ float coupling_inverse_c(f32x16 (&x)[TD], const MLayer& L, float mscale, float log1m,
+                                                    float* lds, int col, int half) {
+    constexpr int TS = TD / 2, SRC0 = REV ? TS : 0, TGT0 = REV ? 0 : TS, D2 = 16 * TD, hp = 32 * TH;
+    float* img0 = lds;
+    float* vec = lds + 2 * kImgFloats;
+    f32x16 src[TS], h1[TH], h2[TH];
+#pragma unroll
+    for (int ms = 0; ms < TS; ++ms) src[ms] = x[SRC0 + ms];
+    hidden_stack<TS, TH, NHL>(src, h1, h2, L, hp, D2, REV, img0, vec, col, half);
+    __syncthreads();
+    stage_matrix(img0, L.W3, 2 * D2, hp, REV, D2, false, 1);
+    stage_vector(vec, L.b3, 2 * D2, REV, D2);
+    __syncthreads();
+    float ld = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < TS; ++mt) {
+        f32x16 ua = vec_tile(vec, mt, half), ub = vec_tile(vec, TS + mt, half);
+        if constexpr (NHL > 1) {
+            gemm_tile<TH>(ua, img0 + (32 * mt + col) * (hp + 4) + 4 * half, h2);
+            gemm_tile<TH>(ub, img0 + (32 * (TS + mt) + col) * (hp + 4) + 4 * half, h2);
+        } else {
+            gemm_tile<TH>(ua, img0 + (32 * mt + col) * (hp + 4) + 4 * half, h1);
+            gemm_tile<TH>(ub, img0 + (32 * (TS + mt) + col) * (hp + 4) + 4 * half, h1);
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const float alpha = fast_exp(fmaf(0.5f, ua[t], log1m)) + mscale;
+            x[TGT0 + mt][t] = (x[TGT0 + mt][t] - 0.5f * ub[t]) * __builtin_amdgcn_rcpf(alpha);
+            ld -= fast_ln(alpha);
+        }
+    }
+    return ld;
+}
+
+// ---- reverse sweep through one inverse coupling layer: (y, dL/dy) -> (v, dL/dv); L = U(x) + sum log alpha
+template <int TD, int TH, int NHL, bool REV>
+__device__ __forceinline__ void coupling_inverse_backward_c(f32x16 (&x)[TD], f32x16 (&g)[TD], const MLayer& L,
+                                                            float mscale, float log1m, float* lds, int col,
+                                                            int half) {
+    constexpr int TS = TD / 2, SRC0 = REV ? TS : 0, TGT0 = REV ? 0 : TS, D2 = 16 * TD, hp = 32 * TH;
+    float* img0 = lds;
+    float* img1 = lds + kImgFloats;
+    float* vec = lds + 2 * kImgFloats;
+    f32x16 src[TS], h1[TH], h2[TH];
+#pragma unroll
+    for (int ms = 0; ms < TS; ++ms) src[ms] = x[SRC0 + ms];
+    hidden_stack<TS, TH, NHL>(src, h1, h2, L, hp, D2, REV, img0, vec, col, half);
+    __syncthreads();
+    stage_matrix(img0, L.W3, 2 * D2, hp, REV, D2, false, 1);
+    stage_matrix(img1, L.W3T, hp, 2 * D2, false, 1, REV, D2);
+    stage_vector(vec, L.b3, 2 * D2, REV, D2);
+    __syncthreads();
+    f32x16 dh[TH];
+#pragma unroll
+    for (int mo = 0; mo < TH; ++mo)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) dh[mo][t] = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < TS; ++mt) {
+        f32x16 ua = vec_tile(vec, mt, half), ub = vec_tile(vec, TS + mt, half);
+        if constexpr (NHL > 1) {
+            gemm_tile<TH>(ua, img0 + (32 * mt + col) * (hp + 4) + 4 * half, h2);
+            gemm_tile<TH>(ub, img0 + (32 * (TS + mt) + col) * (hp + 4) + 4 * half, h2);
+        } else {
+            gemm_tile<TH>(ua, img0 + (32 * mt + col) * (hp + 4) + 4 * half, h1);
+            gemm_tile<TH>(ub, img0 + (32 * (TS + mt) + col) * (hp + 4) + 4 * half, h1);
+        }
+        f32x16 du[1], dv[1];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const float alpha = fast_exp(fmaf(0.5f, ua[t], log1m)) + mscale;
+            const float beta = 0.5f * ub[t];
+            const float ra = __builtin_amdgcn_rcpf(alpha);
+            const float y = x[TGT0 + mt][t];
+            const float gv = g[TGT0 + mt][t] * ra;
+            const float d_alpha = fmaf(-gv, y, ra);
+            du[0][t] = 0.5f * d_alpha * (alpha - mscale);
+            dv[0][t] = -0.5f * gv;
+            g[TGT0 + mt][t] = gv;
+            x[TGT0 + mt][t] = fmaf(alpha, y, beta);
+        }
+#pragma unroll
+        for (int mo = 0; mo < TH; ++mo) {  // dh += W3^T[:, alpha rows of tile mt] du + W3^T[:, beta rows] dv
+            const float* arow = img1 + (32 * mo + col) * (2 * D2 + 4) + 4 * half;
+            gemm_tile<1>(dh[mo], arow + 32 * mt, du);
+            gemm_tile<1>(dh[mo], arow + D2 + 32 * mt, dv);
+        }
+    }
+    // back through the hidden stack (weights in the transposed orientation)
+    if constexpr (NHL > 1) {
+#pragma unroll
+        for (int mo = 0; mo < TH; ++mo)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) dh[mo][t] *= (1.f - h2[mo][t] * h2[mo][t]);
+        __syncthreads();
+        stage_matrix(img0, L.WhT, hp, hp, false, 1, false, 1);
+        __syncthreads();
+        f32x16 d1[TH];
+#pragma unroll
+        for (int mo = 0; mo < TH; ++mo) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) d1[mo][t] = 0.f;
+            gemm_tile<TH>(d1[mo], img0 + (32 * mo + col) * (hp + 4) + 4 * half, dh);
+        }
+#pragma unroll
+        for (int mo = 0; mo < TH; ++mo) dh[mo] = d1[mo];
+    }
+#pragma unroll
+    for (int mo = 0; mo < TH; ++mo)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) dh[mo][t] *= (1.f - h1[mo][t] * h1[mo][t]);
+    __syncthreads();
+    stage_matrix(img0, L.W1T, D2, hp, REV, D2, false, 1);
+    __syncthreads();
+#pragma unroll
+    for (int ms = 0; ms < TS; ++ms) gemm_tile<TH>(g[SRC0 + ms], img0 + (32 * ms + col) * (hp + 4) + 4 * half, dh);
+}
+
+// ---- U~(z), grad U~(z) for the wave's 32 chains.  x: in z (tile positions in latent order), out z again
+// (rebuilt through the inverse of every step); g: gradient in the same positions.  Workgroup-collective.
+template <int TD, int TH, int NHL>
+__device__ __forceinline__ float adjusted_grad_c(f32x16 (&x)[TD], f32x16 (&g)[TD], const NfmcRealNVP& f,
+                                                 const NfmcPotential& pot, float* lds, int col, int half, int lane) {
+    constexpr int d = 32 * TD, hp = 32 * TH;
+    const bool rev_last = (f.n_coupling & 1) != 0;
+    const float log1m = __logf(1.f - f.min_scale);
+    float ldp = 0.f;
+#pragma unroll
+    for (int m = 0; m < TD; ++m) {  // EA1^-1
+        const f32x16 ls = rev_last ? vec_tile_rev(f.ea1_log_scale, m, half, d) : vec_tile(f.ea1_log_scale, m, half);
+        const f32x16 sh = rev_last ? vec_tile_rev(f.ea1_shift, m, half, d) : vec_tile(f.ea1_shift, m, half);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            x[m][t] = (x[m][t] - sh[t]) * fast_exp(-ls[t]);
+            ldp -= ls[t];
+        }
+    }
+    for (int l = f.n_coupling - 1; l >= 0; --l) {
+        const MLayer L = mfma_layer(f.weights + l * f.layer_stride, d, hp, NHL);
+        if ((l & 1) == 0) ldp += coupling_inverse_c<TD, TH, NHL, true>(x, L, f.min_scale, log1m, lds, col, half);
+        else ldp += coupling_inverse_c<TD, TH, NHL, false>(x, L, f.min_scale, log1m, lds, col, half);
+    }
+#pragma unroll
+    for (int m = 0; m < TD; ++m) {  // EA0^-1
+        const f32x16 ls = vec_tile(f.ea0_log_scale, m, half), sh = vec_tile(f.ea0_shift, m, half);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            x[m][t] = (x[m][t] - sh[t]) * fast_exp(-ls[t]);
+            ldp -= ls[t];
+        }
+    }
+    const float u = potential_value_grad_c<TD>(x, g, pot, half, lane);
+    // reverse sweep
+#pragma unroll
+    for (int m = 0; m < TD; ++m) {
+        const f32x16 ls = vec_tile(f.ea0_log_scale, m, half), sh = vec_tile(f.ea0_shift, m, half);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            g[m][t] *= fast_exp(-ls[t]);
+            x[m][t] = fmaf(fast_exp(ls[t]), x[m][t], sh[t]);
+        }
+    }
+    for (int l = 0; l < f.n_coupling; ++l) {
+        const MLayer L = mfma_layer(f.weights + l * f.layer_stride, d, hp, NHL);
+        if ((l & 1) == 0) coupling_inverse_backward_c<TD, TH, NHL, true>(x, g, L, f.min_scale, log1m, lds, col, half);
+        else coupling_inverse_backward_c<TD, TH, NHL, false>(x, g, L, f.min_scale, log1m, lds, col, half);
+    }
+#pragma unroll
+    for (int m = 0; m < TD; ++m) {
+        const f32x16 ls = rev_last ? vec_tile_rev(f.ea1_log_scale, m, half, d) : vec_tile(f.ea1_log_scale, m, half);
+        const f32x16 sh = rev_last ? vec_tile_rev(f.ea1_shift, m, half, d) : vec_tile(f.ea1_shift, m, half);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            g[m][t] *= fast_exp(-ls[t]);
+            x[m][t] = fmaf(fast_exp(ls[t]), x[m][t], sh[t]);
+        }
+    }
+    return u - pair_sum(ldp);
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int TD, int TH, int NHL>
+__global__ void __launch_bounds__(kMfmaBlock) neutra_grad_mfma_kernel(NfmcRealNVP f, NfmcPotential pot,
+                                                                      const float* __restrict__ z, int64_t n,
+                                                                      float* __restrict__ u_out,
+                                                                      float* __restrict__ grad_out, int64_t tiles) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int d = 32 * TD;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 31, half = lane >> 5;
+    const bool rev = (f.n_coupling & 1) != 0;
+    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int64_t row = tile * kMfmaChains + wave * 32 + col;
+        const bool active = row < n;
+        const int64_t rrow = active ? row : n - 1;
+        f32x16 x[TD], g[TD];
+        load_ctiles<TD>(x, z, rrow, d, half, rev);
+        const float u = adjusted_grad_c<TD, TH, NHL>(x, g, f, pot, lds, col, half, lane);
+        if (active) {
+            if (u_out && half == 0) u_out[row] = u;
+            if (grad_out) store_ctiles<TD>(g, grad_out, row, d, half, rev);
+        }
+    }
+}
+
+struct LeapArgs {
+    NfmcNeutraHmcArgs a;
+    float *zq, *p, *g, *gz, *uz, *h0;  // scratch: trajectory position / momentum / grad, grad and U~ at the state, H0
+    int step;                           // transition index within this call
+    int first, last;
+};
+
+// mass / momentum helpers in C layout: tile position pos <-> logical latent coordinate (rev ? d-1-pos : pos)
+template <int TD>
+__device__ __forceinline__ void mass_tiles(f32x16 (&m)[TD], const float* imd, int half, bool rev) {
+    constexpr int d = 32 * TD;
+#pragma unroll
+    for (int k = 0; k < TD; ++k) {
+        if (imd) m[k] = rev ? vec_tile_rev(imd, k, half, d) : vec_tile(imd, k, half);
+        else
+#pragma unroll
+            for (int t = 0; t < 16; ++t) m[k][t] = 1.f;
+    }
+}
+
+template <int TD, int TH, int NHL>
+__global__ void __launch_bounds__(kMfmaBlock) neutra_leapfrog_mfma_kernel(LeapArgs A, int64_t tiles, int dp) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int d = 32 * TD;
+    const NfmcNeutraHmcArgs& a = A.a;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 31, half = lane >> 5;
+    const bool rev = (a.flow.n_coupling & 1) != 0;
+    const int64_t n = a.n;
+    const float h = a.step_size, hh = a.step_size / 2;
+    const int s = A.step;
+
+    // statistics accumulate in LDS behind the weight images (nothing extra stays live across the GEMMs)
+    double* red = reinterpret_cast<double*>(lds + 2 * kImgFloats + kVecFloats);  // [4 waves][2*d + 2]
+    uint32_t n_acc = 0, n_bad = 0;
+    if (A.last) {
+        for (int i = threadIdx.x; i < 4 * (2 * d + 2); i += kMfmaBlock) red[i] = 0.0;
+        __syncthreads();
+    }
+
+    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int64_t row = tile * kMfmaChains + wave * 32 + col;
+        const bool active = row < n;
+        const int64_t rrow = active ? row : n - 1;
+        f32x16 x[TD], g[TD], mass[TD];
+        mass_tiles<TD>(mass, a.inv_mass_diag, half, rev);
+        {
+            f32x16 p[TD];
+            if (A.first) {
+                load_ctiles<TD>(x, a.z, rrow, d, half, rev);
+                load_ctiles<TD>(g, A.gz, rrow, d, half, rev);
+                float kin = 0.f;
+                const uint32_t gchain = (uint32_t)(a.rng.chain_offset + (uint64_t)rrow);
+#pragma unroll
+                for (int m = 0; m < TD; ++m) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int p0 = 32 * m + 8 * q + 4 * half;  // tile position of this 4-block
+                        float zz[4];
+                        if (a.rng.replay_normals) {
+                            const float* src = a.rng.replay_normals + ((int64_t)s * n + rrow) * d;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) zz[j] = src[rev ? d - 1 - (p0 + j) : p0 + j];
+                        } else {
+                            const int blk = rev ? (d - 4 - p0) >> 2 : p0 >> 2;
+                            float w[4];
+                            philox_normal4(gchain, a.rng.step0 + (uint32_t)s, (uint32_t)blk, kTagNoise,
+                                           (uint32_t)a.rng.seed, (uint32_t)(a.rng.seed >> 32), w);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) zz[j] = rev ? w[3 - j] : w[j];
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float mm = mass[m][4 * q + j];
+                            const float v = zz[j] * (1.f / sqrtf(mm));   // hmc.py:100
+                            p[m][4 * q + j] = v;
+                            kin = fmaf(v * v, mm, kin);
+                        }
+                    }
+                }
+                kin = pair_sum(kin);
+                if (active && half == 0) A.h0[row] = A.uz[row] + 0.5f * kin;  // hmc.py:103-106
+            } else {
+                load_ctiles<TD>(x, A.zq, rrow, d, half, rev);
+                load_ctiles<TD>(g, A.g, rrow, d, half, rev);
+                load_ctiles<TD>(p, A.p, rrow, d, half, rev);
+            }
+#pragma unroll
+            for (int m = 0; m < TD; ++m)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {  // hmc.py:68-70
+                    p[m][t] = fmaf(-hh, g[m][t], p[m][t]);
+                    x[m][t] = fmaf(h, p[m][t] * mass[m][t], x[m][t]);
+                }
+            if (active) store_ctiles<TD>(p, A.p, row, d, half, rev);  // momentum is not live across the GEMMs
+        }
+        const float u = adjusted_grad_c<TD, TH, NHL>(x, g, a.flow, a.pot, lds, col, half, lane);
+        f32x16 p[TD];
+        load_ctiles<TD>(p, A.p, rrow, d, half, rev);
+#pragma unroll
+        for (int m = 0; m < TD; ++m)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) p[m][t] = fmaf(-hh, g[m][t], p[m][t]);  // hmc.py:71
+        if (!A.last) {
+            if (active) {
+                store_ctiles<TD>(x, A.zq, row, d, half, rev);
+                store_ctiles<TD>(p, A.p, row, d, half, rev);
+                store_ctiles<TD>(g, A.g, row, d, half, rev);
+            }
+            continue;
+        }
+        // ---- end of the trajectory: Hamiltonian test, masked update, statistics
+        bool accept = true;
+        float lr = 0.f;
+        if (a.adjust) {
+            float kin = 0.f;
+#pragma unroll
+            for (int m = 0; m < TD; ++m)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) kin = fmaf(p[m][t] * p[m][t], mass[m][t], kin);
+            kin = pair_sum(kin);
+            lr = A.h0[rrow] - (u + 0.5f * kin);  // hmc.py:107-111
+            float uni;
+            if (a.rng.replay_uniforms) {
+                uni = a.rng.replay_uniforms[(int64_t)s * n + rrow];
+            } else {
+                const uint32_t step = a.rng.step0 + (uint32_t)s;
+                const uint4 r = philox4x32_10((uint32_t)(a.rng.chain_offset + (uint64_t)rrow), step >> 2, 0u,
+                                              kTagAccept, (uint32_t)a.rng.seed, (uint32_t)(a.rng.seed >> 32));
+                uni = u32_to_uniform(pick_word(r, step & 3u));
+            }
+            accept = fast_ln(uni) < lr;  // hmc.py:112-113
+            if (active && half == 0 && !(fabsf(lr) <= 3.0e38f)) n_bad++;
+        }
+        accept = accept && active;
+        f32x16 zc[TD];
+        if (accept) {
+#pragma unroll
+            for (int m = 0; m < TD; ++m) zc[m] = x[m];
+            store_ctiles<TD>(x, a.z, row, d, half, rev);
+            store_ctiles<TD>(g, A.gz, row, d, half, rev);
+            if (half == 0) {
+                A.uz[row] = u;
+                n_acc++;
+            }
+        } else {
+            load_ctiles<TD>(zc, a.z, rrow, d, half, rev);
+        }
+        if (active) {
+            if (half == 0) {
+                if (a.masks_out) a.masks_out[(int64_t)s * n + row] = accept ? 1 : 0;
+                if (a.log_ratio_out) a.log_ratio_out[(int64_t)s * n + row] = lr;
+            }
+            if (a.samples) store_ctiles<TD>(zc, a.samples + (int64_t)s * n * d, row, d, half, rev);
+        }
+        if (a.stats.sum_x) {  // sums over the 32 chains of the wave (lanes with equal half), kept per wave in LDS
+#pragma unroll
+            for (int m = 0; m < TD; ++m)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const float zv = active ? zc[m][t] : 0.f;
+                    double v1 = (double)zv, v2 = (double)zv * (double)zv;
+                    for (int k = 1; k < 32; k <<= 1) {
+                        v1 += __shfl_xor(v1, k, kWave);
+                        v2 += __shfl_xor(v2, k, kWave);
+                    }
+                    if (col == 0) {
+                        const int pos = 32 * m + (t & 3) + 8 * (t >> 2) + 4 * half;
+                        const int c = rev ? d - 1 - pos : pos;  // logical latent coordinate
+                        red[wave * (2 * d + 2) + c] += v1;
+                        red[wave * (2 * d + 2) + d + c] += v2;
+                    }
+                }
+        }
+    }
+    if (A.last && a.stats.sum_x) {
+        for (int m = 1; m < 32; m <<= 1) {
+            n_acc += __shfl_xor(n_acc, m, kWave);
+            n_bad += __shfl_xor(n_bad, m, kWave);
+        }
+        if (lane == 0) {
+            red[wave * (2 * d + 2) + 2 * d] = (double)n_acc;
+            red[wave * (2 * d + 2) + 2 * d + 1] = (double)n_bad;
+        }
+        __syncthreads();
+        double* out = a.stats.scratch + (size_t)blockIdx.x * (2 * dp + kStatTail);
+        for (int i = threadIdx.x; i < 2 * dp + kStatTail; i += kMfmaBlock) {
+            double v = 0.0;
+            int srci = -1;
+            if (i < dp) srci = i < d ? i : -1;
+            else if (i < 2 * dp) srci = (i - dp) < d ? d + (i - dp) : -1;
+            else if (i == 2 * dp) srci = 2 * d;
+            else if (i == 2 * dp + 1) srci = 2 * d + 1;
+            if (srci >= 0)
+                for (int w = 0; w < 4; ++w) v += red[w * (2 * d + 2) + srci];
+            out[i] = v;
+        }
+    }
+}
+
+// initial U~(z), grad at the state (also used after the caller changed z)
+template <int TD, int TH, int NHL>
+static int launch_grad(const NfmcRealNVP& f, const NfmcPotential& pot, const float* z, int64_t n, float* u, float* g,
+                       hipStream_t st) {
+    const int64_t tiles = (n + kMfmaChains - 1) / kMfmaChains;
+    const int grid = (int)(tiles < kMaxGrid ? tiles : kMaxGrid);
+    auto kern = neutra_grad_mfma_kernel<TD, TH, NHL>;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMfmaLdsBytes);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kMfmaBlock), kMfmaLdsBytes, st, f, pot, z, n, u, g, tiles);
+    return 0;
+}
+
+template <int TD, int TH, int NHL>
+static int run_hmc(const NfmcNeutraHmcArgs& a, float* scratch, hipStream_t st) {
+    constexpr int d = 32 * TD;
+    const int64_t n = a.n;
+    LeapArgs A;
+    A.a = a;
+    A.zq = scratch;
+    A.p = A.zq + n * d;
+    A.g = A.p + n * d;
+    A.gz = A.g + n * d;
+    A.uz = A.gz + n * d;
+    A.h0 = A.uz + n;
+    int rc = launch_grad<TD, TH, NHL>(a.flow, a.pot, a.z, n, A.uz, A.gz, st);
+    if (rc) return rc;
+    const int64_t tiles = (n + kMfmaChains - 1) / kMfmaChains;
+    const int grid = (int)(tiles < kMaxGrid ? tiles : kMaxGrid);
+    const int dp = padded_d(d);
+    auto kern = neutra_leapfrog_mfma_kernel<TD, TH, NHL>;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMfmaLdsBytes);
+    if (e != hipSuccess) return (int)e;
+    for (int s = 0; s < a.n_steps; ++s) {
+        for (int l = 0; l < a.n_leapfrog; ++l) {
+            A.step = s;
+            A.first = (l == 0);
+            A.last = (l == a.n_leapfrog - 1);
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(kMfmaBlock), kMfmaLdsBytes, st, A, tiles, dp);
+        }
+        if (a.stats.sum_x) {
+            hipLaunchKernelGGL(stats_finish_kernel, dim3(stats_finish_grid(dp)), dim3(kFinishBlock), 0, st,
+                               a.stats.scratch, grid, dp, d, a.stats, (unsigned long long)n);
+        }
+    }
+    hipError_t le = hipGetLastError();
+    return le == hipSuccess ? 0 : (int)le;
+}
+
+}  // namespace nfmc
+
+using namespace nfmc;
+
+#define NFMC_MFMA_DISPATCH(TDV, THV, NHLV, CALL)                                        \
+    if (TDV == 2 && THV == 2 && NHLV == 1) { constexpr int TD = 2, TH = 2, NHL = 1; CALL; }      \
+    else if (TDV == 2 && THV == 2 && NHLV == 2) { constexpr int TD = 2, TH = 2, NHL = 2; CALL; } \
+    else if (TDV == 2 && THV == 4 && NHLV == 1) { constexpr int TD = 2, TH = 4, NHL = 1; CALL; } \
+    else if (TDV == 2 && THV == 4 && NHLV == 2) { constexpr int TD = 2, TH = 4, NHL = 2; CALL; } \
+    else if (TDV == 4 && THV == 2 && NHLV == 1) { constexpr int TD = 4, TH = 2, NHL = 1; CALL; } \
+    else if (TDV == 4 && THV == 2 && NHLV == 2) { constexpr int TD = 4, TH = 2, NHL = 2; CALL; } \
+    else if (TDV == 4 && THV == 4 && NHLV == 1) { constexpr int TD = 4, TH = 4, NHL = 1; CALL; } \
+    else if (TDV == 4 && THV == 4 && NHLV == 2) { constexpr int TD = 4, TH = 4, NHL = 2; CALL; } \
+    else return NFMC_EUNSUPPORTED;
+
+// shapes the matrix-core path covers
+int nfmc::nfmc_mfma_supported(int32_t d, int32_t n_hidden, int32_t n_hidden_layers) {
+    return (d == 64 || d == 128) && n_hidden > 32 && n_hidden <= 128 && n_hidden_layers >= 1 && n_hidden_layers <= 2;
+}
+
+int nfmc::nfmc_neutra_potential_grad_mfma_f32(const NfmcRealNVP* flow, const NfmcPotential* pot, const float* z,
+                                                   int64_t n, float* u_out, float* grad_out, nfmc_stream_t stream) {
+    if (!flow || !pot || !z || n <= 0) return NFMC_EINVAL;
+    if (!nfmc_mfma_supported(flow->d, flow->n_hidden, flow->n_hidden_layers)) return NFMC_EUNSUPPORTED;
+    const int td = flow->d / 32, th = nfmc_realnvp_padded_hidden(flow->n_hidden) / 32, nhl = flow->n_hidden_layers;
+    int rc = 0;
+    NFMC_MFMA_DISPATCH(td, th, nhl, rc = (launch_grad<TD, TH, NHL>(*flow, *pot, z, n, u_out, grad_out, (hipStream_t)stream)))
+    if (rc) return rc;
+    NFMC_HIP_CHECK_LAUNCH();
+    return NFMC_OK;
+}
+
+int nfmc::nfmc_neutra_hmc_steps_mfma_f32(const NfmcNeutraHmcArgs* args, float* scratch, int64_t scratch_bytes,
+                                              nfmc_stream_t stream) {
+    if (!args || !scratch) return NFMC_EINVAL;
+    const NfmcNeutraHmcArgs& a = *args;
+    if (!nfmc_mfma_supported(a.flow.d, a.flow.n_hidden, a.flow.n_hidden_layers)) return NFMC_EUNSUPPORTED;
+    if (scratch_bytes < nfmc_neutra_scratch_bytes(a.n, a.flow.d, a.flow.n_hidden)) return NFMC_ESCRATCH;
+    const int td = a.flow.d / 32, th = nfmc_realnvp_padded_hidden(a.flow.n_hidden) / 32, nhl = a.flow.n_hidden_layers;
+    int rc = 0;
+    NFMC_MFMA_DISPATCH(td, th, nhl, rc = (run_hmc<TD, TH, NHL>(a, scratch, (hipStream_t)stream)))
+    return rc;
+}

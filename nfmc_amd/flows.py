@@ -107,25 +107,37 @@ class RealNVP(nn.Module):
         hp = int(lib.nfmc_realnvp_padded_hidden(H))
         stride = int(lib.nfmc_realnvp_layer_floats(d, H, nhl))
         d_a, d_b = d // 2, d - d // 2
+        if hp == 0:
+            raise ValueError('RealNVP conditioner width %d is beyond the kernels (max 128)' % H)
         with torch.no_grad():
             blobs = []
             for cpl in self.couplings:
                 lin = list(cpl.conditioner)
                 parts = []
-                w1t = torch.zeros(d_a, hp)
-                w1t[:, :H] = lin[0].weight.detach().float().cpu().t()
-                b1 = torch.zeros(hp)
-                b1[:H] = lin[0].bias.detach().float().cpu()
-                parts += [w1t.reshape(-1), b1]
-                for l in lin[1:-1]:
-                    wt = torch.zeros(hp, hp)
-                    wt[:H, :H] = l.weight.detach().float().cpu().t()
-                    bh = torch.zeros(hp)
-                    bh[:H] = l.bias.detach().float().cpu()
-                    parts += [wt.reshape(-1), bh]
-                w3 = torch.zeros(2 * d_b, hp)
-                w3[:, :H] = lin[-1].weight.detach().float().cpu()
-                parts += [w3.reshape(-1), lin[-1].bias.detach().float().cpu()]
+
+                def padded(w, rows, cols):
+                    out = torch.zeros(rows, cols)
+                    out[:w.shape[0], :w.shape[1]] = w.detach().float().cpu()
+                    return out
+
+                def padded_vec(b, n):
+                    out = torch.zeros(n)
+                    out[:b.shape[0]] = b.detach().float().cpu()
+                    return out
+
+                w1 = padded(lin[0].weight, hp, d_a)                       # (out, in)
+                if hp > 32:  # matrix-core path: both orientations (csrc/mfma_device.hpp)
+                    parts += [w1.reshape(-1), w1.t().contiguous().reshape(-1), padded_vec(lin[0].bias, hp)]
+                    for l in lin[1:-1]:
+                        wh = padded(l.weight, hp, hp)
+                        parts += [wh.reshape(-1), wh.t().contiguous().reshape(-1), padded_vec(l.bias, hp)]
+                    w3 = padded(lin[-1].weight, 2 * d_b, hp)
+                    parts += [w3.reshape(-1), w3.t().contiguous().reshape(-1), lin[-1].bias.detach().float().cpu()]
+                else:        # VALU path: W1T | b1 | [WhT | bh] | W3 | b3
+                    parts += [w1.t().contiguous().reshape(-1), padded_vec(lin[0].bias, hp)]
+                    for l in lin[1:-1]:
+                        parts += [padded(l.weight, hp, hp).t().contiguous().reshape(-1), padded_vec(l.bias, hp)]
+                    parts += [padded(lin[-1].weight, 2 * d_b, hp).reshape(-1), lin[-1].bias.detach().float().cpu()]
                 blob = torch.cat(parts)
                 assert blob.numel() == stride, (blob.numel(), stride)
                 blobs.append(blob)

@@ -69,7 +69,8 @@ class NfmcNeutraHmcArgs(C.Structure):
     _fields_ = [('z', c_fp), ('n', C.c_int64), ('n_steps', C.c_int32), ('n_leapfrog', C.c_int32),
                 ('step_size', C.c_float), ('adjust', C.c_int32), ('inv_mass_diag', c_fp),
                 ('flow', NfmcRealNVP), ('pot', NfmcPotential), ('rng', NfmcRng), ('stats', NfmcStats),
-                ('samples', c_fp), ('masks_out', c_fp), ('log_ratio_out', c_fp)]
+                ('samples', c_fp), ('masks_out', c_fp), ('log_ratio_out', c_fp), ('scratch', c_fp),
+                ('scratch_bytes', C.c_int64)]
 
 
 class NfmcSelectArgs(C.Structure):
@@ -95,6 +96,7 @@ SYMBOLS = [
     ('nfmc_realnvp_inverse_f32', C.c_int, [C.POINTER(NfmcRealNVP), c_fp, C.c_int64, c_fp, c_fp, c_fp,
                                            C.POINTER(NfmcRng), c_fp]),
     ('nfmc_flow_mh_steps_f32', C.c_int, [C.POINTER(NfmcFlowMhArgs), c_fp]),
+    ('nfmc_neutra_scratch_bytes', C.c_int64, [C.c_int64, C.c_int32, C.c_int32]),
     ('nfmc_neutra_hmc_steps_f32', C.c_int, [C.POINTER(NfmcNeutraHmcArgs), c_fp]),
     ('nfmc_neutra_potential_grad_f32', C.c_int, [C.POINTER(NfmcRealNVP), C.POINTER(NfmcPotential), c_fp, C.c_int64,
                                                  c_fp, c_fp, c_fp]),

@@ -116,6 +116,9 @@ class NeuTra(Sampler):
         buf = torch.empty(T, n, d, dtype=torch.float32, device=run.dev) if (self.params.store_samples and T > 0) else None
         st_flow, _keep = self.kernel.flow.bijection.packed(run.dev)
         imd = imd_tensor(inner.kernel, run.dev)
+        bij = self.kernel.flow.bijection
+        sbytes = int(hip.lib().nfmc_neutra_scratch_bytes(n, d, bij.n_hidden))
+        scratch = torch.empty(max(sbytes // 4, 1), dtype=torch.float32, device=run.dev)
         t0 = time.time()
         done = 0
         limit = hip.MAX_STEPS_PER_CALL if (time_limit_seconds is None and not show_progress) else 4
@@ -137,6 +140,7 @@ class NeuTra(Sampler):
             a.rng = run.rng(done, k, adjusted=inner.params.adjustment)
             a.stats = run.stats.struct()
             a.samples = hip.ptr(buf[done:done + k]) if buf is not None else None
+            a.scratch, a.scratch_bytes = hip.ptr(scratch), sbytes
             hip.check(hip.lib().nfmc_neutra_hmc_steps_f32(C.byref(a), hip.stream()), 'nfmc_neutra_hmc_steps_f32')
             done += k
             bar.update(k)

@@ -565,3 +565,64 @@ def test_jump_warmup_then_sample_improves_jump_acceptance(dev):
     assert warm.statistics.jump_acceptance_rate > cold.statistics.jump_acceptance_rate + 0.2
     assert warm.statistics.jump_acceptance_rate > 0.4
     np.testing.assert_allclose(warm.variance.numpy(), 0.5, atol=0.08)
+
+
+# ------------------------------------------------------------------------------------------ matrix-core path (wide conditioners)
+@pytest.mark.parametrize('d,nl,nh,cl,pot', [(64, 2, 64, 1, 'sumsq'), (64, 3, 40, 2, 'funnel'), (128, 2, 128, 2, 'funnel'),
+                                             (128, 1, 100, 1, 'sumsq'), (128, 2, 64, 2, 'sumsq'), (64, 2, 128, 2, 'sumsq')])
+def test_neutra_mfma_potential_and_gradient_match_autograd(dev, d, nl, nh, cl, pot):
+    """Wide conditioners run on v_mfma_f32_32x32x2_f32; same check as the VALU path: VJP == autograd of the
+    CPU restatement.  fp32 MFMA is an exact fp32 fma chain, so the tolerance stays at the fp32 level."""
+    from nfmc_amd import hip
+    from nfmc_amd.flows import Flow, RealNVP
+    from nfmc_amd.potentials import SumOfSquares, Funnel
+    from oracle import flow as oflow, potentials as opot, samplers as osamp
+    ck = {'n_layers': cl, 'n_hidden': nh}
+    torch.manual_seed(d + nl + nh)
+    of = oflow.perturb_(oflow.Flow(oflow.RealNVP((d,), n_layers=nl, conditioner_kwargs=ck)), 3, 0.15, 0.8)
+    f = Flow(RealNVP((d,), n_layers=nl, conditioner_kwargs=ck))
+    f.load_state_dict(of.state_dict())
+    target_cpu = opot.sum_squares if pot == 'sumsq' else opot.funnel(3.0)
+    target = SumOfSquares((d,)) if pot == 'sumsq' else Funnel((d,), 3.0)
+    n = 200   # not a multiple of the 128-chain workgroup tile
+    z = (0.6 * torch.randn(n, d)).requires_grad_(True)
+    u_ref = osamp.neutra_adjusted_target(of, target_cpu, (d,))(z)
+    g_ref, = torch.autograd.grad(u_ref.sum(), z)
+    st, _keep = f.bijection.packed(dev)
+    pd = target.descriptor(dev)
+    zd = z.detach().to(dev).contiguous()
+    u = torch.empty(n, device=dev)
+    g = torch.empty(n, d, device=dev)
+    hip.check(hip.lib().nfmc_neutra_potential_grad_f32(C.byref(st), C.byref(pd), hip.ptr(zd), n, hip.ptr(u), hip.ptr(g),
+                                                       hip.stream()), 'neutra_potential_grad')
+    np.testing.assert_allclose(u.cpu().numpy(), u_ref.detach().numpy(), atol=3e-4 * (1 + float(u_ref.detach().abs().max())), rtol=0)
+    np.testing.assert_allclose(g.cpu().numpy(), g_ref.numpy(), atol=3e-4 * (1 + float(g_ref.abs().max())), rtol=0)
+
+
+@pytest.mark.parametrize('d,nh,cl,nl', [(64, 64, 1, 2), (128, 128, 2, 2), (64, 128, 2, 3)])
+def test_neutra_hmc_mfma_native_stream_matches_oracle(dev, d, nh, cl, nl):
+    from nfmc_amd.samplers import neutra, mcmc
+    from nfmc_amd.flows import Flow, RealNVP
+    from nfmc_amd.potentials import Funnel, SumOfSquares
+    from oracle import flow as oflow, potentials as opot, samplers as osamp
+    n, T, L, h = 150, 3, 4, 0.03
+    ck = {'n_hidden': nh, 'n_layers': cl}
+    torch.manual_seed(d + nh)
+    of = oflow.perturb_(oflow.Flow(oflow.RealNVP((d,), n_layers=nl, conditioner_kwargs=ck)), 9, 0.1)
+    f = Flow(RealNVP((d,), n_layers=nl, conditioner_kwargs=ck))
+    f.load_state_dict(of.state_dict())
+    z0 = 0.5 * torch.randn(n, d)
+    imd = torch.linspace(0.8, 1.3, d)
+    s = neutra.NeuTraHMC((d,), SumOfSquares((d,)), mcmc.HMCKernel(event_size=d, n_leapfrog_steps=L, step_size=h,
+                                                                    inv_mass_diag=imd.clone()),
+                         mcmc.HMCParameters(), neutra.NeuTraKernel((d,), flow=f), neutra.NeuTraParameters(n_iterations=T))
+    s.seed = 78
+    out = s.sample(z0, show_progress=False)
+    tr = osamp.neutra_hmc_sample(z0, opot.sum_squares, of, T, h, imd, L, noise=osamp.PhiloxNoise(78))
+    got, want = out.samples.reshape(T, n, d), tr.stacked()
+    same = (got - want).abs().amax(dim=(0, 2)) < 5e-4
+    assert same.float().mean() > 0.96
+    np.testing.assert_allclose(got[:, same].numpy(), want[:, same].numpy(), atol=5e-4, rtol=0)
+    assert abs(out.statistics.n_accepted_trajectories - tr.n_accepted) <= 5
+    np.testing.assert_allclose(out.mean.numpy(), tr.moments.first.numpy(), atol=2e-3)
+    np.testing.assert_allclose(out.second_moment.numpy(), tr.moments.second.numpy(), atol=3e-3)
