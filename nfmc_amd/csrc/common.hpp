@@ -112,6 +112,17 @@ __device__ __forceinline__ double cross_chain_reduce(double v) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Register layout of a chain ("interleaved 4-blocks"): lane g of the chain's LPC lanes holds, in register i,
+// coordinate 4 * ((i / 4) * LPC + g) + (i % 4): 4-coordinate blocks dealt round-robin over the lanes.
+// One register quad = one Philox block = one 16-byte global access; consecutive lanes touch consecutive
+// 16-byte pieces of the row (coalesced); with d = CPL * LPC, quad q of every lane lies in the q-th 1/(CPL/4)
+// of the coordinates, which flow_b.hpp uses to give coupling layers compile-time source/target roles.
+template <int CPL, int LPC>
+__device__ __forceinline__ int coord_of(int g, int i) {
+    return 4 * ((i >> 2) * LPC + g) + (i & 3);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Potentials.  `term` is the coordinate's share of U (U = group sum of terms), `grad` dU/dx_c.
 // Coordinates beyond d carry a = 0 / x = 0 so they contribute exactly zero.
 template <int CPL, int LPC, bool FAST>
@@ -127,7 +138,7 @@ struct QuadraticPot {
         if constexpr (!FAST) {
 #pragma unroll
             for (int i = 0; i < CPL; ++i) {
-                const int c = g * CPL + i;
+                const int c = coord_of<CPL, LPC>(g, i);
                 const bool ok = c < d;
                 a[i] = ok ? (p.a ? p.a[c] : p.a_scalar) : 0.f;
                 b[i] = ok ? (p.b ? p.b[c] : p.b_scalar) : 0.f;
@@ -159,7 +170,7 @@ struct FunnelPot {
         half_dm1 = 0.5f * (float)(d - 1);
         lead = (g == 0);
 #pragma unroll
-        for (int i = 0; i < CPL; ++i) valid[i] = (g * CPL + i) < d ? 1.f : 0.f;
+        for (int i = 0; i < CPL; ++i) valid[i] = coord_of<CPL, LPC>(g, i) < d ? 1.f : 0.f;
     }
     __device__ __forceinline__ Ctx prepare(const float (&x)[CPL], int, int) const {
         Ctx c;
@@ -182,42 +193,43 @@ struct FunnelPot {
 };
 
 // ------------------------------------------------------------------------------------------------
-// Row IO for the blocked layout: lane g of a chain group holds coordinates g*CPL .. g*CPL+CPL-1.
-template <int CPL, bool VEC>
+// Row IO: register quad q of lane g <-> the 16 bytes at coordinate 4 * (q * LPC + g) of the row.
+template <int CPL, int LPC, bool VEC>
 __device__ __forceinline__ void load_row(const float* __restrict__ base, int64_t row, int d, int g, bool active,
                                          float (&x)[CPL]) {
     if constexpr (VEC) {
-        const float4* p = reinterpret_cast<const float4*>(base + row * d + g * CPL);
+        const float4* p = reinterpret_cast<const float4*>(base + row * d) + g;
 #pragma unroll
-        for (int i = 0; i < CPL / 4; ++i) {
-            float4 v = active ? p[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-            x[4 * i] = v.x;
-            x[4 * i + 1] = v.y;
-            x[4 * i + 2] = v.z;
-            x[4 * i + 3] = v.w;
+        for (int q = 0; q < CPL / 4; ++q) {
+            float4 v = active ? p[q * LPC] : make_float4(0.f, 0.f, 0.f, 0.f);
+            x[4 * q] = v.x;
+            x[4 * q + 1] = v.y;
+            x[4 * q + 2] = v.z;
+            x[4 * q + 3] = v.w;
         }
     } else {
 #pragma unroll
         for (int i = 0; i < CPL; ++i) {
-            const int c = g * CPL + i;
+            const int c = coord_of<CPL, LPC>(g, i);
             x[i] = (active && c < d) ? base[row * d + c] : 0.f;
         }
     }
 }
 
-template <int CPL, bool VEC>
+template <int CPL, int LPC, bool VEC>
 __device__ __forceinline__ void store_row(float* __restrict__ base, int64_t row, int d, int g, bool active,
                                           const float (&x)[CPL]) {
     if constexpr (VEC) {
         if (active) {
-            float4* p = reinterpret_cast<float4*>(base + row * d + g * CPL);
+            float4* p = reinterpret_cast<float4*>(base + row * d) + g;
 #pragma unroll
-            for (int i = 0; i < CPL / 4; ++i) p[i] = make_float4(x[4 * i], x[4 * i + 1], x[4 * i + 2], x[4 * i + 3]);
+            for (int q = 0; q < CPL / 4; ++q)
+                p[q * LPC] = make_float4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
         }
     } else {
 #pragma unroll
         for (int i = 0; i < CPL; ++i) {
-            const int c = g * CPL + i;
+            const int c = coord_of<CPL, LPC>(g, i);
             if (active && c < d) base[row * d + c] = x[i];
         }
     }
@@ -240,8 +252,8 @@ __device__ __forceinline__ void block_stats_flush(const float (&sx)[CPL], const 
         const double a = cross_chain_reduce<LPC>((double)sx[i]);
         const double b = cross_chain_reduce<LPC>((double)sxx[i]);
         if (lane < LPC) {
-            red[wave][g * CPL + i] = a;
-            red[wave][DP + g * CPL + i] = b;
+            red[wave][coord_of<CPL, LPC>(g, i)] = a;
+            red[wave][DP + coord_of<CPL, LPC>(g, i)] = b;
         }
     }
     if (lane == 0) {

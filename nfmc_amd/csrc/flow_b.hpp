@@ -1,0 +1,201 @@
+// RealNVP in the samplers' register layout (narrow conditioners, HP <= 8): the chain's coordinates stay in
+// the VGPRs of its LPC lanes, so a flow pass can run inside the same kernel, on the same registers, as the
+// MALA / HMC transitions (no HBM or LDS round trip of the state, and LPC x more lanes than the
+// one-chain-per-lane kernels of flow_kernels.hip when the number of chains is small).
+//
+// Layout ("interleaved 4-blocks"): lane g of a chain group holds, in register i, coordinate
+//     c = 4 * ((i / 4) * LPC + g) + (i % 4)
+// i.e. 4-coordinate blocks dealt round-robin over the lanes: 16-byte coalesced IO, one Philox block per
+// register quad, and -- when d == CPL * LPC and CPL == 8 -- register quad 0 of EVERY lane is the first
+// half of the coordinates and quad 1 the second half, so the source/target roles of a coupling layer are
+// compile-time per quad (no lane idles in either phase).
+//
+// Conditioner: each lane accumulates the first-layer pre-activations over its own source coordinates
+// (weights from an LDS image, one ds_read_b128 per coordinate for HP = 4), a DPP butterfly sums them over
+// the group, every lane evaluates the tiny hidden stack redundantly, then computes the affine parameters of
+// its own target coordinates.  Coordinates that are not source (target) in a layer index an all-zero row,
+// and carry an is-target flag of 0, which yields exactly alpha = 1, beta = 0, log alpha = 0 for them:
+// no index arithmetic and no branches, also for ragged d.
+#pragma once
+
+#include "common.hpp"
+#include "flow_device.hpp"
+
+namespace nfmc {
+
+// LDS image of one coupling layer, in floats, indexed by REGISTER SLOT s = i * LPC + g (the slot of the
+// coordinate held by register i of lane g), so a lane's rows are `g` rows past a compile-time base and
+// consecutive lanes read consecutive rows (bank-conflict free ds_read_b128):
+//   W1 (DP x HP): row s = W1T[logical j] if the slot's coordinate is a SOURCE of this layer, else 0
+//   b1 HP | [WhT HP x HP | bh HP] x (n_hl - 1)
+//   W3 (DP x RS): row s = [alpha weights HP | beta weights HP | b3_alpha | b3_beta | is_target | 0] (zeros if not target)
+// followed, after all layers, by the ElementwiseAffine parameters per slot:
+//   ea0_ls | ea0_sh | ea1_ls | ea1_sh   (DP each; ea1 already mapped through the final reversal)
+template <int CPL, int LPC, int HP>
+struct FlowImage {
+    static constexpr int RS = 2 * HP + 4;
+    static constexpr int DP = CPL * LPC;
+    __host__ __device__ static int layer_floats(int n_hl) { return DP * HP + HP + (n_hl - 1) * (HP * HP + HP) + DP * RS; }
+    __host__ __device__ static int total_floats(int n_hl, int n_coupling) { return n_coupling * layer_floats(n_hl) + 4 * DP; }
+
+    // all `nthreads` threads of the workgroup; blob layout: flow_device.hpp (W1T | b1 | [WhT | bh] | W3 | b3)
+    __device__ static void stage(float* __restrict__ img, const NfmcRealNVP& f, int nthreads) {
+        const int d = f.d, d_a = d / 2, d_b = d - d_a, n_hl = f.n_hidden_layers;
+        const int lf = layer_floats(n_hl);
+        const int nmid = HP + (n_hl - 1) * (HP * HP + HP);
+        for (int l = 0; l < f.n_coupling; ++l) {
+            const bool rev = (l & 1) == 0;
+            const float* W = f.weights + l * f.layer_stride;
+            const float* W3 = W + d_a * HP + nmid;
+            const float* b3 = W3 + 2 * d_b * HP;
+            float* o = img + l * lf;
+            for (int t = threadIdx.x; t < DP * HP; t += nthreads) {
+                const int s = t / HP, k = t - s * HP;
+                const int c = coord_of<CPL, LPC>(s % LPC, s / LPC);
+                const int j = rev ? d - 1 - c : c;
+                o[t] = (c < d && j < d_a) ? W[j * HP + k] : 0.f;
+            }
+            for (int t = threadIdx.x; t < nmid; t += nthreads) o[DP * HP + t] = W[d_a * HP + t];
+            float* o3 = o + DP * HP + nmid;
+            for (int t = threadIdx.x; t < DP * RS; t += nthreads) {
+                const int s = t / RS, k = t - s * RS;
+                const int c = coord_of<CPL, LPC>(s % LPC, s / LPC);
+                const int j = rev ? d - 1 - c : c;
+                float v = 0.f;
+                if (c < d && j >= d_a) {
+                    const int tt = j - d_a;
+                    if (k < HP) v = W3[tt * HP + k];
+                    else if (k < 2 * HP) v = W3[(d_b + tt) * HP + (k - HP)];
+                    else if (k == 2 * HP) v = b3[tt];
+                    else if (k == 2 * HP + 1) v = b3[d_b + tt];
+                    else if (k == 2 * HP + 2) v = 1.f;
+                }
+                o3[t] = v;
+            }
+        }
+        float* ea = img + f.n_coupling * lf;
+        const bool revl = (f.n_coupling & 1) != 0;
+        for (int s = threadIdx.x; s < DP; s += nthreads) {
+            const int p = coord_of<CPL, LPC>(s % LPC, s / LPC);
+            const bool ok = p < d;
+            const int c = revl ? d - 1 - p : p;  // logical latent coordinate held at position p
+            ea[s] = ok ? f.ea0_log_scale[p] : 0.f;
+            ea[DP + s] = ok ? f.ea0_shift[p] : 0.f;
+            ea[2 * DP + s] = ok ? f.ea1_log_scale[c] : 0.f;
+            ea[3 * DP + s] = ok ? f.ea1_shift[c] : 0.f;
+        }
+    }
+};
+
+// Per-lane flow evaluator.  x[] always holds PHYSICAL positions (position p = coordinate p of x-space;
+// on the latent side position p holds logical coordinate (odd #reversals ? d-1-p : p), as in flow_device.hpp).
+template <int CPL, int LPC, int HP>
+struct FlowB {
+    using Img = FlowImage<CPL, LPC, HP>;
+    static constexpr int DP = CPL * LPC;
+    const float* img;  // LDS
+    int n_hl, n_coupling, lf, g;
+    float m, log1m;
+
+    __device__ __forceinline__ void init(const float* lds_img, const NfmcRealNVP& f, int g_) {
+        img = lds_img;
+        n_hl = f.n_hidden_layers;
+        n_coupling = f.n_coupling;
+        lf = Img::layer_floats(n_hl);
+        m = f.min_scale;
+        log1m = __logf(1.f - f.min_scale);
+        g = g_;
+    }
+
+    // one coupling layer in place; INVERSE: x_b = (z_b - beta)/alpha.  Returns this lane's share of the logdet.
+    template <bool INVERSE>
+    __device__ __forceinline__ float coupling(float (&x)[CPL], int l) const {
+        const float* W1 = img + l * lf + g * HP;
+        const float* b1 = img + l * lf + DP * HP;
+        float h[HP];
+#pragma unroll
+        for (int k = 0; k < HP; ++k) h[k] = 0.f;
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {  // zero rows for coordinates that are not sources of this layer
+            const float* w = W1 + i * LPC * HP;
+#pragma unroll
+            for (int k = 0; k < HP; ++k) h[k] = fmaf(w[k], x[i], h[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < HP; ++k) h[k] = fast_tanh(group_allreduce<LPC>(h[k]) + b1[k]);
+        const float* Wh = b1 + HP;
+        for (int hl = 1; hl < n_hl; ++hl) {
+            float t[HP];
+            const float* bh = Wh + HP * HP;
+#pragma unroll
+            for (int k = 0; k < HP; ++k) t[k] = bh[k];
+#pragma unroll
+            for (int i = 0; i < HP; ++i)
+#pragma unroll
+                for (int k = 0; k < HP; ++k) t[k] = fmaf(Wh[i * HP + k], h[i], t[k]);
+#pragma unroll
+            for (int k = 0; k < HP; ++k) h[k] = fast_tanh(t[k]);
+            Wh = bh + HP;
+        }
+        const float* W3 = Wh + g * Img::RS;
+        float ld = 0.f;
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            const float* w = W3 + i * LPC * Img::RS;
+            float ua = w[2 * HP], ub = w[2 * HP + 1];
+#pragma unroll
+            for (int k = 0; k < HP; ++k) {
+                ua = fmaf(w[k], h[k], ua);
+                ub = fmaf(w[HP + k], h[k], ub);
+            }
+            // pass-through and padding coordinates (flag 0) stay bitwise unchanged
+            const float alpha = w[2 * HP + 2] != 0.f ? fast_exp(fmaf(0.5f, ua, log1m)) + m : 1.f;
+            const float beta = 0.5f * ub;
+            ld += fast_ln(alpha);
+            x[i] = INVERSE ? (x[i] - beta) * __builtin_amdgcn_rcpf(alpha) : fmaf(alpha, x[i], beta);
+        }
+        return INVERSE ? -ld : ld;
+    }
+
+    // x -> z (z left in physical positions); returns this lane's share of logdet_forward
+    __device__ __forceinline__ float forward(float (&x)[CPL]) const {
+        const float* ea = img + n_coupling * lf + g;
+        float ld = 0.f;
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            const float ls = ea[i * LPC];
+            x[i] = fmaf(fast_exp(ls), x[i], ea[DP + i * LPC]);
+            ld += ls;
+        }
+        for (int l = 0; l < n_coupling; ++l) ld += coupling<false>(x, l);
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            const float ls = ea[2 * DP + i * LPC];
+            x[i] = fmaf(fast_exp(ls), x[i], ea[3 * DP + i * LPC]);
+            ld += ls;
+        }
+        return ld;
+    }
+
+    // z (physical positions) -> x; returns this lane's share of logdet_inverse
+    __device__ __forceinline__ float inverse(float (&x)[CPL]) const {
+        const float* ea = img + n_coupling * lf + g;
+        float ld = 0.f;
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            const float ls = ea[2 * DP + i * LPC];
+            x[i] = (x[i] - ea[3 * DP + i * LPC]) * fast_exp(-ls);
+            ld -= ls;
+        }
+        for (int l = n_coupling - 1; l >= 0; --l) ld += coupling<true>(x, l);
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            const float ls = ea[i * LPC];
+            x[i] = (x[i] - ea[DP + i * LPC]) * fast_exp(-ls);
+            ld -= ls;
+        }
+        return ld;
+    }
+};
+
+}  // namespace nfmc

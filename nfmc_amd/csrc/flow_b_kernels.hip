@@ -1,0 +1,221 @@
+// Flow-proposal Metropolis transitions (jump of JumpNFMC.sample, jump.py:205-243; loop body of
+// FixedIMH.sample, imh.py:220-249) for narrow conditioners (HP <= 8) in the samplers' register layout:
+// LPC lanes per chain, state and proposal in VGPRs, flow weights in one LDS image per workgroup
+// (flow_b.hpp).  Same skeleton and statistics path as mala_kernel.
+#include "flow_b.hpp"
+
+namespace nfmc {
+
+// latent z ~ N(0, I) for this lane's positions: position p holds logical latent coordinate (revl ? d-1-p : p)
+template <int CPL, int LPC>
+__device__ __forceinline__ void draw_latent(float (&z)[CPL], const NfmcRng& rng, uint32_t gchain, int64_t row, int64_t n,
+                                            int d, int g, int s, bool revl) {
+    if (rng.replay_normals) {
+        const float* src = rng.replay_normals + ((int64_t)s * n + row) * d;
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            const int p = coord_of<CPL, LPC>(g, i);
+            z[i] = (row < n && p < d) ? src[revl ? d - 1 - p : p] : 0.f;
+        }
+        return;
+    }
+    const uint32_t k0 = (uint32_t)rng.seed, k1 = (uint32_t)(rng.seed >> 32);
+    const uint32_t step = rng.step0 + (uint32_t)s;
+    if (!revl) {
+#pragma unroll
+        for (int q = 0; q < CPL / 4; ++q) {
+            float w[4];
+            philox_normal4(gchain, step, (uint32_t)(q * LPC + g), kTagLatent, k0, k1, w);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) z[4 * q + r] = (coord_of<CPL, LPC>(g, 4 * q + r) < d) ? w[r] : 0.f;
+        }
+    } else {
+        // logical coordinates d-1-p of a register quad straddle at most two Philox blocks
+#pragma unroll
+        for (int q = 0; q < CPL / 4; ++q) {
+            const int p0 = coord_of<CPL, LPC>(g, 4 * q);
+            const int chi = d - 1 - p0, clo = d - 4 - p0;  // logical coords of registers 0 and 3 (may be < 0: padding)
+            float wa[4] = {0.f, 0.f, 0.f, 0.f}, wb[4] = {0.f, 0.f, 0.f, 0.f};
+            const int bhi = chi >> 2, blo = clo >> 2;
+            if (chi >= 0) philox_normal4(gchain, step, (uint32_t)bhi, kTagLatent, k0, k1, wa);
+            if (clo >= 0 && blo != bhi) philox_normal4(gchain, step, (uint32_t)blo, kTagLatent, k0, k1, wb);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = chi - r;
+                float v = 0.f;
+                if (c >= 0) {
+                    const int e = c & 3;
+                    const bool hi = (c >> 2) == bhi;
+                    const float a0 = hi ? wa[0] : wb[0], a1 = hi ? wa[1] : wb[1], a2 = hi ? wa[2] : wb[2],
+                                a3 = hi ? wa[3] : wb[3];
+                    v = e == 0 ? a0 : (e == 1 ? a1 : (e == 2 ? a2 : a3));
+                }
+                z[4 * q + r] = v;
+            }
+        }
+    }
+}
+
+template <int CPL, int LPC, int HP, template <int, int, bool> class Pot, bool FAST>
+__global__ void __launch_bounds__(kBlock) flow_mh_b_kernel(NfmcFlowMhArgs a, int64_t tiles) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int CPW = kWave / LPC;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane % LPC, cw = lane / LPC;
+    const int d = a.flow.d;
+    const int64_t n = a.n;
+    FlowImage<CPL, LPC, HP>::stage(lds, a.flow, kBlock);
+    __syncthreads();
+    FlowB<CPL, LPC, HP> fl;
+    fl.init(lds, a.flow, g);
+    Pot<CPL, LPC, FAST> pot;
+    pot.init(a.pot, g, d);
+    const bool revl = (a.flow.n_coupling & 1) != 0;
+    const float base_c = -0.5f * (float)d * kLog2Pi;
+
+    float sx[CPL], sxx[CPL];
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) sx[i] = sxx[i] = 0.f;
+    uint32_t n_acc = 0, n_bad = 0;
+    const unsigned long long leaders = LPC == 64 ? 1ull : (LPC == 32 ? 0x0000000100000001ull
+                                       : LPC == 16 ? 0x0001000100010001ull
+                                       : LPC == 8 ? 0x0101010101010101ull
+                                       : LPC == 4 ? 0x1111111111111111ull
+                                       : LPC == 2 ? 0x5555555555555555ull : ~0ull);
+
+    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int64_t row = (tile * kWavesPerBlock + wave) * CPW + cw;
+        const bool active = row < n;
+        const uint32_t gchain = (uint32_t)(a.rng.chain_offset + (uint64_t)row);
+        float x[CPL];
+        load_row<CPL, LPC, FAST>(a.x, row, d, g, active, x);
+        float u_x;
+        {
+            const auto ctx = pot.prepare(x, g, d);
+            float up = 0.f;
+#pragma unroll
+            for (int i = 0; i < CPL; ++i) up += pot.term(ctx, i, x[i]);
+            u_x = group_allreduce<LPC>(up);                                  // jump.py:212 / imh.py:224
+        }
+        float f_x;
+        if (a.logq_cached) {
+            f_x = active ? a.logq[row] : 0.f;
+        } else {                                                             // flow.log_prob(x): jump.py:218 / imh.py:214
+            float w[CPL];
+#pragma unroll
+            for (int i = 0; i < CPL; ++i) w[i] = x[i];
+            float part = fl.forward(w);
+#pragma unroll
+            for (int i = 0; i < CPL; ++i) part = fmaf(-0.5f * w[i], w[i], part);
+            f_x = group_allreduce<LPC>(part) + base_c;
+        }
+        for (int s = 0; s < a.n_steps; ++s) {
+            float xp[CPL];
+            draw_latent<CPL, LPC>(xp, a.rng, gchain, row, n, d, g, s, revl);  // flow.sample: jump.py:205 / imh.py:221
+            float part = 0.f;
+#pragma unroll
+            for (int i = 0; i < CPL; ++i) part = fmaf(-0.5f * xp[i], xp[i], part);
+            part -= fl.inverse(xp);
+            const float f_xp = group_allreduce<LPC>(part) + base_c;
+            float up = 0.f;
+            {
+                const auto ctx = pot.prepare(xp, g, d);
+#pragma unroll
+                for (int i = 0; i < CPL; ++i) up += pot.term(ctx, i, xp[i]);
+            }
+            const float u_xp = group_allreduce<LPC>(up);                     // jump.py:213 / imh.py:225
+            const float lr = (-u_xp) - (-u_x) + f_x - f_xp;                  // util.py:392
+            bool accept = true;
+            if (a.adjusted) {
+                float u;
+                if (a.rng.replay_uniforms) {
+                    u = active ? a.rng.replay_uniforms[(int64_t)s * n + row] : 0.5f;
+                } else {
+                    const uint4 r = philox4x32_10(gchain, a.rng.step0 + (uint32_t)s, 0u, kTagJump, (uint32_t)a.rng.seed,
+                                                  (uint32_t)(a.rng.seed >> 32));
+                    u = u32_to_uniform(r.x);
+                }
+                accept = fast_ln(u) < lr;                                     // jump.py:225 / imh.py:229-230
+                n_bad += (uint32_t)__popcll(__ballot(active && !(fabsf(lr) <= 3.0e38f)) & leaders);
+            }
+            accept = accept && active;
+            n_acc += (uint32_t)__popcll(__ballot(accept) & leaders);
+            if (accept) {
+                f_x = f_xp;
+                u_x = u_xp;
+            }
+#pragma unroll
+            for (int i = 0; i < CPL; ++i) {
+                x[i] = accept ? xp[i] : x[i];                                 // jump.py:231 / imh.py:232-233
+                sx[i] += x[i];
+                sxx[i] = fmaf(x[i], x[i], sxx[i]);
+            }
+            if (a.samples) store_row<CPL, LPC, FAST>(a.samples + (int64_t)s * n * d, row, d, g, active, x);
+            if (g == 0 && active) {
+                if (a.masks_out) a.masks_out[(int64_t)s * n + row] = accept ? 1 : 0;
+                if (a.log_ratio_out) a.log_ratio_out[(int64_t)s * n + row] = lr;
+            }
+        }
+        store_row<CPL, LPC, FAST>(a.x, row, d, g, active, x);
+        if (g == 0 && active) a.logq[row] = f_x;
+    }
+    if (a.stats.sum_x) block_stats_flush<CPL, LPC>(sx, sxx, n_acc, n_bad, a.stats.scratch);
+}
+
+struct BCfg {
+    int cpl, lpc;
+};
+static const BCfg kBCfgs[] = {{4, 1}, {4, 2}, {4, 4}, {4, 8}, {8, 8}, {8, 16}, {8, 32}, {8, 64}};
+
+#define NFMC_FOR_BCFG(M) M(4, 1) M(4, 2) M(4, 4) M(4, 8) M(8, 8) M(8, 16) M(8, 32) M(8, 64)
+
+template <int CPL, int LPC, int HP>
+static int launch_b(const NfmcFlowMhArgs& a, bool fast, int64_t tiles, int grid, hipStream_t st) {
+    const size_t lds = (size_t)FlowImage<CPL, LPC, HP>::total_floats(a.flow.n_hidden_layers, a.flow.n_coupling) * sizeof(float);
+    if (lds > 120 * 1024) return NFMC_EUNSUPPORTED;
+#define NFMC_LB(POT, F)                                                                                         \
+    {                                                                                                           \
+        auto kern = flow_mh_b_kernel<CPL, LPC, HP, POT, F>;                                                     \
+        if (lds > 48 * 1024) {                                                                                  \
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                               (int)lds);                                                       \
+            if (e != hipSuccess) return (int)e;                                                                 \
+        }                                                                                                       \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, st, a, tiles);                                  \
+    }
+    if (a.pot.kind == NFMC_POT_FUNNEL) NFMC_LB(FunnelPot, false)
+    else if (fast) NFMC_LB(QuadraticPot, true)
+    else NFMC_LB(QuadraticPot, false)
+#undef NFMC_LB
+    return 0;
+}
+
+// Returns NFMC_EUNSUPPORTED when this path does not cover the request (caller falls back to flow_mh_kernel).
+int flow_mh_b_launch(const NfmcFlowMhArgs& a, hipStream_t st, int* grid_out, int* dp_out) {
+    const int d = a.flow.d;
+    const int hp = a.flow.n_hidden <= 4 ? 4 : 8;
+    if (a.flow.n_hidden > 8 || d > 512) return NFMC_EUNSUPPORTED;
+    BCfg c = {0, 0};
+    for (const BCfg& k : kBCfgs)
+        if (k.cpl * k.lpc >= d && (c.cpl == 0 || k.cpl * k.lpc < c.cpl * c.lpc)) c = k;
+    if (!c.cpl) return NFMC_EUNSUPPORTED;
+    const int dp = c.cpl * c.lpc;
+    const bool fast = d == dp && (d % 4) == 0 && a.pot.a == nullptr && a.pot.b == nullptr &&
+                      (((uintptr_t)a.x) & 15u) == 0 && (!a.samples || (((uintptr_t)a.samples) & 15u) == 0);
+    const int cpw = kWave / c.lpc;
+    const int64_t tiles = (a.n + (int64_t)kWavesPerBlock * cpw - 1) / ((int64_t)kWavesPerBlock * cpw);
+    const int grid = (int)(tiles < kMaxGrid ? tiles : kMaxGrid);
+    if (a.stats.sum_x && a.stats.scratch_bytes < (int64_t)grid * (2 * dp + kStatTail) * (int64_t)sizeof(double))
+        return NFMC_ESCRATCH;
+    int rc = NFMC_EUNSUPPORTED;
+#define M(CPL, LPC)                                                                      \
+    if (c.cpl == CPL && c.lpc == LPC)                                                    \
+        rc = hp == 4 ? launch_b<CPL, LPC, 4>(a, fast, tiles, grid, st) : launch_b<CPL, LPC, 8>(a, fast, tiles, grid, st);
+    NFMC_FOR_BCFG(M)
+#undef M
+    *grid_out = grid;
+    *dp_out = dp;
+    return rc;
+}
+
+}  // namespace nfmc

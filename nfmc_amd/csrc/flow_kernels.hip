@@ -13,6 +13,9 @@
 namespace nfmc {
 
 constexpr int kFlowBlock = 64;
+
+// flow_b_kernels.hip: register-layout path for narrow conditioners
+int flow_mh_b_launch(const NfmcFlowMhArgs& a, hipStream_t st, int* grid_out, int* dp_out);
 constexpr int kMaxSlots = 8;  // d <= 512 -> at most 8 coordinates per lane in the column-sum pass
 
 template <int HP>
@@ -325,17 +328,24 @@ extern "C" int nfmc_flow_mh_steps_f32(const NfmcFlowMhArgs* args, nfmc_stream_t 
     if (a.stats.sum_x && (!a.stats.sum_x2 || !a.stats.counters || !a.stats.scratch)) return NFMC_EINVAL;
     if (a.adjusted && (a.rng.replay_normals != nullptr) != (a.rng.replay_uniforms != nullptr)) return NFMC_EINVAL;
     const int d = a.flow.d;
-    const int dp = padded_d(d);
-    const int64_t tiles = (a.n + 63) / 64;
-    const int grid = (int)(tiles < kMaxGrid ? tiles : kMaxGrid);
-    if (a.stats.sum_x && a.stats.scratch_bytes < (int64_t)grid * (2 * dp + kStatTail) * (int64_t)sizeof(double))
-        return NFMC_ESCRATCH;
-    const size_t lds = (size_t)2 * 64 * tile_stride(d) * sizeof(float);
+    int dp = padded_d(d);
     hipStream_t st = (hipStream_t)stream;
-    NFMC_HP_DISPATCH(hp_bucket(a.flow.n_hidden), {
-        if ((rc = set_lds(flow_mh_kernel<HP>, lds))) return rc;
-        hipLaunchKernelGGL((flow_mh_kernel<HP>), dim3(grid), dim3(kFlowBlock), lds, st, a, tiles, dp);
-    })
+    int grid = 0;
+    rc = getenv("NFMC_FLOW_TILE_PATH") ? NFMC_EUNSUPPORTED : flow_mh_b_launch(a, st, &grid, &dp);
+    if (rc == NFMC_EUNSUPPORTED) {  // wider conditioners: one chain per lane, wave tiles in LDS
+        dp = padded_d(d);
+        const int64_t tiles = (a.n + 63) / 64;
+        grid = (int)(tiles < kMaxGrid ? tiles : kMaxGrid);
+        if (a.stats.sum_x && a.stats.scratch_bytes < (int64_t)grid * (2 * dp + kStatTail) * (int64_t)sizeof(double))
+            return NFMC_ESCRATCH;
+        const size_t lds = (size_t)2 * 64 * tile_stride(d) * sizeof(float);
+        NFMC_HP_DISPATCH(hp_bucket(a.flow.n_hidden), {
+            if ((rc = set_lds(flow_mh_kernel<HP>, lds))) return rc;
+            hipLaunchKernelGGL((flow_mh_kernel<HP>), dim3(grid), dim3(kFlowBlock), lds, st, a, tiles, dp);
+        })
+    } else if (rc) {
+        return rc;
+    }
     NFMC_HIP_CHECK_LAUNCH();
     if (a.stats.sum_x) {
         hipLaunchKernelGGL(stats_finish_kernel, dim3(stats_finish_grid(dp)), dim3(kFinishBlock), 0, st, a.stats.scratch, grid, dp, d, a.stats,

@@ -84,15 +84,15 @@ __global__ void __launch_bounds__(kBlock) select_kernel(NfmcSelectArgs a, int64_
             if (g == 0 && !(fabsf(lr) <= 3.0e38f)) n_bad++;
         }
         float x[CPL], xp[CPL];
-        load_row<CPL, false>(a.x, row, d, g, active, x);
-        load_row<CPL, false>(a.x_prime, row, d, g, active, xp);
+        load_row<CPL, LPC, false>(a.x, row, d, g, active, x);
+        load_row<CPL, LPC, false>(a.x_prime, row, d, g, active, xp);
 #pragma unroll
         for (int i = 0; i < CPL; ++i) {
             x[i] = accept ? xp[i] : x[i];
             sx[i] += x[i];
             sxx[i] = fmaf(x[i], x[i], sxx[i]);
         }
-        if (accept) store_row<CPL, false>(a.x, row, d, g, true, x);
+        if (accept) store_row<CPL, LPC, false>(a.x, row, d, g, true, x);
         if (g == 0 && active) {
             if (accept) {
                 n_acc++;

@@ -15,7 +15,7 @@
 
 namespace nfmc {
 
-template <int CPL, bool FAST>
+template <int CPL, int LPC, bool FAST>
 struct MassCoef {
     // Langevin: c1 = -h/m^2, c2 = sqrt(2h)/m, hA = h/m^2, invA = m^2 ; HMC: rs = 1/sqrt(m), m
     float c1_s, c2_s, hA_s;
@@ -29,7 +29,7 @@ struct MassCoef {
         if constexpr (!FAST) {
 #pragma unroll
             for (int i = 0; i < CPL; ++i) {
-                const int c = g * CPL + i;
+                const int c = coord_of<CPL, LPC>(g, i);
                 const bool ok = c < d;
                 const float mm = (ok && imd) ? imd[c] : 1.f;
                 const float A = 1.f / (mm * mm);
@@ -51,14 +51,14 @@ struct MassCoef {
 };
 
 // noise for this lane's CPL coordinates of (chain, step): native Philox or replay from HBM
-template <int CPL>
+template <int CPL, int LPC>
 __device__ __forceinline__ void draw_normals(const NfmcRng& rng, uint32_t tag, uint32_t gchain, int64_t row, int64_t n,
                                              int d, int g, int s, float (&e)[CPL]) {
     if (rng.replay_normals) {
         const float* p = rng.replay_normals + ((int64_t)s * n + row) * d;
 #pragma unroll
         for (int i = 0; i < CPL; ++i) {
-            const int c = g * CPL + i;
+            const int c = coord_of<CPL, LPC>(g, i);
             e[i] = (row < n && c < d) ? p[c] : 0.f;
         }
     } else {
@@ -66,7 +66,7 @@ __device__ __forceinline__ void draw_normals(const NfmcRng& rng, uint32_t tag, u
 #pragma unroll
         for (int b = 0; b < CPL / 4; ++b) {
             float z[4];
-            philox_normal4(gchain, rng.step0 + (uint32_t)s, (uint32_t)(g * (CPL / 4) + b), tag, k0, k1, z);
+            philox_normal4(gchain, rng.step0 + (uint32_t)s, (uint32_t)(b * LPC + g), tag, k0, k1, z);
             e[4 * b] = z[0];
             e[4 * b + 1] = z[1];
             e[4 * b + 2] = z[2];
@@ -97,7 +97,7 @@ __global__ void __launch_bounds__(kBlock, NFMC_WPE) mala_kernel(NfmcMalaArgs a, 
     const float h = a.step_size;
     const float inv4h = 1.f / (4.f * h);
 
-    MassCoef<CPL, FAST> mc;
+    MassCoef<CPL, LPC, FAST> mc;
     mc.init(h, sqrt2h, a.inv_mass_diag, g, d);
     Pot<CPL, LPC, FAST> pot;
     pot.init(a.pot, g, d);
@@ -117,12 +117,12 @@ __global__ void __launch_bounds__(kBlock, NFMC_WPE) mala_kernel(NfmcMalaArgs a, 
         const bool active = row < n;
         const uint32_t gchain = (uint32_t)(a.rng.chain_offset + (uint64_t)row);
         float x[CPL];
-        load_row<CPL, FAST>(a.x, row, d, g, active, x);
+        load_row<CPL, LPC, FAST>(a.x, row, d, g, active, x);
         AcceptUniform au;
 
         for (int s = 0; s < a.n_steps; ++s) {
             float e[CPL], xp[CPL];
-            draw_normals<CPL>(a.rng, kTagNoise, gchain, row, n, d, g, s, e);
+            draw_normals<CPL, LPC>(a.rng, kTagNoise, gchain, row, n, d, g, s, e);
             const auto ctx = pot.prepare(x, g, d);
 #pragma unroll
             for (int i = 0; i < CPL; ++i)
@@ -151,13 +151,13 @@ __global__ void __launch_bounds__(kBlock, NFMC_WPE) mala_kernel(NfmcMalaArgs a, 
                 sx[i] += x[i];
                 sxx[i] = fmaf(x[i], x[i], sxx[i]);
             }
-            if (a.samples) store_row<CPL, FAST>(a.samples + (int64_t)s * n * d, row, d, g, active, x);
+            if (a.samples) store_row<CPL, LPC, FAST>(a.samples + (int64_t)s * n * d, row, d, g, active, x);
             if (g == 0 && active) {
                 if (a.masks_out) a.masks_out[(int64_t)s * n + row] = accept ? 1 : 0;
                 if (a.log_ratio_out) a.log_ratio_out[(int64_t)s * n + row] = lr;
             }
         }
-        store_row<CPL, FAST>(a.x, row, d, g, active, x);
+        store_row<CPL, LPC, FAST>(a.x, row, d, g, active, x);
     }
     if (a.stats.sum_x) block_stats_flush<CPL, LPC>(sx, sxx, n_acc, n_bad, a.stats.scratch);
 }
@@ -172,7 +172,7 @@ __global__ void __launch_bounds__(kBlock, NFMC_WPE) hmc_kernel(NfmcHmcArgs a, in
     const int64_t n = a.n;
     const float h = a.step_size, hh = a.step_size / 2;
 
-    MassCoef<CPL, FAST> mc;
+    MassCoef<CPL, LPC, FAST> mc;
     mc.init(h, 0.f, a.inv_mass_diag, g, d);
     Pot<CPL, LPC, FAST> pot;
     pot.init(a.pot, g, d);
@@ -192,12 +192,12 @@ __global__ void __launch_bounds__(kBlock, NFMC_WPE) hmc_kernel(NfmcHmcArgs a, in
         const bool active = row < n;
         const uint32_t gchain = (uint32_t)(a.rng.chain_offset + (uint64_t)row);
         float x[CPL];
-        load_row<CPL, FAST>(a.x, row, d, g, active, x);
+        load_row<CPL, LPC, FAST>(a.x, row, d, g, active, x);
         AcceptUniform au;
 
         for (int s = 0; s < a.n_steps; ++s) {
             float p[CPL], q[CPL];
-            draw_normals<CPL>(a.rng, kTagNoise, gchain, row, n, d, g, s, p);
+            draw_normals<CPL, LPC>(a.rng, kTagNoise, gchain, row, n, d, g, s, p);
             float dh = 0.f;  // this lane's share of H0 - H1
             {
                 const auto ctx = pot.prepare(x, g, d);
@@ -238,13 +238,13 @@ __global__ void __launch_bounds__(kBlock, NFMC_WPE) hmc_kernel(NfmcHmcArgs a, in
                 sx[i] += x[i];
                 sxx[i] = fmaf(x[i], x[i], sxx[i]);
             }
-            if (a.samples) store_row<CPL, FAST>(a.samples + (int64_t)s * n * d, row, d, g, active, x);
+            if (a.samples) store_row<CPL, LPC, FAST>(a.samples + (int64_t)s * n * d, row, d, g, active, x);
             if (g == 0 && active) {
                 if (a.masks_out) a.masks_out[(int64_t)s * n + row] = accept ? 1 : 0;
                 if (a.log_ratio_out) a.log_ratio_out[(int64_t)s * n + row] = lr;
             }
         }
-        store_row<CPL, FAST>(a.x, row, d, g, active, x);
+        store_row<CPL, LPC, FAST>(a.x, row, d, g, active, x);
     }
     if (a.stats.sum_x) block_stats_flush<CPL, LPC>(sx, sxx, n_acc, n_bad, a.stats.scratch);
 }

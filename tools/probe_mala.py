@@ -72,6 +72,8 @@ def time_flow_mh(n, d, K, nh=None, reps=3):
     run.dev, run.n, run.d = dev, n, d
     run.x = torch.randn(n, d, device=dev) * 0.7
     run.rng = lambda step0, k=0, adjusted=True: hip.make_rng(1, 0, step0)
+    import contextlib
+    run.timed = lambda label: contextlib.nullcontext()
     st = hip.DeviceStats(d, dev)
     logq = torch.empty(n, device=dev)
     pot = SumOfSquares((d,))

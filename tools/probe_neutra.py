@@ -1,0 +1,27 @@
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from nfmc_amd import sample
+from nfmc_amd.potentials import Funnel, SumOfSquares
+
+def run(n, d, nh, cl, L, T, pot='funnel'):
+    torch.manual_seed(0)
+    target = Funnel((d,), 3.0) if pot == 'funnel' else SumOfSquares((d,))
+    kw = dict(strategy='neutra_hmc', flow='realnvp', flow_kwargs={'conditioner_kwargs': {'n_hidden': nh, 'n_layers': cl}},
+              n_iterations=T, show_progress=False, inner_kernel_kwargs={'n_leapfrog_steps': L, 'step_size': 0.02},
+              param_kwargs={'store_samples': False}, seed=1)
+    x0 = (0.5 * torch.randn(n, d)).cuda()
+    sample(target, x0=x0[:1024], **{**kw, 'n_iterations': 1})
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    out = sample(target, x0=x0, **kw)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    flops = None
+    print(f'neutra_hmc n={n} d={d} H={nh} cl={cl} L={L} T={T}: {dt/T*1e3:.2f} ms/step  {n*T/dt/1e6:.3f} M chain-steps/s  acc={out.statistics.acceptance_rate:.2f}', flush=True)
+
+if __name__ == '__main__':
+    run(65536, 128, 128, 2, 10, 3)
+    run(65536, 128, 64, 2, 10, 3)
+    run(65536, 64, 64, 1, 10, 3)
+    run(65536, 128, 32, 2, 10, 2)
+    run(65536, 128, 8, 2, 10, 3)
+    run(65536, 64, 4, 2, 10, 5, 'sumsq')
