@@ -128,6 +128,7 @@ __device__ __forceinline__ int coord_of(int g, int i) {
 template <int CPL, int LPC, bool FAST>
 struct QuadraticPot {
     // U = sum a_c (x_c - b_c)^2
+    static constexpr bool kQuadratic = true;
     float a_s, b_s;
     float a[FAST ? 1 : CPL], b[FAST ? 1 : CPL];
     struct Ctx {};
@@ -158,6 +159,7 @@ struct QuadraticPot {
 template <int CPL, int LPC, bool FAST>
 struct FunnelPot {
     // U = x0^2/(2 s^2) + sum_{i>=1} [ x_i^2 e^{-x0} / 2 + x0 / 2 ]
+    static constexpr bool kQuadratic = false;
     float inv_s2, half_dm1;
     bool lead;          // this lane holds coordinate 0 in register 0
     float valid[CPL];   // 1 for real coordinates, 0 for padding

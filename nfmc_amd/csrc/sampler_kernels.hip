@@ -123,21 +123,38 @@ __global__ void __launch_bounds__(kBlock, NFMC_WPE) mala_kernel(NfmcMalaArgs a, 
         for (int s = 0; s < a.n_steps; ++s) {
             float e[CPL], xp[CPL];
             draw_normals<CPL, LPC>(a.rng, kTagNoise, gchain, row, n, d, g, s, e);
-            const auto ctx = pot.prepare(x, g, d);
-#pragma unroll
-            for (int i = 0; i < CPL; ++i)
-                xp[i] = fmaf(mc.C2(i), e[i], fmaf(mc.C1(i), pot.grad(ctx, i, x[i]), x[i]));  // langevin.py:74-76
             bool accept = true;
             float lr = 0.f;
-            if (a.adjust) {
-                const auto ctxp = pot.prepare(xp, g, d);
+            if constexpr (Pot<CPL, LPC, FAST>::kQuadratic) {
+                // U = sum a (x-b)^2: with t = x - b, t' = x' - b the reference's ratio (langevin.py:88-105)
+                //   (u - u') + [q(x'|x) - q(x|x')]   collapses term by term to   a^2 (h/m^2) (t^2 - t'^2)
+                // (expand tf = d + 2 a hA t, tb = -d + 2 a hA t', d = t' - t; invA hA = h): same value, 7
+                // instead of 17 VALU instructions per coordinate; checked against the golden vectors.
 #pragma unroll
                 for (int i = 0; i < CPL; ++i) {
-                    const float gj = pot.grad(ctx, i, x[i]), gp = pot.grad(ctxp, i, xp[i]);
-                    const float tf = (xp[i] - x[i]) + mc.HA(i) * gj;  // q(x'|x)  langevin.py:31-42
-                    const float tb = (x[i] - xp[i]) + mc.HA(i) * gp;  // q(x|x')
-                    lr += (pot.term(ctx, i, x[i]) - pot.term(ctxp, i, xp[i])) + inv4h * mc.IA(i) * (tf * tf - tb * tb);
+                    const float t = x[i] - pot.bb(i);
+                    xp[i] = fmaf(mc.C2(i), e[i], fmaf(mc.C1(i) * (2.f * pot.aa(i)), t, x[i]));  // langevin.py:74-76
+                    const float tp = xp[i] - pot.bb(i);
+                    lr = fmaf(pot.aa(i) * pot.aa(i) * mc.HA(i) * (t - tp), t + tp, lr);
                 }
+            } else {
+                const auto ctx = pot.prepare(x, g, d);
+#pragma unroll
+                for (int i = 0; i < CPL; ++i)
+                    xp[i] = fmaf(mc.C2(i), e[i], fmaf(mc.C1(i), pot.grad(ctx, i, x[i]), x[i]));  // langevin.py:74-76
+                if (a.adjust) {
+                    const auto ctxp = pot.prepare(xp, g, d);
+#pragma unroll
+                    for (int i = 0; i < CPL; ++i) {
+                        const float gj = pot.grad(ctx, i, x[i]), gp = pot.grad(ctxp, i, xp[i]);
+                        const float tf = (xp[i] - x[i]) + mc.HA(i) * gj;  // q(x'|x)  langevin.py:31-42
+                        const float tb = (x[i] - xp[i]) + mc.HA(i) * gp;  // q(x|x')
+                        lr += (pot.term(ctx, i, x[i]) - pot.term(ctxp, i, xp[i])) +
+                              inv4h * mc.IA(i) * (tf * tf - tb * tb);
+                    }
+                }
+            }
+            if (a.adjust) {
                 lr = group_allreduce<LPC>(lr);
                 const float u = au.draw(a.rng, gchain, row, n, s);
                 accept = fast_ln(u) < lr;  // NaN -> reject (langevin.py:106)
