@@ -81,48 +81,6 @@ typedef struct {
 
 int64_t nfmc_stats_scratch_bytes(int32_t d);
 
-/* ---- K1 (+K6, K7): n_steps fused Langevin transitions.
- * Replaces `Langevin.propose` + the masked update + counters + moments of `MCMCSampler.sample`
- * (langevin.py:61-122; mcmc/base.py:74-90). */
-typedef struct {
-    float* x;                   /* (n, d) in/out */
-    int64_t n;
-    int32_t d;
-    int32_t n_steps;            /* 1..NFMC_MAX_STEPS_PER_CALL */
-    float step_size;
-    int32_t adjust;             /* 1 = MALA, 0 = ULA */
-    const float* inv_mass_diag; /* (d,) or NULL = ones (mcmc/base.py:113-116) */
-    NfmcPotential pot;
-    NfmcRng rng;
-    NfmcStats stats;
-    float* samples;             /* NULL or (n_steps, n, d): state after every step (MCMCSamples.add) */
-    uint8_t* masks_out;         /* NULL or (n_steps, n) accept masks (tests / split path) */
-    float* log_ratio_out;       /* NULL or (n_steps, n) */
-} NfmcMalaArgs;
-
-int nfmc_mala_steps_f32(const NfmcMalaArgs* args, nfmc_stream_t stream);
-
-/* ---- K2: n_steps fused HMC trajectories.  Replaces `HMC.propose`/`hmc_trajectory` (hmc.py:61-126). */
-typedef struct {
-    float* x;
-    int64_t n;
-    int32_t d;
-    int32_t n_steps;
-    float step_size;
-    int32_t n_leapfrog;
-    int32_t adjust;             /* 1 = HMC, 0 = UHMC */
-    int32_t reserved;
-    const float* inv_mass_diag;
-    NfmcPotential pot;
-    NfmcRng rng;
-    NfmcStats stats;
-    float* samples;
-    uint8_t* masks_out;
-    float* log_ratio_out;
-} NfmcHmcArgs;
-
-int nfmc_hmc_steps_f32(const NfmcHmcArgs* args, nfmc_stream_t stream);
-
 /* ---- RealNVP (the build's spec: DESIGN.md "RealNVP spec"; stands in for torchflows.RealNVP,
  * call sites nfmc/util.py:280-281). */
 typedef struct {
@@ -148,6 +106,66 @@ typedef struct {
  * whose blob also carries every matrix in both orientations: csrc/mfma_device.hpp); 0 = unsupported. */
 int32_t nfmc_realnvp_padded_hidden(int32_t n_hidden);
 int64_t nfmc_realnvp_layer_floats(int32_t d, int32_t n_hidden, int32_t n_hidden_layers);
+
+/* Optional tail of a sampler call: after the n_steps inner transitions, ONE flow-proposal Metropolis jump
+ * (jump.py:205-243: flow.sample, flow.log_prob, 2 target calls, log u < log alpha, masked update) on the
+ * same registers, as transition rng.step0 + n_steps.  With a tail, `samples` holds n_steps + 1 rows and the
+ * moments include the post-jump state.  Narrow conditioners only (n_hidden <= 8, d <= 512); otherwise the
+ * call returns NFMC_EUNSUPPORTED and the caller issues nfmc_flow_mh_steps_f32 separately. */
+typedef struct {
+    NfmcRealNVP flow;
+    int32_t adjusted;             /* 0: accept every proposal (adjusted_jumps=False) */
+    int32_t reserved;
+    unsigned long long* counters; /* (NFMC_CNT_WORDS,) jump counters: accepted / attempted / nonfinite */
+    const float* replay_latent;   /* NULL -> native stream 2; else (n, d) latents */
+    const float* replay_uniform;  /* NULL -> native stream 3; else (n,) */
+    uint8_t* mask_out;            /* NULL or (n,) */
+    float* log_ratio_out;         /* NULL or (n,) */
+} NfmcJumpTail;
+
+/* ---- K1 (+K6, K7): n_steps fused Langevin transitions.
+ * Replaces `Langevin.propose` + the masked update + counters + moments of `MCMCSampler.sample`
+ * (langevin.py:61-122; mcmc/base.py:74-90). */
+typedef struct {
+    float* x;                   /* (n, d) in/out */
+    int64_t n;
+    int32_t d;
+    int32_t n_steps;            /* 1..NFMC_MAX_STEPS_PER_CALL */
+    float step_size;
+    int32_t adjust;             /* 1 = MALA, 0 = ULA */
+    const float* inv_mass_diag; /* (d,) or NULL = ones (mcmc/base.py:113-116) */
+    NfmcPotential pot;
+    NfmcRng rng;
+    NfmcStats stats;
+    float* samples;             /* NULL or (n_steps, n, d): state after every step (MCMCSamples.add) */
+    uint8_t* masks_out;         /* NULL or (n_steps, n) accept masks (tests / split path) */
+    float* log_ratio_out;       /* NULL or (n_steps, n) */
+    const NfmcJumpTail* jump;   /* NULL or a jump to run after the inner transitions (host pointer) */
+} NfmcMalaArgs;
+
+int nfmc_mala_steps_f32(const NfmcMalaArgs* args, nfmc_stream_t stream);
+
+/* ---- K2: n_steps fused HMC trajectories.  Replaces `HMC.propose`/`hmc_trajectory` (hmc.py:61-126). */
+typedef struct {
+    float* x;
+    int64_t n;
+    int32_t d;
+    int32_t n_steps;
+    float step_size;
+    int32_t n_leapfrog;
+    int32_t adjust;             /* 1 = HMC, 0 = UHMC */
+    int32_t reserved;
+    const float* inv_mass_diag;
+    NfmcPotential pot;
+    NfmcRng rng;
+    NfmcStats stats;
+    float* samples;
+    uint8_t* masks_out;
+    float* log_ratio_out;
+    const NfmcJumpTail* jump;   /* as in NfmcMalaArgs */
+} NfmcHmcArgs;
+
+int nfmc_hmc_steps_f32(const NfmcHmcArgs* args, nfmc_stream_t stream);
 
 /* K4: x -> z, logdet_forward; log_prob = N(z;0,I) + logdet (either output may be NULL).
  * Replaces `bijection.forward` / `Flow.log_prob` (jump.py:218, imh.py:214). */

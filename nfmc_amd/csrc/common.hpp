@@ -17,7 +17,7 @@ constexpr int kMaxGrid = 2048;       // 256 CUs x 8 workgroups; larger problems 
 #ifndef NFMC_WPE
 #define NFMC_WPE 1
 #endif
-constexpr int kStatTail = 4;         // per-workgroup scratch tail: accepted, nonfinite, 2 spare
+constexpr int kStatTail = 4;         // per-workgroup scratch tail: accepted, nonfinite, jump accepted, jump nonfinite
 
 // RNG stream tags (oracle/philox.py)
 constexpr uint32_t kTagNoise = 0, kTagAccept = 1, kTagLatent = 2, kTagJump = 3;
@@ -244,7 +244,8 @@ __device__ __forceinline__ void store_row(float* __restrict__ base, int64_t row,
 // kernel folds the slab into the accumulators in a fixed order (no atomics: run-to-run bitwise equal).
 template <int CPL, int LPC>
 __device__ __forceinline__ void block_stats_flush(const float (&sx)[CPL], const float (&sxx)[CPL], uint32_t accepted,
-                                                  uint32_t nonfinite, double* __restrict__ scratch) {
+                                                  uint32_t nonfinite, double* __restrict__ scratch,
+                                                  uint32_t jump_accepted = 0, uint32_t jump_nonfinite = 0) {
     constexpr int DP = CPL * LPC;
     __shared__ double red[kWavesPerBlock][2 * DP + kStatTail];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -261,8 +262,8 @@ __device__ __forceinline__ void block_stats_flush(const float (&sx)[CPL], const 
     if (lane == 0) {
         red[wave][2 * DP + 0] = (double)accepted;
         red[wave][2 * DP + 1] = (double)nonfinite;
-        red[wave][2 * DP + 2] = 0.0;
-        red[wave][2 * DP + 3] = 0.0;
+        red[wave][2 * DP + 2] = (double)jump_accepted;
+        red[wave][2 * DP + 3] = (double)jump_nonfinite;
     }
     __syncthreads();
     double* out = scratch + (size_t)blockIdx.x * (2 * DP + kStatTail);
@@ -280,7 +281,9 @@ __device__ __forceinline__ void block_stats_flush(const float (&sx)[CPL], const 
 constexpr int kFinishCols = 32, kFinishSlices = 32, kFinishBlock = kFinishCols * kFinishSlices;
 static __global__ void __launch_bounds__(kFinishBlock) stats_finish_kernel(const double* __restrict__ scratch,
                                                                            int nblocks, int dp, int d, NfmcStats st,
-                                                                           unsigned long long attempted) {
+                                                                           unsigned long long attempted,
+                                                                           unsigned long long* jump_counters = nullptr,
+                                                                           unsigned long long jump_attempted = 0) {
     __shared__ double part[kFinishSlices][kFinishCols];
     const int width = 2 * dp + kStatTail;
     const int col = threadIdx.x % kFinishCols, slice = threadIdx.x / kFinishCols;
@@ -311,6 +314,11 @@ static __global__ void __launch_bounds__(kFinishBlock) stats_finish_kernel(const
             st.counters[NFMC_CNT_ATTEMPTED] += attempted;
         } else if (t == 2 * dp + 1) {
             st.counters[NFMC_CNT_NONFINITE] += (unsigned long long)(s + 0.5);
+        } else if (t == 2 * dp + 2 && jump_counters) {
+            jump_counters[NFMC_CNT_ACCEPTED] += (unsigned long long)(s + 0.5);
+            jump_counters[NFMC_CNT_ATTEMPTED] += jump_attempted;
+        } else if (t == 2 * dp + 3 && jump_counters) {
+            jump_counters[NFMC_CNT_NONFINITE] += (unsigned long long)(s + 0.5);
         }
     }
 }

@@ -37,25 +37,30 @@ class NfmcStats(C.Structure):
                 ('scratch_bytes', C.c_int64)]
 
 
+class NfmcRealNVP(C.Structure):
+    _fields_ = [('d', C.c_int32), ('n_coupling', C.c_int32), ('n_hidden', C.c_int32), ('n_hidden_layers', C.c_int32),
+                ('min_scale', C.c_float), ('reserved', C.c_int32),
+                ('ea0_log_scale', c_fp), ('ea0_shift', c_fp), ('ea1_log_scale', c_fp), ('ea1_shift', c_fp),
+                ('weights', c_fp), ('layer_stride', C.c_int64)]
+
+
+class NfmcJumpTail(C.Structure):
+    _fields_ = [('flow', NfmcRealNVP), ('adjusted', C.c_int32), ('reserved', C.c_int32), ('counters', c_fp),
+                ('replay_latent', c_fp), ('replay_uniform', c_fp), ('mask_out', c_fp), ('log_ratio_out', c_fp)]
+
+
 class NfmcMalaArgs(C.Structure):
     _fields_ = [('x', c_fp), ('n', C.c_int64), ('d', C.c_int32), ('n_steps', C.c_int32),
                 ('step_size', C.c_float), ('adjust', C.c_int32), ('inv_mass_diag', c_fp),
                 ('pot', NfmcPotential), ('rng', NfmcRng), ('stats', NfmcStats),
-                ('samples', c_fp), ('masks_out', c_fp), ('log_ratio_out', c_fp)]
+                ('samples', c_fp), ('masks_out', c_fp), ('log_ratio_out', c_fp), ('jump', C.POINTER(NfmcJumpTail))]
 
 
 class NfmcHmcArgs(C.Structure):
     _fields_ = [('x', c_fp), ('n', C.c_int64), ('d', C.c_int32), ('n_steps', C.c_int32),
                 ('step_size', C.c_float), ('n_leapfrog', C.c_int32), ('adjust', C.c_int32), ('reserved', C.c_int32),
                 ('inv_mass_diag', c_fp), ('pot', NfmcPotential), ('rng', NfmcRng), ('stats', NfmcStats),
-                ('samples', c_fp), ('masks_out', c_fp), ('log_ratio_out', c_fp)]
-
-
-class NfmcRealNVP(C.Structure):
-    _fields_ = [('d', C.c_int32), ('n_coupling', C.c_int32), ('n_hidden', C.c_int32), ('n_hidden_layers', C.c_int32),
-                ('min_scale', C.c_float), ('reserved', C.c_int32),
-                ('ea0_log_scale', c_fp), ('ea0_shift', c_fp), ('ea1_log_scale', c_fp), ('ea1_shift', c_fp),
-                ('weights', c_fp), ('layer_stride', C.c_int64)]
+                ('samples', c_fp), ('masks_out', c_fp), ('log_ratio_out', c_fp), ('jump', C.POINTER(NfmcJumpTail))]
 
 
 class NfmcFlowMhArgs(C.Structure):

@@ -83,6 +83,23 @@ def flow_is_native(flow) -> bool:
     return bij.d <= lim.max_d_flow and bij.n_hidden <= lim.max_hidden_valu and bij.n_hidden_layers <= 4
 
 
+def flow_fits_jump_tail(flow) -> bool:
+    """The jump can ride at the end of the inner sampler's launch (NfmcJumpTail): narrow conditioner, d <= 512."""
+    bij = getattr(flow, 'bijection', None)
+    return isinstance(bij, RealNVP) and bij.n_hidden <= 8 and bij.d <= 512 and bij.n_hidden_layers <= 4
+
+
+def make_jump_tail(run: Run, flow, adjusted, jump_counters):
+    """NfmcJumpTail for the transition right after an inner launch (+ keep-alive references)."""
+    st, keep = flow.bijection.packed(run.dev)
+    t = hip.NfmcJumpTail()
+    t.flow = st
+    t.adjusted = 1 if adjusted else 0
+    t.counters = hip.ptr(jump_counters, torch.int64)
+    t._keep = [keep, jump_counters]
+    return t
+
+
 def launch_flow_mh(run: Run, flow, pot, logq, k, step0, cached, adjusted, stats_struct, samples=None,
                    masks_out=None, log_ratio_out=None):
     a = hip.NfmcFlowMhArgs()
@@ -150,6 +167,12 @@ def split_flow_mh(run: Run, flow, target, event_shape, step, adjusted, stats_str
 class JumpNFMC(Sampler):
     """Requires a flow with an efficient inverse (and forward, for adjusted jumps)."""
 
+    # Run the jump as the tail of the last inner launch (NfmcJumpTail) instead of its own kernel.  Correct and
+    # tested, but off by default: the flow code raises the fused kernel's VGPR allocation from 91 to ~200
+    # (occupancy 5 -> 2 waves/SIMD), which costs the 100 inner transitions more than the separate 58 us jump
+    # launch does (measured 0.474 vs 0.45 ms per outer iteration at C3).
+    fuse_jump_tail = False
+
     def __init__(self, event_shape, target, inner_sampler: Sampler, kernel: NFMCKernel = None,
                  params: JumpNFMCParameters = None):
         if kernel is None:
@@ -195,6 +218,8 @@ class JumpNFMC(Sampler):
         T, K = int(self.params.n_iterations), int(inner.params.n_iterations)
         pot = resolve_target(self.target, event_shape, getattr(inner, 'fuse', 'auto'))
         fused = pot is not None and flow_is_native(flow)
+        tail_ok = (self.fuse_jump_tail and fused and flow_fits_jump_tail(flow) and not self.params.fit_nf
+                   and isinstance(inner, (MALA, ULA, HMC, UHMC)))
         inner._cur_run = run
 
         buf = torch.empty(T * (K + 1), n, d, dtype=torch.float32, device=run.dev) if self.params.store_samples else None
@@ -214,11 +239,30 @@ class JumpNFMC(Sampler):
                     break
             base = i * (K + 1)
             inner_view = buf[base:base + K] if buf is not None else fit_buf
-            # ---- K inner transitions (jump.py:178)
+            # ---- K inner transitions (jump.py:178); when the flow is narrow the jump rides at the end of
+            # the last inner launch, on the same registers (NfmcJumpTail)
+            tail_done = False
             if pot is not None:
                 for off, k in chunks(K):
-                    view = inner_view[off:off + k] if inner_view is not None else None
-                    inner._launch(run, pot, k, base + off, view)
+                    last = off + k == K
+                    tail = None
+                    if last and tail_ok:
+                        tail = make_jump_tail(run, flow, self.params.adjusted_jumps, jump_counters)
+                    if tail is not None:  # k inner rows + the jump row, contiguous in the store
+                        view = buf[base + off:base + off + k + 1] if buf is not None else None
+                    else:
+                        view = inner_view[off:off + k] if inner_view is not None else None
+                    if tail is not None and run.replay is not None:
+                        # replay order: K inner fields, then the jump's latent + uniform
+                        rng_inner = run.rng(base + off, k, adjusted=inner.params.adjustment)
+                        lat, un = run.replay.take(1, with_uniforms=self.params.adjusted_jumps)
+                        tail.replay_latent = hip.ptr(lat[0].contiguous())
+                        tail.replay_uniform = hip.ptr(un[0].contiguous()) if un is not None else None
+                        tail._keep += [lat, un]
+                        inner._launch_with_rng(run, pot, k, rng_inner, view, jump=tail)
+                    else:
+                        inner._launch(run, pot, k, base + off, view, jump=tail)
+                    tail_done = tail is not None
             else:
                 for off in range(K):
                     inner._split_step(run, base + off, inner_view[off:off + 1] if inner_view is not None else None)
@@ -231,7 +275,9 @@ class JumpNFMC(Sampler):
                 flow.fit(x_train=x_train, x_val=x_val, **self.params.flow_fit_kwargs)
             # ---- the jump (jump.py:205-243)
             jview = buf[base + K:base + K + 1] if buf is not None else None
-            if fused:
+            if tail_done:
+                pass
+            elif fused:
                 launch_flow_mh(run, flow, pot, logq, 1, base + K, False, self.params.adjusted_jumps, jstats, jview)
             else:
                 split_flow_mh(run, flow, self.target, event_shape, base + K, self.params.adjusted_jumps, jstats)

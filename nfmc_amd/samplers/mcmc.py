@@ -114,11 +114,20 @@ class MCMCSampler(Sampler):
         raise NotImplementedError
 
     # ---- fused launch of k transitions; implemented by Langevin / HMC
-    def _launch(self, run: Run, pot, k, step0, samples, masks_out=None, log_ratio_out=None):
+    def _launch(self, run: Run, pot, k, step0, samples, masks_out=None, log_ratio_out=None, jump=None):
         raise NotImplementedError
 
     def _counts(self, n, k):
         raise NotImplementedError
+
+    def _launch_with_rng(self, run: Run, pot, k, rng, samples, jump=None):
+        """`_launch` with an NfmcRng prepared by the caller (replay bookkeeping of fused jump tails)."""
+        orig = run.rng
+        run.rng = lambda step0, kk=0, adjusted=True: rng
+        try:
+            self._launch(run, pot, k, 0, samples, jump=jump)
+        finally:
+            run.rng = orig
 
     def warmup(self, x0, show_progress: bool = True, time_limit_seconds=None) -> MCMCOutput:
         # mcmc/base.py:39-54
@@ -248,7 +257,7 @@ class Langevin(MetropolisSampler):
         per = 2 * n if self.params.adjustment else n  # langevin.py:116-120
         return per * k, per * k
 
-    def _launch(self, run, pot, k, step0, samples, masks_out=None, log_ratio_out=None):
+    def _launch(self, run, pot, k, step0, samples, masks_out=None, log_ratio_out=None, jump=None):
         a = hip.NfmcMalaArgs()
         a.x, a.n, a.d, a.n_steps = hip.ptr(run.x), run.n, run.d, k
         a.step_size = float(self.kernel.step_size)
@@ -261,6 +270,7 @@ class Langevin(MetropolisSampler):
         a.samples = hip.ptr(samples) if samples is not None else None
         a.masks_out = hip.ptr(masks_out, torch.uint8) if masks_out is not None else None
         a.log_ratio_out = hip.ptr(log_ratio_out) if log_ratio_out is not None else None
+        a.jump = C.pointer(jump) if jump is not None else None
         with run.timed('mala_steps'):
             hip.check(hip.lib().nfmc_mala_steps_f32(C.byref(a), hip.stream()), 'nfmc_mala_steps_f32')
 
@@ -338,7 +348,7 @@ class HMC(MetropolisSampler):
         calls = grads + (2 * n if self.params.adjustment else 0)
         return calls * k, grads * k
 
-    def _launch(self, run, pot, k, step0, samples, masks_out=None, log_ratio_out=None):
+    def _launch(self, run, pot, k, step0, samples, masks_out=None, log_ratio_out=None, jump=None):
         a = hip.NfmcHmcArgs()
         a.x, a.n, a.d, a.n_steps = hip.ptr(run.x), run.n, run.d, k
         a.step_size = float(self.kernel.step_size)
@@ -352,6 +362,7 @@ class HMC(MetropolisSampler):
         a.samples = hip.ptr(samples) if samples is not None else None
         a.masks_out = hip.ptr(masks_out, torch.uint8) if masks_out is not None else None
         a.log_ratio_out = hip.ptr(log_ratio_out) if log_ratio_out is not None else None
+        a.jump = C.pointer(jump) if jump is not None else None
         with run.timed('hmc_steps'):
             hip.check(hip.lib().nfmc_hmc_steps_f32(C.byref(a), hip.stream()), 'nfmc_hmc_steps_f32')
 

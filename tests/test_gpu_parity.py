@@ -132,7 +132,8 @@ def test_hmc_golden_python_callable_split_path(dev):
 
 
 # ------------------------------------------------------------------------------------------ golden: flow samplers
-def test_jump_mala_golden(dev):
+@pytest.mark.parametrize('fuse_tail', [False, True])
+def test_jump_mala_golden(dev, fuse_tail):
     from nfmc_amd.samplers import jump, mcmc
     from nfmc_amd.containers import NFMCKernel
     from nfmc_amd.potentials import SumOfSquares
@@ -143,11 +144,13 @@ def test_jump_mala_golden(dev):
                       mcmc.LangevinKernel(event_size=d, step_size=float(fx['step_size'])),
                       mcmc.LangevinParameters(n_iterations=int(fx['n_inner'])))
     s.replay = _noise(fx)
+    s.fuse_jump_tail = fuse_tail   # jump as the tail of the inner launch (NfmcJumpTail) or as its own kernel
     out = s.sample(torch.from_numpy(fx['x0']), show_progress=False)
     _check_out(out, fx, jump=True)
 
 
-def test_jump_hmc_golden(dev):
+@pytest.mark.parametrize('fuse_tail', [False, True])
+def test_jump_hmc_golden(dev, fuse_tail):
     from nfmc_amd.samplers import jump, mcmc
     from nfmc_amd.containers import NFMCKernel
     from nfmc_amd.potentials import SumOfSquares
@@ -159,6 +162,7 @@ def test_jump_hmc_golden(dev):
                      mcmc.HMCKernel(event_size=d, step_size=float(fx['step_size']), n_leapfrog_steps=int(fx['n_leapfrog'])),
                      mcmc.HMCParameters(n_iterations=int(fx['n_inner'])))
     s.replay = _noise(fx)
+    s.fuse_jump_tail = fuse_tail
     out = s.sample(torch.from_numpy(fx['x0']), show_progress=False)
     _check_out(out, fx, jump=True)
 
@@ -326,6 +330,10 @@ def test_jump_mala_native_stream_matches_oracle(dev):
                       None, mcmc.LangevinParameters(n_iterations=K))
     s.seed = 31337
     out = s.sample(x0, show_progress=False)
+    s.fuse_jump_tail = True
+    out_fused = s.sample(x0, show_progress=False)
+    assert torch.allclose(out_fused.samples, out.samples, atol=1e-5)   # same stream, same transitions
+    assert out_fused.statistics.n_accepted_jumps == out.statistics.n_accepted_jumps
     tr = osamp.jump_sample(x0, opot.sum_squares, of, 'langevin', T, K, d ** (-1 / 3), noise=osamp.PhiloxNoise(31337))
     got, want = out.samples.reshape(T * (K + 1), n, d), tr.stacked()
     same = (got - want).abs().amax(dim=(0, 2)) < 2e-4
