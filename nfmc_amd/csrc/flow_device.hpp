@@ -87,15 +87,66 @@ __device__ __forceinline__ const float* w3_of(const float* __restrict__ W, const
     return W + (int64_t)g.d_a * HP + HP + (int64_t)(g.n_hl - 1) * (HP * HP + HP);
 }
 
+// ---- wide conditioners (HP = 64 / 128) on shapes the matrix-core kernels do not cover (any d, any depth):
+// same one-chain-per-lane scheme, but the HP accumulators are the only register array; the activations of
+// the previous layer sit in an LDS buffer hbuf[HP][64 lanes] (lane-contiguous, conflict free) and are
+// streamed one per HP fused multiply-adds.  Blob layout of the wide path (mfma_device.hpp):
+//   W1 (HP,d_a) | W1T (d_a,HP) | b1 | [Wh | WhT | bh] x (n_hl-1) | W3 (2d_b,HP) | W3T | b3
+template <int HP>
+__device__ __forceinline__ void conditioner_hidden_wide(const float* __restrict__ row, const float* __restrict__ W,
+                                                        const FlowGeom& g, bool rev, float (&h)[HP],
+                                                        float* __restrict__ hbuf, int lane) {
+    const float* W1T = W + (int64_t)HP * g.d_a;
+    const float* b1 = W1T + (int64_t)g.d_a * HP;
+#pragma unroll
+    for (int k = 0; k < HP; ++k) h[k] = b1[k];
+    for (int j = 0; j < g.d_a; ++j) {
+        const float xj = row[phys(j, g.d, rev)];
+        const float* w = W1T + (int64_t)j * HP;
+#pragma unroll
+        for (int k = 0; k < HP; ++k) h[k] = fmaf(w[k], xj, h[k]);
+    }
+    const float* p = b1 + HP;
+    for (int l = 1; l < g.n_hl; ++l) {
+        const float* WhT = p + HP * HP;
+        const float* bh = WhT + HP * HP;
+#pragma unroll
+        for (int k = 0; k < HP; ++k) hbuf[k * 64 + lane] = fast_tanh(h[k]);
+#pragma unroll
+        for (int k = 0; k < HP; ++k) h[k] = bh[k];
+        for (int i = 0; i < HP; ++i) {
+            const float hi = hbuf[i * 64 + lane];
+            const float* w = WhT + i * HP;
+#pragma unroll
+            for (int k = 0; k < HP; ++k) h[k] = fmaf(w[k], hi, h[k]);
+        }
+        p = bh + HP;
+    }
+#pragma unroll
+    for (int k = 0; k < HP; ++k) h[k] = fast_tanh(h[k]);
+}
+
+__device__ __forceinline__ const float* w3_of_wide(const float* __restrict__ W, const FlowGeom& g, int HP) {
+    return W + (int64_t)2 * HP * g.d_a + HP + (int64_t)(g.n_hl - 1) * (2 * HP * HP + HP);
+}
+
 // One coupling layer applied in place to this lane's row.  Returns the layer's log|det| contribution
 // (forward: +sum log alpha; inverse: -sum log alpha).
 template <int HP, bool INVERSE>
 __device__ __forceinline__ float coupling_apply(float* __restrict__ row, const float* __restrict__ W,
-                                                const FlowGeom& g, bool rev) {
+                                                const FlowGeom& g, bool rev, float* __restrict__ hbuf = nullptr) {
     float h[HP];
-    conditioner_hidden<HP>(row, W, g, rev, h);
-    const float* W3 = w3_of(W, g, HP);
-    const float* b3 = W3 + (int64_t)2 * g.d_b * HP;
+    const float* W3;
+    const float* b3;
+    if constexpr (HP > 32) {
+        conditioner_hidden_wide<HP>(row, W, g, rev, h, hbuf, (int)(threadIdx.x & 63));
+        W3 = w3_of_wide(W, g, HP);
+        b3 = W3 + (int64_t)4 * g.d_b * HP;  // W3 | W3T | b3
+    } else {
+        conditioner_hidden<HP>(row, W, g, rev, h);
+        W3 = w3_of(W, g, HP);
+        b3 = W3 + (int64_t)2 * g.d_b * HP;
+    }
     float ld = 0.f;
     for (int t = 0; t < g.d_b; ++t) {
         float ua = b3[t], ub = b3[g.d_b + t];
@@ -118,7 +169,8 @@ __device__ __forceinline__ float coupling_apply(float* __restrict__ row, const f
 
 // x -> z in place; returns logdet_forward.
 template <int HP>
-__device__ __forceinline__ float flow_forward_row(float* __restrict__ row, const NfmcRealNVP& f, const FlowGeom& g) {
+__device__ __forceinline__ float flow_forward_row(float* __restrict__ row, const NfmcRealNVP& f, const FlowGeom& g,
+                                                  float* __restrict__ hbuf = nullptr) {
     float ld = 0.f;
     for (int c = 0; c < g.d; ++c) {
         const float ls = f.ea0_log_scale[c];
@@ -126,7 +178,7 @@ __device__ __forceinline__ float flow_forward_row(float* __restrict__ row, const
         ld += ls;
     }
     for (int l = 0; l < g.n_coupling; ++l)
-        ld += coupling_apply<HP, false>(row, f.weights + l * g.layer_stride, g, (l & 1) == 0);
+        ld += coupling_apply<HP, false>(row, f.weights + l * g.layer_stride, g, (l & 1) == 0, hbuf);
     // the last ElementwiseAffine acts on logical coordinates: physical p <-> logical (odd #reversals ? d-1-p : p)
     const bool rev = (g.n_coupling & 1) != 0;
     for (int c = 0; c < g.d; ++c) {
@@ -140,7 +192,8 @@ __device__ __forceinline__ float flow_forward_row(float* __restrict__ row, const
 
 // z -> x in place; returns logdet_inverse.
 template <int HP>
-__device__ __forceinline__ float flow_inverse_row(float* __restrict__ row, const NfmcRealNVP& f, const FlowGeom& g) {
+__device__ __forceinline__ float flow_inverse_row(float* __restrict__ row, const NfmcRealNVP& f, const FlowGeom& g,
+                                                  float* __restrict__ hbuf = nullptr) {
     float ld = 0.f;
     const bool rev_last = (g.n_coupling & 1) != 0;
     for (int c = 0; c < g.d; ++c) {
@@ -150,7 +203,7 @@ __device__ __forceinline__ float flow_inverse_row(float* __restrict__ row, const
         ld -= ls;
     }
     for (int l = g.n_coupling - 1; l >= 0; --l)
-        ld += coupling_apply<HP, true>(row, f.weights + l * g.layer_stride, g, (l & 1) == 0);
+        ld += coupling_apply<HP, true>(row, f.weights + l * g.layer_stride, g, (l & 1) == 0, hbuf);
     for (int c = 0; c < g.d; ++c) {
         const float ls = f.ea0_log_scale[c];
         row[c] = (row[c] - f.ea0_shift[c]) * fast_exp(-ls);

@@ -28,13 +28,14 @@ __global__ void __launch_bounds__(kFlowBlock) realnvp_forward_kernel(NfmcRealNVP
     const int stride = tile_stride(g.d);
     const int lane = threadIdx.x;
     float* row = lds + lane * stride;
+    float* hbuf = lds + 64 * stride;  // wide conditioners only
     const bool rev = (g.n_coupling & 1) != 0;
     for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         const int64_t r0 = tile * 64;
         __syncthreads();
         tile_load(lds, stride, x, r0, n, g.d);
         __syncthreads();
-        const float ld = flow_forward_row<HP>(row, f, g);
+        const float ld = flow_forward_row<HP>(row, f, g, hbuf);
         float ss = 0.f;
         for (int c = 0; c < g.d; ++c) ss = fmaf(row[c], row[c], ss);
         if (r0 + lane < n) {
@@ -88,6 +89,7 @@ __global__ void __launch_bounds__(kFlowBlock) realnvp_inverse_kernel(NfmcRealNVP
     const int stride = tile_stride(g.d);
     const int lane = threadIdx.x;
     float* row = lds + lane * stride;
+    float* hbuf = lds + 64 * stride;  // wide conditioners only
     const bool rev = (g.n_coupling & 1) != 0;
     for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         const int64_t r0 = tile * 64;
@@ -100,7 +102,7 @@ __global__ void __launch_bounds__(kFlowBlock) realnvp_inverse_kernel(NfmcRealNVP
         } else {
             ss = draw_latent_row(row, g, rng, r0 + lane, n, 0);
         }
-        const float ld = flow_inverse_row<HP>(row, f, g);
+        const float ld = flow_inverse_row<HP>(row, f, g, hbuf);
         if (r0 + lane < n) {
             if (logdet) logdet[r0 + lane] = ld;
             if (log_q) log_q[r0 + lane] = -0.5f * ss - 0.5f * (float)g.d * kLog2Pi - ld;
@@ -122,6 +124,7 @@ __global__ void __launch_bounds__(kFlowBlock) flow_mh_kernel(NfmcFlowMhArgs a, i
     float* pt = lds + 64 * stride;    // proposals
     float* xr = xt + lane * stride;
     float* pr = pt + lane * stride;
+    float* hbuf = lds + 128 * stride;  // wide conditioners only
     const int64_t n = a.n;
     const float base_c = -0.5f * (float)d * kLog2Pi;
 
@@ -144,14 +147,14 @@ __global__ void __launch_bounds__(kFlowBlock) flow_mh_kernel(NfmcFlowMhArgs a, i
             f_x = active ? a.logq[row] : 0.f;
         } else {  // flow.log_prob(x): jump.py:218 / imh.py:214
             for (int c = 0; c < d; ++c) pr[c] = xr[c];
-            const float ld = flow_forward_row<HP>(pr, f, g);
+            const float ld = flow_forward_row<HP>(pr, f, g, hbuf);
             float ss = 0.f;
             for (int c = 0; c < d; ++c) ss = fmaf(pr[c], pr[c], ss);
             f_x = -0.5f * ss + base_c + ld;
         }
         for (int s = 0; s < a.n_steps; ++s) {
             const float ss = draw_latent_row(pr, g, a.rng, row, n, s);       // flow.sample: jump.py:205 / imh.py:221
-            const float ldi = flow_inverse_row<HP>(pr, f, g);
+            const float ldi = flow_inverse_row<HP>(pr, f, g, hbuf);
             const float f_xp = -0.5f * ss + base_c - ldi;
             const float u_xp = potential_row(pr, a.pot, d);                   // jump.py:213 / imh.py:225
             const float lr = (-u_xp) - (-u_x) + f_x - f_xp;                   // util.py:392
@@ -233,7 +236,7 @@ static int check_flow(const NfmcRealNVP* f) {
     if (f->n_coupling > 0 && !f->weights) return NFMC_EINVAL;
     if (f->d < 2 && f->n_coupling > 0) return NFMC_ESHAPE;
     if (f->d > 512) return NFMC_ESHAPE;
-    if (f->n_hidden > 32) return NFMC_EUNSUPPORTED;  // MFMA path: neutra_kernels.hip
+    if (f->n_hidden > 128) return NFMC_EUNSUPPORTED;
     if (!(f->min_scale >= 0.f && f->min_scale < 1.f)) return NFMC_EINVAL;
     if (f->n_coupling > 0 && f->layer_stride < nfmc_realnvp_layer_floats(f->d, f->n_hidden, f->n_hidden_layers))
         return NFMC_EINVAL;
@@ -275,8 +278,13 @@ extern "C" int64_t nfmc_realnvp_layer_floats(int32_t d, int32_t n_hidden, int32_
         case 4: { constexpr int HP = 4; CALL; } break;   \
         case 8: { constexpr int HP = 8; CALL; } break;   \
         case 16: { constexpr int HP = 16; CALL; } break; \
-        default: { constexpr int HP = 32; CALL; } break; \
+        case 32: { constexpr int HP = 32; CALL; } break; \
+        case 64: { constexpr int HP = 64; CALL; } break; \
+        default: { constexpr int HP = 128; CALL; } break; \
     }
+
+// LDS floats behind the wave tiles for the wide conditioners' activation buffer
+static size_t hbuf_bytes(int n_hidden) { return n_hidden > 32 ? (size_t)nfmc_realnvp_padded_hidden(n_hidden) * 64 * sizeof(float) : 0; }
 
 extern "C" int nfmc_realnvp_forward_f32(const NfmcRealNVP* flow, const float* x, int64_t n, float* z, float* logdet,
                                         float* log_prob, nfmc_stream_t stream) {
@@ -285,9 +293,9 @@ extern "C" int nfmc_realnvp_forward_f32(const NfmcRealNVP* flow, const float* x,
     if (!x || n <= 0) return NFMC_EINVAL;
     const int64_t tiles = (n + 63) / 64;
     const int grid = (int)(tiles < 4 * kMaxGrid ? tiles : 4 * kMaxGrid);
-    const size_t lds = (size_t)64 * tile_stride(flow->d) * sizeof(float);
+    const size_t lds = (size_t)64 * tile_stride(flow->d) * sizeof(float) + hbuf_bytes(flow->n_hidden);
     hipStream_t st = (hipStream_t)stream;
-    NFMC_HP_DISPATCH(hp_bucket(flow->n_hidden), {
+    NFMC_HP_DISPATCH(nfmc_realnvp_padded_hidden(flow->n_hidden), {
         if ((rc = set_lds(realnvp_forward_kernel<HP>, lds))) return rc;
         hipLaunchKernelGGL((realnvp_forward_kernel<HP>), dim3(grid), dim3(kFlowBlock), lds, st, *flow, x, n, z, logdet,
                            log_prob, tiles);
@@ -306,9 +314,9 @@ extern "C" int nfmc_realnvp_inverse_f32(const NfmcRealNVP* flow, const float* z,
     r.replay_normals = nullptr;  // explicit latents come through `z`
     const int64_t tiles = (n + 63) / 64;
     const int grid = (int)(tiles < 4 * kMaxGrid ? tiles : 4 * kMaxGrid);
-    const size_t lds = (size_t)64 * tile_stride(flow->d) * sizeof(float);
+    const size_t lds = (size_t)64 * tile_stride(flow->d) * sizeof(float) + hbuf_bytes(flow->n_hidden);
     hipStream_t st = (hipStream_t)stream;
-    NFMC_HP_DISPATCH(hp_bucket(flow->n_hidden), {
+    NFMC_HP_DISPATCH(nfmc_realnvp_padded_hidden(flow->n_hidden), {
         if ((rc = set_lds(realnvp_inverse_kernel<HP>, lds))) return rc;
         hipLaunchKernelGGL((realnvp_inverse_kernel<HP>), dim3(grid), dim3(kFlowBlock), lds, st, *flow, z, n, x, logdet,
                            log_q, r, tiles);
@@ -338,8 +346,8 @@ extern "C" int nfmc_flow_mh_steps_f32(const NfmcFlowMhArgs* args, nfmc_stream_t 
         grid = (int)(tiles < kMaxGrid ? tiles : kMaxGrid);
         if (a.stats.sum_x && a.stats.scratch_bytes < (int64_t)grid * (2 * dp + kStatTail) * (int64_t)sizeof(double))
             return NFMC_ESCRATCH;
-        const size_t lds = (size_t)2 * 64 * tile_stride(d) * sizeof(float);
-        NFMC_HP_DISPATCH(hp_bucket(a.flow.n_hidden), {
+        const size_t lds = (size_t)2 * 64 * tile_stride(d) * sizeof(float) + hbuf_bytes(a.flow.n_hidden);
+        NFMC_HP_DISPATCH(nfmc_realnvp_padded_hidden(a.flow.n_hidden), {
             if ((rc = set_lds(flow_mh_kernel<HP>, lds))) return rc;
             hipLaunchKernelGGL((flow_mh_kernel<HP>), dim3(grid), dim3(kFlowBlock), lds, st, a, tiles, dp);
         })

@@ -80,7 +80,7 @@ def flow_is_native(flow) -> bool:
     if not isinstance(bij, RealNVP):
         return False
     lim = hip.limits()
-    return bij.d <= lim.max_d_flow and bij.n_hidden <= lim.max_hidden_valu and bij.n_hidden_layers <= 4
+    return bij.d <= lim.max_d_flow and bij.n_hidden <= lim.max_hidden
 
 
 def flow_fits_jump_tail(flow) -> bool:

@@ -198,7 +198,8 @@ def test_imh_golden_python_callable_split_path(dev):
 
 # ------------------------------------------------------------------------------------------ flow known answers
 FLOW_CASES = [(6, 2, None, 2), (7, 3, 5, 3), (25, 2, None, 2), (64, 2, None, 2), (64, 4, 16, 2), (100, 3, 7, 1),
-              (8, 1, 32, 2), (256, 2, 4, 2), (2, 2, 4, 2), (3, 5, 9, 2)]
+              (8, 1, 32, 2), (256, 2, 4, 2), (2, 2, 4, 2), (3, 5, 9, 2),
+              (100, 4, 100, 5), (64, 2, 64, 1), (128, 2, 128, 2), (30, 2, 40, 3)]   # wide conditioners
 
 
 @pytest.mark.parametrize('d,nl,nh,cl', FLOW_CASES)
@@ -434,13 +435,17 @@ def test_no_sample_storing(dev):
 
 
 def test_flow_kwargs(dev):
-    """test/test_flow_kwargs.py."""
+    """test/test_flow_kwargs.py (test_basic and test_advanced)."""
     from nfmc_amd import sample
     t = lambda x: torch.sum(x ** 2, dim=-1)
     basic = sample(event_shape=(100,), target=t, flow='realnvp', strategy='imh', n_iterations=3, show_progress=False)
     adv = sample(event_shape=(100,), target=t, flow='realnvp%{"n_layers": 10}', strategy='imh', n_iterations=3,
                  show_progress=False)
     assert len(adv.kernel.flow.bijection.layers) > len(basic.kernel.flow.bijection.layers)
+    adv2 = sample(event_shape=(100,), target=t, strategy='imh', n_iterations=3, show_progress=False,
+                  flow='realnvp%{"n_layers": 10, "conditioner_kwargs": {"n_layers": 5, "n_hidden": 100}}')
+    assert len(adv2.kernel.flow.bijection.layers) > len(basic.kernel.flow.bijection.layers)
+    assert adv2.samples.shape == (3, 100, 100) and torch.isfinite(adv2.samples).all()
 
 
 # ------------------------------------------------------------------------------------------ NeuTra (K5)
