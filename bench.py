@@ -16,7 +16,9 @@ roofline: the dominant kernel is `mala_kernel`.  achieved = (8*d bytes per chain
 n_local * 100 transitions per launch) / mean launch duration from HIP events recorded on the launch stream
 during the timed region.  The kernel keeps the state in registers for the 100 transitions of a launch, so its
 real HBM traffic (`traffic`, PMC-measured, profiles/) is ~1% of the algorithmic figure and the kernel is
-VALU-bound; frac is reported against the HBM roof because that is the per-transition bound SURVEY 8d names.
+VALU-issue bound (profiles/: SQ_ACTIVE_INST_VALU ~ 100% of the launch); frac is quoted against the HBM roof
+because that is the per-transition bound SURVEY 8d names -- frac > 1 means the fused kernel runs faster than
+ANY kernel that streams the state once per transition could (it says nothing about being "over peak").
 
 cpu_baseline: the CPU oracle (oracle/samplers.py: the reference's op sequence, eager PyTorch + autograd) on
 one outer iteration of the same workload (65536 chains, 100 MALA + 1 jump), rank 0, N = 1 only.
@@ -147,8 +149,9 @@ def main():
                          'frac': (achieved / HBM_PEAK_GBS) if achieved else None, 'traffic': traffic,
                          'kernel': 'mala_kernel', 'mean_launch_ms': mean_mala, 'launches': len(mala_ms),
                          'algorithmic_bytes_per_launch': alg_bytes_per_launch,
-                         'note': 'state stays in VGPRs for the 100 transitions of a launch: real HBM traffic << '
-                                 'algorithmic bytes, kernel is VALU-bound (Philox + Box-Muller + MALA arithmetic)',
+                         'note': 'state stays in VGPRs for the 100 transitions of a launch: real HBM traffic (traffic) << '
+                                 'algorithmic bytes; the kernel is VALU-issue bound (Philox4x32-10 + Box-Muller + MALA '
+                                 'arithmetic), so frac vs the HBM roof can exceed 1',
                          'flow_mh_mean_launch_ms': (sum(jump_ms) / len(jump_ms)) if jump_ms else None},
             'parity': {'mean_abs_max': float(out.mean.abs().max()), 'variance_mean': float(out.variance.mean()),
                        'variance_rel_err_max': float(((out.variance - 0.5).abs() / 0.5).max()),
