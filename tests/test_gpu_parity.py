@@ -639,3 +639,61 @@ def test_neutra_hmc_mfma_native_stream_matches_oracle(dev, d, nh, cl, nl):
     assert abs(out.statistics.n_accepted_trajectories - tr.n_accepted) <= 5
     np.testing.assert_allclose(out.mean.numpy(), tr.moments.first.numpy(), atol=2e-3)
     np.testing.assert_allclose(out.second_moment.numpy(), tr.moments.second.numpy(), atol=3e-3)
+
+
+# ------------------------------------------------------------------------------------------ N > 1 on one card
+SHARD_WORKER = r'''
+import os, sys, json, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+rank, world, port, outdir = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
+os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
+dist.init_process_group('gloo', rank=rank, world_size=world)
+torch.cuda.set_device(0)
+from nfmc_amd import sample
+from nfmc_amd.dist import Shard
+from nfmc_amd.potentials import SumOfSquares
+d, n = 64, 4096
+x0 = torch.randn(n, d, generator=torch.Generator().manual_seed(3)) * 0.7
+torch.manual_seed(1)   # identical flow weights on every rank
+out = sample(SumOfSquares((d,)), strategy='jump_mala', n_iterations=3, show_progress=False, x0=x0, seed=11,
+             shard=Shard(), inner_param_kwargs={'n_iterations': 10}, param_kwargs={'store_samples': False})
+st = out.statistics
+torch.save({'last': out.running_samples.last_sample.cpu(), 'mean': out.mean, 'second': out.second_moment,
+            'acc': st.n_accepted_trajectories, 'att': st.n_attempted_trajectories, 'jacc': st.n_accepted_jumps,
+            'jatt': st.n_attempted_jumps, 'calls': st.n_target_calls}, os.path.join(outdir, f'r{rank}.pt'))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_sharded_sampling_matches_single_process(dev, tmp_path):
+    """One process per rank (gloo rendezvous, both ranks on this card): every rank simulates its block of the
+    global chains and ends with the statistics of ALL chains (collective C2); together they reproduce the
+    single-process run bit for bit (global-chain-id keyed noise)."""
+    import socket, subprocess, sys, os
+    from nfmc_amd import sample
+    from nfmc_amd.potentials import SumOfSquares
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / 'worker.py'
+    script.write_text(SHARD_WORKER)
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = str(s.getsockname()[1])
+    procs = [subprocess.Popen([sys.executable, str(script), root, str(r), '2', port, str(tmp_path)],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=280)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+    d, n = 64, 4096
+    x0 = torch.randn(n, d, generator=torch.Generator().manual_seed(3)) * 0.7
+    torch.manual_seed(1)
+    ref = sample(SumOfSquares((d,)), strategy='jump_mala', n_iterations=3, show_progress=False, x0=x0, seed=11,
+                 inner_param_kwargs={'n_iterations': 10}, param_kwargs={'store_samples': False})
+    r0, r1 = (torch.load(tmp_path / f'r{r}.pt') for r in range(2))
+    assert torch.equal(torch.cat([r0['last'], r1['last']]), ref.running_samples.last_sample.cpu())
+    for r in (r0, r1):   # both ranks hold the merged (global) statistics
+        assert r['acc'] == ref.statistics.n_accepted_trajectories and r['att'] == ref.statistics.n_attempted_trajectories
+        assert r['jacc'] == ref.statistics.n_accepted_jumps and r['jatt'] == ref.statistics.n_attempted_jumps
+        assert r['calls'] == ref.statistics.n_target_calls
+        np.testing.assert_allclose(r['mean'].numpy(), ref.mean.numpy(), atol=1e-6)
+        np.testing.assert_allclose(r['second'].numpy(), ref.second_moment.numpy(), atol=1e-6)
