@@ -132,7 +132,9 @@ typedef struct {
     int32_t d;
     int32_t n_steps;            /* 1..NFMC_MAX_STEPS_PER_CALL */
     float step_size;
-    int32_t adjust;             /* 1 = MALA, 0 = ULA */
+    int32_t adjust;             /* bit 0: Metropolis test (1 = MALA, 0 = ULA); bit 1: random-walk proposal
+                                   x' = x + inv_mass_diag * eps instead of the Langevin drift (mh.py:51-60:
+                                   3 = MH, 2 = RandomWalk) */
     const float* inv_mass_diag; /* (d,) or NULL = ones (mcmc/base.py:113-116) */
     NfmcPotential pot;
     NfmcRng rng;

@@ -20,13 +20,32 @@ namespace nfmc {
 template <int CPL, int LPC, bool FAST>
 struct MassCoef {
     // Langevin: c1 = -h/m^2, c2 = sqrt(2h)/m, hA = h/m^2, invA = m^2 ; HMC: rs = 1/sqrt(m), m
-    float c1_s, c2_s, hA_s;
+    // Random-walk proposals (mh.py:51-55): x' = x + m eps, symmetric => c1 = 0, c2 = m and no q terms.
+    float c1_s, c2_s, hA_s, cg_s, kap_s;
     float c1[FAST ? 1 : CPL], c2[FAST ? 1 : CPL], hA[FAST ? 1 : CPL], invA[FAST ? 1 : CPL];
-    float m[FAST ? 1 : CPL], rs[FAST ? 1 : CPL];
+    float m[FAST ? 1 : CPL], rs[FAST ? 1 : CPL], cg[FAST ? 1 : CPL], kap[FAST ? 1 : CPL];
 
-    __device__ __forceinline__ void init(float h, float sqrt2h, const float* __restrict__ imd, int g, int d) {
-        c1_s = -h;
-        c2_s = sqrt2h;
+    // coefficients of the closed-form quadratic-potential transition: x' = x + cg t + c2 eps,
+    // log r = sum kap (t^2 - t'^2);  MALA: cg = -2 a h/m^2, kap = a^2 h/m^2;  random walk: cg = 0, kap = a
+    template <class PotT>
+    __device__ __forceinline__ void init_quadratic(const PotT& pot, bool rw) {
+        cg_s = rw ? 0.f : c1_s * (2.f * pot.aa(0));
+        kap_s = rw ? pot.aa(0) : pot.aa(0) * pot.aa(0) * hA_s;
+        if constexpr (!FAST) {
+#pragma unroll
+            for (int i = 0; i < CPL; ++i) {
+                cg[i] = rw ? 0.f : c1[i] * (2.f * pot.aa(i));
+                kap[i] = rw ? pot.aa(i) : pot.aa(i) * pot.aa(i) * hA[i];
+            }
+        }
+    }
+    __device__ __forceinline__ float CG(int i) const { return FAST ? cg_s : cg[FAST ? 0 : i]; }
+    __device__ __forceinline__ float KAP(int i) const { return FAST ? kap_s : kap[FAST ? 0 : i]; }
+
+    __device__ __forceinline__ void init(float h, float sqrt2h, const float* __restrict__ imd, int g, int d,
+                                         bool rw = false) {
+        c1_s = rw ? 0.f : -h;
+        c2_s = rw ? 1.f : sqrt2h;
         hA_s = h;
         if constexpr (!FAST) {
 #pragma unroll
@@ -35,8 +54,8 @@ struct MassCoef {
                 const bool ok = c < d;
                 const float mm = (ok && imd) ? imd[c] : 1.f;
                 const float A = 1.f / (mm * mm);
-                c1[i] = ok ? (-h) / (mm * mm) : 0.f;
-                c2[i] = ok ? sqrt2h / mm : 0.f;
+                c1[i] = (ok && !rw) ? (-h) / (mm * mm) : 0.f;
+                c2[i] = ok ? (rw ? mm : sqrt2h / mm) : 0.f;
                 hA[i] = ok ? h * A : 0.f;
                 invA[i] = ok ? 1.f / A : 0.f;
                 m[i] = ok ? mm : 0.f;
@@ -212,12 +231,14 @@ __global__ void __launch_bounds__(kBlock, NFMC_WPE) mala_kernel(NfmcMalaArgs a, 
     const int d = a.d;
     const int64_t n = a.n;
     const float h = a.step_size;
-    const float inv4h = 1.f / (4.f * h);
+    const bool adjust = (a.adjust & 1) != 0, rw = (a.adjust & 2) != 0;
+    const float inv4h = rw ? 0.f : 1.f / (4.f * h);
 
     MassCoef<CPL, LPC, FAST> mc;
-    mc.init(h, sqrt2h, a.inv_mass_diag, g, d);
+    mc.init(h, sqrt2h, a.inv_mass_diag, g, d, rw);
     Pot<CPL, LPC, FAST> pot;
     pot.init(a.pot, g, d);
+    if constexpr (Pot<CPL, LPC, FAST>::kQuadratic) mc.init_quadratic(pot, rw);
     FlowB<CPL, LPC, JHP == 0 ? 4 : JHP, true> fl;
     if constexpr (JHP > 0) {
         FlowImage<CPL, LPC, JHP>::stage(flow_lds, jd.flow, kBlock);
@@ -256,16 +277,16 @@ __global__ void __launch_bounds__(kBlock, NFMC_WPE) mala_kernel(NfmcMalaArgs a, 
 #pragma unroll
                 for (int i = 0; i < CPL; ++i) {
                     const float t = x[i] - pot.bb(i);
-                    xp[i] = fmaf(mc.C2(i), e[i], fmaf(mc.C1(i) * (2.f * pot.aa(i)), t, x[i]));  // langevin.py:74-76
+                    xp[i] = fmaf(mc.C2(i), e[i], fmaf(mc.CG(i), t, x[i]));  // langevin.py:74-76 / mh.py:55
                     const float tp = xp[i] - pot.bb(i);
-                    lr = fmaf(pot.aa(i) * pot.aa(i) * mc.HA(i) * (t - tp), t + tp, lr);
+                    lr = fmaf(mc.KAP(i) * (t - tp), t + tp, lr);
                 }
             } else {
                 const auto ctx = pot.prepare(x, g, d);
 #pragma unroll
                 for (int i = 0; i < CPL; ++i)
                     xp[i] = fmaf(mc.C2(i), e[i], fmaf(mc.C1(i), pot.grad(ctx, i, x[i]), x[i]));  // langevin.py:74-76
-                if (a.adjust) {
+                if (adjust) {
                     const auto ctxp = pot.prepare(xp, g, d);
 #pragma unroll
                     for (int i = 0; i < CPL; ++i) {
@@ -277,10 +298,10 @@ __global__ void __launch_bounds__(kBlock, NFMC_WPE) mala_kernel(NfmcMalaArgs a, 
                     }
                 }
             }
-            if (a.adjust) {
+            if (adjust) {
                 lr = group_allreduce<LPC>(lr);
                 const float u = au.draw(a.rng, gchain, row, n, s);
-                accept = fast_ln(u) < lr;  // NaN -> reject (langevin.py:106)
+                accept = fast_ln(u) < lr;  // NaN -> reject (langevin.py:106, mh.py:59)
                 n_bad += (uint32_t)__popcll(__ballot(active && !(fabsf(lr) <= 3.0e38f)) & leaders);
             }
             accept = accept && active;

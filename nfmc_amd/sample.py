@@ -1,10 +1,10 @@
 """Public entry points `sample()` / `create_sampler()` with the reference's signature and keyword
 plumbing (nfmc/sample.py:20-30, 243-314) for the strategies on this build's path:
 
-    mala, ula, hmc, uhmc                                  (inner samplers)
-    imh / fixed_imh, jump_mala, jump_ula, jump_hmc, jump_uhmc, neutra_hmc
+    mala, ula, hmc, uhmc, mh                              (inner samplers)
+    imh / fixed_imh, jump_mala, jump_ula, jump_hmc, jump_uhmc, jump_mh, neutra_hmc, neutra_mh
 
-Other reference strategies (mh, ess, nuts, adaptive_imh, jump_mh, jump_ess, neutra_mh, tess, dlmc) are
+Other reference strategies (ess, nuts, adaptive_imh, jump_ess, tess, dlmc) are
 outside the path and raise ValueError naming what is supported.
 """
 from typing import Optional, Tuple, Union
@@ -15,9 +15,10 @@ from .containers import MCMCOutput, NFMCKernel, Sampler
 from .flows import Flow
 from .potentials import Potential
 from .samplers.imh import FixedIMH, IMHKernel, IMHParameters
-from .samplers.jump import JumpHMC, JumpMALA, JumpNFMCParameters, JumpUHMC, JumpULA
-from .samplers.mcmc import HMC, MALA, UHMC, ULA, HMCKernel, HMCParameters, LangevinKernel, LangevinParameters
-from .samplers.neutra import NeuTraHMC, NeuTraKernel, NeuTraParameters
+from .samplers.jump import JumpHMC, JumpMALA, JumpMH, JumpNFMCParameters, JumpUHMC, JumpULA
+from .samplers.mcmc import (HMC, MALA, MH, UHMC, ULA, HMCKernel, HMCParameters, LangevinKernel, LangevinParameters,
+                            MHKernel, MHParameters)
+from .samplers.neutra import NeuTraHMC, NeuTraKernel, NeuTraMH, NeuTraParameters
 from .util import create_flow_object, get_supported_samplers
 
 
@@ -57,8 +58,11 @@ def create_sampler(target: callable,
     if strategy == "ula":
         return ULA(event_shape, target, LangevinKernel(event_size=event_size, **kernel_kwargs),
                    LangevinParameters(**param_kwargs))
+    if strategy == "mh":
+        return MH(event_shape, target, MHKernel(event_size=event_size, **kernel_kwargs), MHParameters(**param_kwargs))
 
-    if strategy in ("imh", "fixed_imh", "jump_mala", "jump_ula", "jump_hmc", "jump_uhmc", "neutra_hmc"):
+    if strategy in ("imh", "fixed_imh", "jump_mala", "jump_ula", "jump_hmc", "jump_uhmc", "jump_mh", "neutra_hmc",
+                    "neutra_mh"):
         if flow is None:
             raise ValueError("Flow object must be provided")
         if isinstance(flow, str):
@@ -83,6 +87,15 @@ def create_sampler(target: callable,
                        params=JumpNFMCParameters(**param_kwargs),
                        inner_kernel=HMCKernel(event_size=event_size, **inner_kernel_kwargs),
                        inner_params=HMCParameters(**inner_param_kwargs))
+        if strategy == 'jump_mh':
+            return JumpMH(event_shape, target, kernel=NFMCKernel(event_shape, flow=flow_object),
+                          params=JumpNFMCParameters(**param_kwargs),
+                          inner_kernel=MHKernel(event_size=event_size, **inner_kernel_kwargs),
+                          inner_params=MHParameters(**inner_param_kwargs))
+        if strategy == 'neutra_mh':
+            return NeuTraMH(event_shape, target, MHKernel(event_size=event_size, **inner_kernel_kwargs),
+                            MHParameters(**inner_param_kwargs), NeuTraKernel(event_shape, flow=flow_object),
+                            NeuTraParameters(**param_kwargs))
         if strategy == 'neutra_hmc':
             return NeuTraHMC(event_shape, target, HMCKernel(event_size=event_size, **inner_kernel_kwargs),
                              HMCParameters(**inner_param_kwargs), NeuTraKernel(event_shape, flow=flow_object),

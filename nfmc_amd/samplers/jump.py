@@ -18,7 +18,7 @@ from ..flows import RealNVP
 from ..tuning import train_val_split
 from ..util import metropolis_acceptance_log_ratio
 from .common import Run, chunks, resolve_target
-from .mcmc import HMC, MALA, UHMC, ULA
+from .mcmc import HMC, MALA, MH, UHMC, ULA
 
 
 @dataclass
@@ -336,4 +336,8 @@ class JumpMALA(_make(MALA)):
 
 
 class JumpULA(_make(ULA)):
+    pass
+
+
+class JumpMH(_make(MH)):
     pass

@@ -261,7 +261,7 @@ class Langevin(MetropolisSampler):
         a = hip.NfmcMalaArgs()
         a.x, a.n, a.d, a.n_steps = hip.ptr(run.x), run.n, run.d, k
         a.step_size = float(self.kernel.step_size)
-        a.adjust = 1 if self.params.adjustment else 0
+        a.adjust = (1 if self.params.adjustment else 0) | (2 if getattr(self, 'random_walk', False) else 0)
         imd = imd_tensor(self.kernel, run.dev)
         a.inv_mass_diag = hip.ptr(imd)
         a.pot = pot.descriptor(run.dev)
@@ -325,6 +325,88 @@ class MALA(Langevin):
 
 
 class ULA(Langevin):
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.params.adjustment = False
+
+
+@dataclass
+class MHKernel(MetropolisKernel):
+    event_size: int
+
+    def __repr__(self):
+        return (f'log step: {math.log(self.step_size):.2f}, '
+                f'mass norm: {torch.max(torch.abs(self.inv_mass_diag)):.2f}')
+
+
+@dataclass
+class MHParameters(MetropolisParameters):
+    imd_adjustment: float = 1e-5
+
+    def __post_init__(self):
+        self.tune_step_size = False       # mh.py:23-25
+        self.tune_inv_mass_diag = True
+
+
+class MH(Langevin):
+    """Random-walk Metropolis (nfmc/algorithms/sampling/mcmc/mh.py): x' = x + eps * inv_mass_diag.  Runs on the
+    Langevin kernel with a random-walk proposal (NfmcMalaArgs.adjust bit 1)."""
+    random_walk = True
+
+    def __init__(self, event_shape, target, kernel: Optional[MHKernel] = None, params: Optional[MHParameters] = None):
+        if kernel is None:
+            kernel = MHKernel(event_size=int(torch.prod(torch.as_tensor(event_shape))))
+        if params is None:
+            params = MHParameters()
+        MetropolisSampler.__init__(self, event_shape, target, kernel, params)
+
+    @property
+    def name(self):
+        return "MH"
+
+    def _counts(self, n, k):
+        return (2 * n * k if self.params.adjustment else 0), 0   # mh.py:67-71
+
+    def propose(self, x):
+        """mh.py:44-73 for an arbitrary target (split path)."""
+        dev = hip.require_gpu()
+        n = x.shape[0]
+        xf = x.detach().to(dev, torch.float32).reshape(n, -1).contiguous()
+        d = xf.shape[1]
+        run = getattr(self, '_cur_run', None)
+        step = getattr(self, '_cur_step', 0)
+        seed = run.seed if run is not None else (self.seed or 0)
+        off = run.chain_offset if run is not None else 0
+        un = None
+        if run is not None and run.replay is not None:
+            nz, un = run.replay.take(1, with_uniforms=self.params.adjustment)
+            noise = nz[0]
+        else:
+            noise = torch.empty(n, d, dtype=torch.float32, device=dev)
+            rng = hip.make_rng(seed, off, step)
+            hip.check(hip.lib().nfmc_philox_normals_f32(C.byref(rng), hip.TAG_NOISE, n, d, hip.ptr(noise), hip.stream()),
+                      'nfmc_philox_normals_f32')
+        x_prime = (xf + noise * self.kernel.inv_mass_diag.to(dev, torch.float32)[None]).contiguous()
+        self._last_log_ratio = None
+        self._last_uniforms = un[0].contiguous() if un is not None else None
+        mask = torch.ones(n, dtype=torch.bool, device=dev)
+        n_calls = 0
+        if self.params.adjustment:
+            with torch.no_grad():
+                lr = (self.target(xf.reshape(n, *self.event_shape)).reshape(-1)
+                      - self.target(x_prime.reshape(n, *self.event_shape)).reshape(-1))
+            self._last_log_ratio = lr.float().contiguous()
+            n_calls = 2 * n
+            if run is None:
+                unif = torch.empty(n, dtype=torch.float32, device=dev)
+                rng = hip.make_rng(seed, off, step)
+                hip.check(hip.lib().nfmc_philox_uniforms_f32(C.byref(rng), hip.TAG_ACCEPT, n, hip.ptr(unif), hip.stream()),
+                          'nfmc_philox_uniforms_f32')
+                mask = torch.log(unif) < self._last_log_ratio
+        return x_prime, mask, n_calls, 0, 0
+
+
+class RandomWalk(MH):
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
         self.params.adjustment = False

@@ -18,7 +18,8 @@ from tqdm import tqdm
 from .. import hip
 from ..containers import MCMCOutput, NFMCKernel, NFMCParameters, Sampler
 from .common import Run, chunks, imd_tensor, resolve_target
-from .mcmc import HMC, HMCKernel, HMCParameters, MetropolisKernel, MetropolisParameters, MetropolisSampler
+from .mcmc import (HMC, MH, HMCKernel, HMCParameters, MHKernel, MHParameters, MetropolisKernel, MetropolisParameters,
+                   MetropolisSampler)
 
 
 @dataclass
@@ -109,8 +110,12 @@ class NeuTra(Sampler):
         run = Run(self, x0)
         n, d, event_shape = run.n, run.d, run.event_shape
         pot = resolve_target(self.target, event_shape)
-        if pot is None or not isinstance(inner, HMC):
-            raise ValueError('neutra: the device path needs a closed-form potential and the HMC inner sampler')
+        if not isinstance(inner, HMC) or pot is None:
+            # NeuTraMH / arbitrary targets: the inner sampler's split path on the adjusted target (neutra.py:116-127)
+            inner.seed, inner.shard, inner.replay = self.seed, self.shard, self.replay
+            out = inner.sample(x0, show_progress=show_progress, time_limit_seconds=time_limit_seconds)
+            out.kernel.flow = self.kernel.flow
+            return out
         out = MCMCOutput(event_shape, store_samples=self.params.store_samples)
         T = int(self.params.n_iterations)
         buf = torch.empty(T, n, d, dtype=torch.float32, device=run.dev) if (self.params.store_samples and T > 0) else None
@@ -189,3 +194,16 @@ class NeuTraHMC(NeuTra):
         if inner_params is None:
             inner_params = HMCParameters()
         super().__init__(event_shape, target, HMC, inner_kernel, inner_params, kernel, params)
+
+
+class NeuTraMH(NeuTra):
+    """neutra.py:147-159: random-walk MH in latent space (the adjusted potential comes from the HIP kernel,
+    the proposal/test through the inner sampler's split path)."""
+
+    def __init__(self, event_shape, target, inner_kernel: MHKernel = None, inner_params: MHParameters = None,
+                 kernel: NeuTraKernel = None, params: NeuTraParameters = None):
+        if inner_kernel is None:
+            inner_kernel = MHKernel(event_size=int(torch.prod(torch.as_tensor(event_shape))))
+        if inner_params is None:
+            inner_params = MHParameters()
+        super().__init__(event_shape, target, MH, inner_kernel, inner_params, kernel, params)

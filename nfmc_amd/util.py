@@ -52,11 +52,11 @@ def metropolis_acceptance_log_ratio(log_prob_target_curr, log_prob_target_prime,
 
 
 def get_supported_mcmc_samplers() -> List[str]:
-    return ['hmc', 'uhmc', 'ula', 'mala']
+    return ['hmc', 'uhmc', 'ula', 'mala', 'mh']
 
 
 def get_supported_nfmc_samplers() -> List[str]:
-    return ['imh', 'fixed_imh', 'jump_mala', 'jump_ula', 'jump_hmc', 'jump_uhmc', 'neutra_hmc']
+    return ['imh', 'fixed_imh', 'jump_mala', 'jump_ula', 'jump_hmc', 'jump_uhmc', 'jump_mh', 'neutra_hmc', 'neutra_mh']
 
 
 def get_supported_samplers() -> List[str]:

@@ -177,6 +177,18 @@ def langevin_propose(x, target, step_size, inv_mass_diag, adjustment, noise, ste
     return x_prime, log_u < log_ratio, log_ratio, log_u
 
 
+# --------------------------------------------------------------------------- random-walk MH (f2)
+def mh_propose(x, target, inv_mass_diag, adjustment, noise, step):
+    """One `MH.propose` (nfmc/algorithms/sampling/mcmc/mh.py:44-73): x' = x + eps * inv_mass_diag, symmetric."""
+    n = x.shape[0]
+    x_prime = x + noise.normal(n, x.shape[1:], step, philox.TAG_NOISE) * inv_mass_diag[None]        # :50-55
+    if not adjustment:
+        return x_prime, torch.ones(n, dtype=torch.bool), None, None
+    log_ratio = (-target(x_prime)) - (-target(x))                                                    # :58, util.py:392
+    log_u = torch.log(noise.uniform(n, step, philox.TAG_ACCEPT))                                      # :59
+    return x_prime, log_u < log_ratio, log_ratio, log_u
+
+
 # --------------------------------------------------------------------------- A.2 HMC / UHMC
 def hmc_propose(x, target, step_size, inv_mass_diag, n_leapfrog, adjustment, noise, step):
     """One `HMC.propose` (hmc.py:96-126) with `hmc_trajectory` (:61-77).  x: (n, d)."""
@@ -200,7 +212,7 @@ def hmc_propose(x, target, step_size, inv_mass_diag, n_leapfrog, adjustment, noi
 # --------------------------------------------------------------------------- inner loop
 def mcmc_sample(x0, target, kind, n_iterations, step_size, inv_mass_diag=None, n_leapfrog=20,
                 adjustment=True, noise=None, step0=0, store=True):
-    """`MCMCSampler.sample` (mcmc/base.py:56-102) for kind in {'langevin', 'hmc'}.
+    """`MCMCSampler.sample` (mcmc/base.py:56-102) for kind in {'langevin', 'hmc', 'mh'}.
 
     Events are flattened to (n, d) for the arithmetic; samples keep the flattened shape.
     """
@@ -216,6 +228,9 @@ def mcmc_sample(x0, target, kind, n_iterations, step_size, inv_mass_diag=None, n
         if kind == 'langevin':
             x_prime, mask, lr, lu = langevin_propose(x, target, step_size, inv_mass_diag, adjustment, noise, step)
             calls = grads = n * (2 if adjustment else 1)                         # langevin.py:116-120
+        elif kind == 'mh':
+            x_prime, mask, lr, lu = mh_propose(x, target, inv_mass_diag, adjustment, noise, step)
+            calls, grads = (2 * n if adjustment else 0), 0                       # mh.py:67-71
         else:
             x_prime, mask, lr, lu = hmc_propose(x, target, step_size, inv_mass_diag, n_leapfrog, adjustment, noise, step)
             grads = 2 * n_leapfrog * n                                           # hmc.py:122-125

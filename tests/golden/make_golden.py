@@ -162,6 +162,19 @@ def main():
     save('mala_funnel_d5', rec, x0=x0.numpy(), step_size=np.float64(kern.step_size),
          inv_mass_diag=kern.inv_mass_diag.numpy(), **out_arrays(out))
 
+    # ---------------------------------------------------------------- random-walk MH (f2)
+    from nfmc.algorithms.sampling.mcmc.mh import MH, RandomWalk, MHKernel, MHParameters
+    from nfmc.algorithms.sampling.nfmc.jump import JumpMH
+    for name, cls, d, n, k, imd in [('mh_d5', MH, 5, 16, 8, 'small'), ('rw_d6', RandomWalk, 6, 8, 4, 'small')]:
+        torch.manual_seed(31)
+        x0 = torch.randn(n, d)
+        kern = MHKernel(event_size=d)
+        kern.inv_mass_diag = torch.linspace(0.2, 0.5, d)
+        s = cls((d,), sumsq, kern, MHParameters(n_iterations=k))
+        with DrawRecorder() as rec:
+            out = s.sample(x0.clone(), show_progress=False)
+        save(name, rec, x0=x0.numpy(), inv_mass_diag=kern.inv_mass_diag.numpy(), **out_arrays(out))
+
     # ---------------------------------------------------------------- HMC / UHMC (a7)
     for name, cls, d, n, k, L, h, imd in [('hmc_d5', HMC, 5, 8, 4, 3, 0.1, None),
                                           ('hmc_d6_mass', HMC, 6, 8, 4, 4, 0.08, 'ramp'),

@@ -68,8 +68,8 @@ def test_product_does_not_import_the_oracle():
                 assert not re.search(r'^\s*(from|import)\s+oracle\b', text, re.M), f
 
 
-@pytest.mark.parametrize('strategy', ['mala', 'ula', 'hmc', 'uhmc', 'imh', 'fixed_imh', 'jump_mala', 'jump_ula',
-                                      'jump_hmc', 'jump_uhmc', 'neutra_hmc'])
+@pytest.mark.parametrize('strategy', ['mala', 'ula', 'hmc', 'uhmc', 'mh', 'imh', 'fixed_imh', 'jump_mala', 'jump_ula',
+                                      'jump_hmc', 'jump_uhmc', 'jump_mh', 'neutra_hmc', 'neutra_mh'])
 def test_create_sampler_plumbing(strategy):
     """nfmc/sample.py:20-240 keyword plumbing and defaults."""
     from nfmc_amd.sample import create_sampler
@@ -80,7 +80,10 @@ def test_create_sampler_plumbing(strategy):
         inner = s.inner_sampler
         assert inner.params.n_iterations == (5 if strategy == 'jump_hmc' else 100)   # sample.py:161-162, base.py:31
         assert s.params.adjusted_jumps and not s.params.fit_nf and s.params.n_jumps_before_training == 10
-        assert inner.params.adjustment == (strategy in ('jump_mala', 'jump_hmc'))
+        assert inner.params.adjustment == (strategy in ('jump_mala', 'jump_hmc', 'jump_mh'))
+    if strategy in ('mh', 'jump_mh'):
+        k = s.inner_sampler if strategy == 'jump_mh' else s
+        assert k.params.imd_adjustment == 1e-5 and k.params.tune_step_size is False   # mh.py:20-25
     if 'mala' in strategy or 'ula' in strategy:
         k = s.inner_sampler.kernel if strategy.startswith('jump') else s.kernel
         assert abs(k.step_size - 10 ** (-1 / 3)) < 1e-12                                  # langevin.py:16-18

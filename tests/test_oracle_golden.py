@@ -52,6 +52,14 @@ def test_hmc(name, adjust):
     _check(tr, fx)
 
 
+@pytest.mark.parametrize('name,adjust', [('mh_d5', True), ('rw_d6', False)])
+def test_random_walk_mh(name, adjust):
+    fx = load_golden(name)
+    tr = osamp.mcmc_sample(torch.from_numpy(fx['x0']), opot.sum_squares, 'mh', fx['exp/samples'].shape[0], 0.01,
+                           torch.from_numpy(fx['inv_mass_diag']), adjustment=adjust, noise=_noise(fx))
+    _check(tr, fx)
+
+
 def test_jump_mala():
     fx = load_golden('jump_mala_d6')
     flow = golden_flow(fx, 6)

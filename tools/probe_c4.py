@@ -1,0 +1,6 @@
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from tools.probe_neutra import run
+if __name__ == '__main__':
+    run(65536, 128, 128, 2, 10, 2)
