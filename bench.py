@@ -75,6 +75,7 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-events', action='store_true', help='(experiment) no HIP events in the timed region')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -111,7 +112,8 @@ def main():
 
     if args.warmup > 0:
         run(args.warmup)
-    dt, out = run(args.steps, time_kernels=True)
+    # HIP events only around the dominant kernel's launches: every event pair costs ~6 us of stream time
+    dt, out = run(args.steps, time_kernels=False if args.no_kernel_events else 'mala_steps')
     if distributed:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

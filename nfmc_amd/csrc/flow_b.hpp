@@ -207,4 +207,47 @@ struct FlowB {
     }
 };
 
+// latent z ~ N(0, I) for this lane's positions: position p holds logical latent coordinate (revl ? d-1-p : p).
+// `replay`: NULL -> native stream 2, else the (n, d) latents of this transition.
+template <int CPL, int LPC>
+__device__ __forceinline__ void draw_latent(float (&z)[CPL], const float* __restrict__ replay, uint64_t seed,
+                                            uint32_t step, uint32_t gchain, int64_t row, int64_t n, int d, int g,
+                                            bool revl) {
+    if (replay) {
+        const float* src = replay + row * d;
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            const int p = coord_of<CPL, LPC>(g, i);
+            z[i] = (row < n && p < d) ? src[revl ? d - 1 - p : p] : 0.f;
+        }
+        return;
+    }
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    if (!revl || (d & 3) == 0) {
+        // a register quad is one Philox block (reversed flows with d % 4 == 0: block d/4-1-b, elements reversed)
+#pragma unroll
+        for (int q = 0; q < CPL / 4; ++q) {
+            const int b = q * LPC + g;
+            float w[4];
+            philox_normal4(gchain, step, (uint32_t)(revl ? (d >> 2) - 1 - b : b), kTagLatent, k0, k1, w);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) z[4 * q + r] = (4 * b + r < d) ? (revl ? w[3 - r] : w[r]) : 0.f;
+        }
+    } else {
+        // reversed AND ragged: the quad straddles two blocks; rare, so one (low-register) call per coordinate
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            const int c = d - 1 - coord_of<CPL, LPC>(g, i);
+            float v = 0.f;
+            if (c >= 0) {
+                float w[4];
+                philox_normal4(gchain, step, (uint32_t)(c >> 2), kTagLatent, k0, k1, w);
+                const int e = c & 3;
+                v = e == 0 ? w[0] : (e == 1 ? w[1] : (e == 2 ? w[2] : w[3]));
+            }
+            z[i] = v;
+        }
+    }
+}
+
 }  // namespace nfmc

@@ -6,56 +6,6 @@
 
 namespace nfmc {
 
-// latent z ~ N(0, I) for this lane's positions: position p holds logical latent coordinate (revl ? d-1-p : p)
-template <int CPL, int LPC>
-__device__ __forceinline__ void draw_latent(float (&z)[CPL], const NfmcRng& rng, uint32_t gchain, int64_t row, int64_t n,
-                                            int d, int g, int s, bool revl) {
-    if (rng.replay_normals) {
-        const float* src = rng.replay_normals + ((int64_t)s * n + row) * d;
-#pragma unroll
-        for (int i = 0; i < CPL; ++i) {
-            const int p = coord_of<CPL, LPC>(g, i);
-            z[i] = (row < n && p < d) ? src[revl ? d - 1 - p : p] : 0.f;
-        }
-        return;
-    }
-    const uint32_t k0 = (uint32_t)rng.seed, k1 = (uint32_t)(rng.seed >> 32);
-    const uint32_t step = rng.step0 + (uint32_t)s;
-    if (!revl) {
-#pragma unroll
-        for (int q = 0; q < CPL / 4; ++q) {
-            float w[4];
-            philox_normal4(gchain, step, (uint32_t)(q * LPC + g), kTagLatent, k0, k1, w);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) z[4 * q + r] = (coord_of<CPL, LPC>(g, 4 * q + r) < d) ? w[r] : 0.f;
-        }
-    } else {
-        // logical coordinates d-1-p of a register quad straddle at most two Philox blocks
-#pragma unroll
-        for (int q = 0; q < CPL / 4; ++q) {
-            const int p0 = coord_of<CPL, LPC>(g, 4 * q);
-            const int chi = d - 1 - p0, clo = d - 4 - p0;  // logical coords of registers 0 and 3 (may be < 0: padding)
-            float wa[4] = {0.f, 0.f, 0.f, 0.f}, wb[4] = {0.f, 0.f, 0.f, 0.f};
-            const int bhi = chi >> 2, blo = clo >> 2;
-            if (chi >= 0) philox_normal4(gchain, step, (uint32_t)bhi, kTagLatent, k0, k1, wa);
-            if (clo >= 0 && blo != bhi) philox_normal4(gchain, step, (uint32_t)blo, kTagLatent, k0, k1, wb);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int c = chi - r;
-                float v = 0.f;
-                if (c >= 0) {
-                    const int e = c & 3;
-                    const bool hi = (c >> 2) == bhi;
-                    const float a0 = hi ? wa[0] : wb[0], a1 = hi ? wa[1] : wb[1], a2 = hi ? wa[2] : wb[2],
-                                a3 = hi ? wa[3] : wb[3];
-                    v = e == 0 ? a0 : (e == 1 ? a1 : (e == 2 ? a2 : a3));
-                }
-                z[4 * q + r] = v;
-            }
-        }
-    }
-}
-
 template <int CPL, int LPC, int HP, template <int, int, bool> class Pot, bool FAST>
 __global__ void __launch_bounds__(kBlock) flow_mh_b_kernel(NfmcFlowMhArgs a, int64_t tiles) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -111,7 +61,8 @@ __global__ void __launch_bounds__(kBlock) flow_mh_b_kernel(NfmcFlowMhArgs a, int
         }
         for (int s = 0; s < a.n_steps; ++s) {
             float xp[CPL];
-            draw_latent<CPL, LPC>(xp, a.rng, gchain, row, n, d, g, s, revl);  // flow.sample: jump.py:205 / imh.py:221
+            draw_latent<CPL, LPC>(xp, a.rng.replay_normals ? a.rng.replay_normals + (int64_t)s * n * d : nullptr, a.rng.seed,
+                                  a.rng.step0 + (uint32_t)s, gchain, row, n, d, g, revl);  // flow.sample: jump.py:205 / imh.py:221
             float part = 0.f;
 #pragma unroll
             for (int i = 0; i < CPL; ++i) part = fmaf(-0.5f * xp[i], xp[i], part);
@@ -165,9 +116,9 @@ __global__ void __launch_bounds__(kBlock) flow_mh_b_kernel(NfmcFlowMhArgs a, int
 struct BCfg {
     int cpl, lpc;
 };
-static const BCfg kBCfgs[] = {{4, 1}, {4, 2}, {4, 4}, {4, 8}, {8, 8}, {8, 16}, {8, 32}, {8, 64}};
+static const BCfg kBCfgs[] = {{4, 1}, {4, 2}, {4, 4}, {4, 8}, {8, 8}, {4, 16}, {8, 16}, {4, 32}, {8, 32}, {4, 64}, {8, 64}};
 
-#define NFMC_FOR_BCFG(M) M(4, 1) M(4, 2) M(4, 4) M(4, 8) M(8, 8) M(8, 16) M(8, 32) M(8, 64)
+#define NFMC_FOR_BCFG(M) M(4, 1) M(4, 2) M(4, 4) M(4, 8) M(8, 8) M(4, 16) M(8, 16) M(4, 32) M(8, 32) M(4, 64) M(8, 64)
 
 template <int CPL, int LPC, int HP>
 static int launch_b(const NfmcFlowMhArgs& a, bool fast, int64_t tiles, int grid, hipStream_t st) {
@@ -195,16 +146,30 @@ int flow_mh_b_launch(const NfmcFlowMhArgs& a, hipStream_t st, int* grid_out, int
     const int d = a.flow.d;
     const int hp = a.flow.n_hidden <= 4 ? 4 : 8;
     if (a.flow.n_hidden > 8 || d > 512) return NFMC_EUNSUPPORTED;
+    // smallest capacity; at equal capacity CPL = 8 for many chains (fewer redundant hidden-stack evaluations),
+    // CPL = 4 for few (twice the lanes: IMH at n = 8192 0.345 vs 0.376 ms per 100 transitions)
     BCfg c = {0, 0};
-    for (const BCfg& k : kBCfgs)
-        if (k.cpl * k.lpc >= d && (c.cpl == 0 || k.cpl * k.lpc < c.cpl * c.lpc)) c = k;
+    const int want_cpl = a.n <= 16384 ? 4 : 8;
+    for (const BCfg& k : kBCfgs) {
+        if (k.cpl * k.lpc < d) continue;
+        if (c.cpl == 0 || k.cpl * k.lpc < c.cpl * c.lpc || (k.cpl * k.lpc == c.cpl * c.lpc && k.cpl == want_cpl)) c = k;
+    }
+    if (const char* e = getenv("NFMC_FLOWB_CFG")) {  // "cpl,lpc" override (tuning)
+        int cc = 0, ll = 0;
+        if (sscanf(e, "%d,%d", &cc, &ll) == 2)
+            for (const BCfg& k : kBCfgs)
+                if (k.cpl == cc && k.lpc == ll && cc * ll >= d) c = k;
+    }
     if (!c.cpl) return NFMC_EUNSUPPORTED;
     const int dp = c.cpl * c.lpc;
     const bool fast = d == dp && (d % 4) == 0 && a.pot.a == nullptr && a.pot.b == nullptr &&
                       (((uintptr_t)a.x) & 15u) == 0 && (!a.samples || (((uintptr_t)a.samples) & 15u) == 0);
     const int cpw = kWave / c.lpc;
     const int64_t tiles = (a.n + (int64_t)kWavesPerBlock * cpw - 1) / ((int64_t)kWavesPerBlock * cpw);
-    const int grid = (int)(tiles < kMaxGrid ? tiles : kMaxGrid);
+    int gcap = 512;  // ~2 resident workgroups per CU: the weight image is staged once per workgroup, so fewer,
+                     // longer-lived workgroups amortise it (2048 workgroups: 57 us per jump, see profiles/)
+    if (const char* e = getenv("NFMC_FLOWB_GRID")) gcap = atoi(e) > 0 ? atoi(e) : gcap;
+    const int grid = (int)(tiles < gcap ? tiles : gcap);
     if (a.stats.sum_x && a.stats.scratch_bytes < (int64_t)grid * (2 * dp + kStatTail) * (int64_t)sizeof(double))
         return NFMC_ESCRATCH;
     int rc = NFMC_EUNSUPPORTED;

@@ -118,56 +118,6 @@ struct JumpDev {
     float* log_ratio_out;
 };
 
-// latent z ~ N(0, I) for this lane's positions: position p holds logical latent coordinate (revl ? d-1-p : p)
-template <int CPL, int LPC>
-__device__ __forceinline__ void draw_latent(float (&z)[CPL], const float* __restrict__ replay, uint64_t seed,
-                                            uint32_t step, uint32_t gchain, int64_t row, int64_t n, int d, int g,
-                                            bool revl) {
-    if (replay) {
-        const float* src = replay + row * d;
-#pragma unroll
-        for (int i = 0; i < CPL; ++i) {
-            const int p = coord_of<CPL, LPC>(g, i);
-            z[i] = (row < n && p < d) ? src[revl ? d - 1 - p : p] : 0.f;
-        }
-        return;
-    }
-    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-    if (!revl) {
-#pragma unroll
-        for (int q = 0; q < CPL / 4; ++q) {
-            float w[4];
-            philox_normal4(gchain, step, (uint32_t)(q * LPC + g), kTagLatent, k0, k1, w);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) z[4 * q + r] = (coord_of<CPL, LPC>(g, 4 * q + r) < d) ? w[r] : 0.f;
-        }
-    } else {
-        // logical coordinates d-1-p of a register quad straddle at most two Philox blocks
-#pragma unroll
-        for (int q = 0; q < CPL / 4; ++q) {
-            const int p0 = coord_of<CPL, LPC>(g, 4 * q);
-            const int chi = d - 1 - p0, clo = d - 4 - p0;
-            float wa[4] = {0.f, 0.f, 0.f, 0.f}, wb[4] = {0.f, 0.f, 0.f, 0.f};
-            const int bhi = chi >> 2, blo = clo >> 2;
-            if (chi >= 0) philox_normal4(gchain, step, (uint32_t)bhi, kTagLatent, k0, k1, wa);
-            if (clo >= 0 && blo != bhi) philox_normal4(gchain, step, (uint32_t)blo, kTagLatent, k0, k1, wb);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int c = chi - r;
-                float v = 0.f;
-                if (c >= 0) {
-                    const int e = c & 3;
-                    const bool hi = (c >> 2) == bhi;
-                    const float a0 = hi ? wa[0] : wb[0], a1 = hi ? wa[1] : wb[1], a2 = hi ? wa[2] : wb[2],
-                                a3 = hi ? wa[3] : wb[3];
-                    v = e == 0 ? a0 : (e == 1 ? a1 : (e == 2 ? a2 : a3));
-                }
-                z[4 * q + r] = v;
-            }
-        }
-    }
-}
-
 // One flow-proposal Metropolis jump on the registers of the chain (jump.py:205-243).  Returns accept.
 // (The fused kernels cap their VGPR budget at 128 so the jump tail, executed once per launch, cannot cost the
 // inner loop its occupancy: __launch_bounds__ below.)

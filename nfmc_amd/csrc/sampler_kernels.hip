@@ -8,7 +8,7 @@ namespace nfmc {
 // (CPL, LPC) layouts, ordered by capacity CPL*LPC; equal capacities in order of measured preference
 // (CPL = 8 keeps 4 waves/SIMD resident).
 static const Cfg kCfgs[] = {{4, 1}, {4, 2}, {4, 4}, {4, 8}, {8, 8}, {4, 16}, {16, 4}, {8, 16}, {16, 8}, {8, 32}, {16, 16}, {8, 64}, {16, 32}, {16, 64}};
-static const Cfg kBCfgs[] = {{4, 1}, {4, 2}, {4, 4}, {4, 8}, {8, 8}, {8, 16}, {8, 32}, {8, 64}};  // shared with flow_b
+static const Cfg kBCfgs[] = {{4, 1}, {4, 2}, {4, 4}, {4, 8}, {8, 8}, {8, 16}, {8, 32}, {8, 64}};  // jump-tail variants
 
 static Cfg choose_cfg(int d, bool with_jump) {
     if (const char* e = getenv("NFMC_SAMPLER_CFG")) {  // "cpl,lpc" override (tuning)

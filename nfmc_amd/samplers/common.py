@@ -80,7 +80,9 @@ class Run:
             self.replay = Replay(normals, uniforms, self.dev)
         self.t0 = time.time()
         self.kernel_events = None   # bench.py: list of (label, start_event, end_event) when kernel timing is on
-        if getattr(sampler, 'time_kernels', False):
+        tk = getattr(sampler, 'time_kernels', False)
+        self.kernel_event_filter = tk if isinstance(tk, str) else None   # a label: time only that kernel
+        if tk:
             self.kernel_events = []
 
     def timed(self, label):
@@ -107,15 +109,19 @@ class _Timed:
     def __init__(self, run, label):
         self.run, self.label = run, label
 
+    def _on(self):
+        sel = getattr(self.run, 'kernel_event_filter', None)
+        return self.run.kernel_events is not None and (sel is None or sel == self.label)
+
     def __enter__(self):
-        if self.run.kernel_events is not None:
+        if self._on():
             self.e0 = torch.cuda.Event(enable_timing=True)
             self.e1 = torch.cuda.Event(enable_timing=True)
             self.e0.record(torch.cuda.current_stream())
         return self
 
     def __exit__(self, *exc):
-        if self.run.kernel_events is not None:
+        if self._on():
             self.e1.record(torch.cuda.current_stream())
             self.run.kernel_events.append((self.label, self.e0, self.e1))
 
