@@ -14,11 +14,14 @@
         uint32_t e = a * 3, f = b * 5, g = c * 7, h = d * 11;                        \
         uint64_t w = a, x2 = b, y2 = c, z2 = d;                                      \
         float fa = a * 1e-9f + 1.1f, fb = b * 1e-9f + 1.2f, fc = 1.3f, fd = 1.4f;    \
+        typedef float f2_ __attribute__((ext_vector_type(2)));                       \
+        f2_ pa = {fa, fb}, pb = {fb, fa}, pc = {fc, fd}, pd = {fd, fc};              \
+        const uint64_t sm = __ballot(a & 1);                                         \
         for (int it = 0; it < iters; ++it) {                                         \
             _Pragma("unroll") for (int r = 0; r < REP / 4; ++r) { BODY }             \
         }                                                                            \
         out[blockIdx.x * 256 + threadIdx.x] = a ^ b ^ c ^ d ^ e ^ f ^ g ^ h ^ (uint32_t)w ^ (uint32_t)x2 ^ (uint32_t)y2 ^ (uint32_t)z2 ^ \
-            __float_as_uint(fa) ^ __float_as_uint(fb) ^ __float_as_uint(fc) ^ __float_as_uint(fd);           \
+            __float_as_uint(fa) ^ __float_as_uint(fb) ^ __float_as_uint(fc) ^ __float_as_uint(fd) ^ __float_as_uint(pa[0] + pa[1] + pb[0] + pb[1] + pc[0] + pc[1] + pd[0] + pd[1]); \
     }
 
 // four independent chains per body -> REP instructions per iteration
@@ -44,6 +47,16 @@ BENCH_KERNEL(k_cvt_u2f, asm volatile("v_cvt_f32_u32 %0, %0\n v_cvt_f32_u32 %1, %
 BENCH_KERNEL(k_cndmask, asm volatile("v_cndmask_b32 %0, %0, %1, vcc\n v_cndmask_b32 %1, %1, %2, vcc\n v_cndmask_b32 %2, %2, %3, vcc\n v_cndmask_b32 %3, %3, %0, vcc" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));)
 BENCH_KERNEL(k_dpp, asm volatile("v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "+v"(fa), "+v"(fb), "+v"(fc), "+v"(fd));)
 
+BENCH_KERNEL(k_cndmask_s, asm volatile("v_cndmask_b32 %0, %0, %1, %4\n v_cndmask_b32 %1, %1, %2, %4\n v_cndmask_b32 %2, %2, %3, %4\n v_cndmask_b32 %3, %3, %0, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "s"(sm));)
+BENCH_KERNEL(k_bfi, asm volatile("v_bfi_b32 %0, %4, %0, %1\n v_bfi_b32 %1, %4, %1, %2\n v_bfi_b32 %2, %4, %2, %3\n v_bfi_b32 %3, %4, %3, %0" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e));)
+BENCH_KERNEL(k_pk_fma, asm volatile("v_pk_fma_f32 %0, %0, %0, %0\n v_pk_fma_f32 %1, %1, %1, %1\n v_pk_fma_f32 %2, %2, %2, %2\n v_pk_fma_f32 %3, %3, %3, %3" : "+v"(pa), "+v"(pb), "+v"(pc), "+v"(pd));)
+BENCH_KERNEL(k_pk_mul, asm volatile("v_pk_mul_f32 %0, %0, %0\n v_pk_mul_f32 %1, %1, %1\n v_pk_mul_f32 %2, %2, %2\n v_pk_mul_f32 %3, %3, %3" : "+v"(pa), "+v"(pb), "+v"(pc), "+v"(pd));)
+BENCH_KERNEL(k_pk_add, asm volatile("v_pk_add_f32 %0, %0, %0\n v_pk_add_f32 %1, %1, %1\n v_pk_add_f32 %2, %2, %2\n v_pk_add_f32 %3, %3, %3" : "+v"(pa), "+v"(pb), "+v"(pc), "+v"(pd));)
+BENCH_KERNEL(k_and_or, asm volatile("v_and_or_b32 %0, %0, %1, %2\n v_and_or_b32 %1, %1, %2, %3\n v_and_or_b32 %2, %2, %3, %0\n v_and_or_b32 %3, %3, %0, %1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));)
+BENCH_KERNEL(k_mul_f32, asm volatile("v_mul_f32 %0, %0, %0\n v_mul_f32 %1, %1, %1\n v_mul_f32 %2, %2, %2\n v_mul_f32 %3, %3, %3" : "+v"(fa), "+v"(fb), "+v"(fc), "+v"(fd));)
+BENCH_KERNEL(k_cos, asm volatile("v_cos_f32 %0, %0\n v_cos_f32 %1, %1\n v_cos_f32 %2, %2\n v_cos_f32 %3, %3" : "+v"(fa), "+v"(fb), "+v"(fc), "+v"(fd));)
+BENCH_KERNEL(k_fmac_e32, asm volatile("v_fmac_f32 %0, %1, %2\n v_fmac_f32 %1, %2, %3\n v_fmac_f32 %2, %3, %0\n v_fmac_f32 %3, %0, %1" : "+v"(fa), "+v"(fb), "+v"(fc), "+v"(fd));)
+
 struct Ent { const char* name; void (*fn)(uint32_t*, int); };
 
 int main() {
@@ -55,7 +68,10 @@ int main() {
                   {"v_mul_u32_u24", k_mul24}, {"v_mul_hi_u32_u24", k_mulhi24}, {"v_mad_u32_u24", k_mad24},
                   {"v_xad_u32", k_xad}, {"v_add3_u32", k_add3}, {"v_lshl_add_u32", k_lshl_add}, {"v_log_f32", k_log},
                   {"v_exp_f32", k_exp}, {"v_sin_f32", k_sin}, {"v_sqrt_f32", k_sqrt}, {"v_rcp_f32", k_rcp},
-                  {"v_cvt_f32_u32", k_cvt_u2f}, {"v_cndmask_b32", k_cndmask}, {"v_add_f32_dpp", k_dpp}};
+                  {"v_cvt_f32_u32", k_cvt_u2f}, {"v_cndmask_b32", k_cndmask}, {"v_add_f32_dpp", k_dpp},
+                  {"v_cndmask(sgpr)", k_cndmask_s}, {"v_bfi_b32", k_bfi}, {"v_pk_fma_f32", k_pk_fma}, {"v_pk_mul_f32", k_pk_mul},
+                  {"v_pk_add_f32", k_pk_add}, {"v_and_or_b32", k_and_or}, {"v_mul_f32", k_mul_f32}, {"v_cos_f32", k_cos},
+                  {"v_fmac_f32(e32)", k_fmac_e32}};
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
