@@ -14,7 +14,7 @@ import torch
 from .containers import MCMCOutput, NFMCKernel, Sampler
 from .flows import Flow
 from .potentials import Potential
-from .samplers.imh import FixedIMH, IMHKernel, IMHParameters
+from .samplers.imh import AdaptiveIMH, FixedIMH, IMHKernel, IMHParameters
 from .samplers.jump import JumpHMC, JumpMALA, JumpMH, JumpNFMCParameters, JumpUHMC, JumpULA
 from .samplers.mcmc import (HMC, MALA, MH, UHMC, ULA, HMCKernel, HMCParameters, LangevinKernel, LangevinParameters,
                             MHKernel, MHParameters)
@@ -61,7 +61,7 @@ def create_sampler(target: callable,
     if strategy == "mh":
         return MH(event_shape, target, MHKernel(event_size=event_size, **kernel_kwargs), MHParameters(**param_kwargs))
 
-    if strategy in ("imh", "fixed_imh", "jump_mala", "jump_ula", "jump_hmc", "jump_uhmc", "jump_mh", "neutra_hmc",
+    if strategy in ("imh", "fixed_imh", "adaptive_imh", "jump_mala", "jump_ula", "jump_hmc", "jump_uhmc", "jump_mh", "neutra_hmc",
                     "neutra_mh"):
         if flow is None:
             raise ValueError("Flow object must be provided")
@@ -73,6 +73,10 @@ def create_sampler(target: callable,
             raise ValueError(f"Unknown type for normalizing flow: {type(flow)}")
         if strategy in ("imh", "fixed_imh"):
             return FixedIMH(event_shape, target, IMHKernel(event_shape, flow=flow_object), IMHParameters(**param_kwargs))
+        if strategy == "adaptive_imh":
+            # sample.py:127-130 builds IMHParameters() and so drops param_kwargs (n_iterations included);
+            # deliberate deviation: they are honoured here
+            return AdaptiveIMH(event_shape, target, IMHKernel(event_shape, flow=flow_object), IMHParameters(**param_kwargs))
         if strategy in ('jump_mala', 'jump_ula'):
             cls = JumpMALA if strategy == 'jump_mala' else JumpULA
             return cls(event_shape, target, kernel=NFMCKernel(event_shape, flow=flow_object),

@@ -56,7 +56,7 @@ def get_supported_mcmc_samplers() -> List[str]:
 
 
 def get_supported_nfmc_samplers() -> List[str]:
-    return ['imh', 'fixed_imh', 'jump_mala', 'jump_ula', 'jump_hmc', 'jump_uhmc', 'jump_mh', 'neutra_hmc', 'neutra_mh']
+    return ['imh', 'fixed_imh', 'adaptive_imh', 'jump_mala', 'jump_ula', 'jump_hmc', 'jump_uhmc', 'jump_mh', 'neutra_hmc', 'neutra_mh']
 
 
 def get_supported_samplers() -> List[str]:

@@ -147,6 +147,9 @@ class Flow(nn.Module):
         z, logdet = self.bijection.forward(x)
         return self.base_log_prob(z) + logdet
 
+    def fit(self, x_train, x_val=None, n_epochs: int = 1, lr: float = 0.05, **_ignored):
+        return fit_(self, x_train, n_epochs=n_epochs, lr=lr)
+
     def sample(self, n, return_log_prob=False, no_grad=False):
         if self._latent_source is not None:
             z = self._latent_source(n)
@@ -158,6 +161,23 @@ class Flow(nn.Module):
             if return_log_prob:
                 return x, self.base_log_prob(z) - logdet_inv
         return x
+
+
+def fit_(flow: Flow, x_train, n_epochs: int = 1, lr: float = 0.05):
+    """Maximum-likelihood refit used by the adaptive samplers (imh.py:171-175 calls `flow.fit(x_train, n_epochs=1)`):
+    `n_epochs` full-batch AdamW steps on -mean log q(x_train); ValueError on a non-finite loss, which is the
+    only error the callers catch.  torchflows' own `fit` is not in /root/reference ("parity unpinned" for its
+    optimiser details); this is the build's spec, mirrored by nfmc_amd/flow_training.py."""
+    opt = torch.optim.AdamW(flow.parameters(), lr=lr)
+    x = x_train.detach().reshape(x_train.shape[0], -1).float()
+    for _ in range(int(n_epochs)):
+        opt.zero_grad()
+        loss = -flow.log_prob(x.reshape(x.shape[0], *flow.event_shape)).mean()
+        if not torch.isfinite(loss):
+            raise ValueError('flow training diverged (non-finite loss)')
+        loss.backward()
+        opt.step()
+    return flow
 
 
 def perturb_(flow: Flow, seed: int, scale: float = 0.3, target_std: float = None):

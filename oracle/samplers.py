@@ -128,6 +128,7 @@ class Trace:
     n_target_gradient_calls: int = 0
     n_accepted_jumps: int = 0
     n_attempted_jumps: int = 0
+    n_refits: int = 0
     moments: Optional[Moments] = None
     last: Optional[torch.Tensor] = None
 
@@ -340,6 +341,89 @@ def imh_sample(x0, target, flow, n_iterations, noise=None, store=True):
             if store:
                 tr.samples.append(x.clone())
             tr.last = x.clone()
+    return tr
+
+
+class TorchHostDraws:
+    """Host-side scalar draws of AdaptiveIMH (imh.py:148,156-160) from torch's global generator."""
+
+    def rand(self):
+        return float(torch.rand(size=()))
+
+    def randint(self, low, high):
+        return int(torch.randint(low=low, high=high, size=()))
+
+
+class ReplayHostDraws:
+    def __init__(self, uniforms, ints):
+        self.uniforms, self.ints = list(uniforms), list(ints)
+
+    def rand(self):
+        return float(self.uniforms.pop(0))
+
+    def randint(self, low, high):
+        k = int(self.ints.pop(0))
+        assert low <= k < high
+        return k
+
+
+def bounded_geom_index(p, max_val, u):
+    """`sample_bounded_geom` (imh.py:39-45) with the uniform passed in."""
+    v = torch.arange(0, max_val + 1)
+    pdf = p * (1 - p) ** (max_val - v) / (1 - (1 - p) ** (max_val + 1))
+    cdf = torch.cumsum(pdf, dim=0)
+    return int(torch.searchsorted(cdf, torch.tensor(u, dtype=cdf.dtype), right=True))
+
+
+def adaptive_imh_sample(x0, target, flow, n_iterations, adaptation_dropoff=0.9999, train_distribution='uniform',
+                        noise=None, host=None, fit_fn=None):
+    """`AdaptiveIMH.sample` (nfmc/algorithms/sampling/nfmc/imh.py:103-181): IMH whose proposal flow is refitted
+    on one stored state per iteration with probability dropoff^i.  log q is recomputed every iteration
+    (the flow moves).  Quirk kept: the 2n target evaluations are booked as gradient calls (:142)."""
+    noise = noise or TorchNoise()
+    host = host or TorchHostDraws()
+    fit_fn = fit_fn or (lambda f, xt: f.fit(xt, n_epochs=1, show_progress=False))
+    n = x0.shape[0]
+    event = x0.shape[1:]
+    x = x0.detach().clone().reshape(n, -1)
+    tr = Trace(moments=Moments.for_event((x.shape[1],)))
+    for it in range(n_iterations):
+        with torch.no_grad():
+            z = noise.normal(n, event, it, philox.TAG_LATENT)
+            x_prime, ld_inv = flow.bijection.inverse(z)                              # :123
+            x_prime = x_prime.reshape(n, -1)
+            f_xp = flow.base_log_prob(z) - ld_inv
+            f_x = flow.log_prob(x.reshape(n, *event))                                # :128
+            log_alpha = (-target(x_prime)) - (-target(x)) + f_x - f_xp              # :125-130
+            log_u = noise.uniform(n, it, philox.TAG_JUMP).log()                      # :131
+            mask = torch.less(log_u, log_alpha)                                      # :132
+            x = x.clone()
+            x[mask] = x_prime[mask]                                                  # :133
+        tr.moments.update(x)                                                         # :139
+        tr.n_target_gradient_calls += 2 * n                                          # :141 (sic)
+        tr.n_accepted += int(mask.sum())
+        tr.n_attempted += n
+        tr.masks.append(mask.clone())
+        tr.log_ratios.append(log_alpha.clone())
+        tr.samples.append(x.clone())                                                 # :145
+        tr.last = x.clone()
+        if host.rand() < adaptation_dropoff ** it:                                   # :147-149
+            n_samples = len(tr.samples)
+            if train_distribution == 'uniform':
+                k = host.randint(0, n_samples)                                       # :156
+            elif train_distribution == 'bounded_geom_approx':
+                k = host.randint(max(0, n_samples - 100), n_samples)                 # :158
+            elif train_distribution == 'bounded_geom':
+                k = bounded_geom_index(0.025, n_samples - 1, host.rand())            # :160
+            else:
+                raise ValueError
+            x_train = tr.samples[k].reshape(n, *event)
+            saved = {kk: v.detach().clone() for kk, v in flow.state_dict().items()}  # :166
+            try:
+                fit_fn(flow, x_train)                                                # :168
+                tr.n_refits += 1
+            except ValueError:
+                flow.load_state_dict(saved)                                          # :170
     return tr
 
 

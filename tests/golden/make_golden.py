@@ -68,8 +68,8 @@ class DrawRecorder:
 
     def __enter__(self):
         self.normals, self.uniforms = [], []
-        self._orig = {k: getattr(torch, k) for k in ('randn', 'randn_like', 'rand', 'rand_like', 'randperm')}
-        self.perms = []
+        self._orig = {k: getattr(torch, k) for k in ('randn', 'randn_like', 'rand', 'rand_like', 'randperm', 'randint')}
+        self.perms, self.ints = [], []
 
         def wrap(name, store):
             fn = self._orig[name]
@@ -86,6 +86,7 @@ class DrawRecorder:
         torch.rand = wrap('rand', self.uniforms)
         torch.rand_like = wrap('rand_like', self.uniforms)
         torch.randperm = wrap('randperm', self.perms)
+        torch.randint = wrap('randint', self.ints)
         return self
 
     def __exit__(self, *exc):
@@ -111,10 +112,20 @@ def out_arrays(out, jump=False):
     return d
 
 
+ONLY = set(sys.argv[1:])   # `python make_golden.py NAME...` rewrites only those fixtures
+
+
 def save(name, rec, **arrays):
+    if ONLY and name not in ONLY:
+        return
     if rec is not None:
+        chain_u = [v for v in rec.uniforms if v.dim() > 0]
+        host_u = [v for v in rec.uniforms if v.dim() == 0]      # scalar host-side draws (AdaptiveIMH)
         arrays['noise/normals'] = np.stack([v.numpy() for v in rec.normals]) if rec.normals else np.zeros((0,), np.float32)
-        arrays['noise/uniforms'] = np.stack([v.numpy() for v in rec.uniforms]) if rec.uniforms else np.zeros((0,), np.float32)
+        arrays['noise/uniforms'] = np.stack([v.numpy() for v in chain_u]) if chain_u else np.zeros((0,), np.float32)
+        if host_u or rec.ints:
+            arrays['noise/host_uniforms'] = np.array([float(v) for v in host_u], dtype=np.float64)
+            arrays['noise/host_ints'] = np.array([int(v) for v in rec.ints], dtype=np.int64)
     np.savez_compressed(os.path.join(OUT, name + '.npz'), **arrays)
     print('wrote', name, {k: getattr(v, 'shape', None) for k, v in arrays.items() if not k.startswith('flow/')})
 
@@ -242,6 +253,21 @@ def main():
         out = s.sample(x0.clone(), show_progress=False)
     save('imh_d7_odd', rec, x0=x0.numpy(), n_iterations=np.int64(T), flow_n_layers=np.int64(3),
          **flow_arrays(flow), **out_arrays(out))
+
+    # ---------------------------------------------------------------- AdaptiveIMH (f2); the flow's `fit` is the
+    # build's own one-step AdamW refit (oracle/flow.py fit_), torchflows' is not available
+    from nfmc.algorithms.sampling.nfmc.imh import AdaptiveIMH
+    for name, dist, d, n, T in [('adaptive_imh_d6', 'uniform', 6, 24, 6), ('adaptive_imh_geom_d5', 'bounded_geom', 5, 16, 5)]:
+        flow = make_flow(d, 26, target_std=0.7)
+        w0 = flow_arrays(flow)
+        torch.manual_seed(27)
+        x0 = torch.randn(n, d)
+        s = AdaptiveIMH((d,), sumsq, IMHKernel((d,), flow=flow),
+                        IMHParameters(n_iterations=T, train_distribution=dist, adaptation_dropoff=0.8))
+        with DrawRecorder() as rec:
+            out = s.sample(x0.clone(), show_progress=False)
+        save(name, rec, x0=x0.numpy(), n_iterations=np.int64(T), adaptation_dropoff=np.float64(0.8),
+             **w0, **{k.replace('flow/', 'flow_final/'): v for k, v in flow_arrays(flow).items()}, **out_arrays(out))
 
     # ---------------------------------------------------------------- NeuTra HMC (a10)
     d, n, T, L = 6, 8, 3, 3

@@ -195,6 +195,42 @@ def test_imh_golden(dev, name, d, nl):
     _check_out(out, fx)
 
 
+@pytest.mark.parametrize('name,dist,d', [('adaptive_imh_d6', 'uniform', 6), ('adaptive_imh_geom_d5', 'bounded_geom', 5)])
+def test_adaptive_imh_golden(dev, name, dist, d):
+    """AdaptiveIMH (imh.py:82-181) vs the reference's own run: chain noise and host draws replayed; the one-epoch
+    refits run on the GPU (AdamW through the differentiable flow), so weights agree to fp32 training noise:
+    tolerance 5e-5 on samples / final weights, counters exact."""
+    from nfmc_amd.samplers import imh
+    from nfmc_amd.potentials import SumOfSquares
+    fx = load_golden(name)
+    flow = _amd_flow(fx, d, 2)
+    s = imh.AdaptiveIMH((d,), SumOfSquares((d,)), imh.IMHKernel((d,), flow=flow),
+                        imh.IMHParameters(n_iterations=int(fx['n_iterations']), train_distribution=dist,
+                                          adaptation_dropoff=float(fx['adaptation_dropoff'])))
+    s.replay = _noise(fx)
+    s.host_draws = (fx['noise/host_uniforms'], fx['noise/host_ints'])
+    out = s.sample(torch.from_numpy(fx['x0']), show_progress=False)
+    np.testing.assert_allclose(out.samples.numpy(), fx['exp/samples'], atol=5e-5, rtol=0)
+    np.testing.assert_allclose(out.mean.numpy(), fx['exp/first_moment'], atol=5e-5, rtol=0)
+    np.testing.assert_allclose(out.second_moment.numpy(), fx['exp/second_moment'], atol=5e-5, rtol=0)
+    st = out.statistics
+    c = fx['exp/counters']
+    assert (st.n_accepted_trajectories, st.n_attempted_trajectories, st.n_target_calls,
+            st.n_target_gradient_calls) == (c[0], c[1], c[3], c[4])
+    assert s.n_refits > 0
+    for k, v in flow.state_dict().items():
+        np.testing.assert_allclose(v.detach().cpu().numpy(), fx['flow_final/' + k], atol=5e-5, rtol=0)
+
+
+def test_adaptive_imh_strategy_string(dev):
+    from nfmc_amd import sample
+    torch.manual_seed(0)
+    out = sample(lambda x: torch.sum(x ** 2, dim=-1), event_shape=(6,), strategy='adaptive_imh', n_chains=64,
+                 n_iterations=12, show_progress=False)
+    assert out.samples.shape == (12, 64, 6) and torch.isfinite(out.samples).all()
+    assert out.statistics.n_attempted_trajectories == 12 * 64
+
+
 def test_imh_golden_python_callable_split_path(dev):
     from nfmc_amd.samplers import imh
     fx = load_golden('imh_d6')

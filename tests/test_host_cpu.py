@@ -316,3 +316,22 @@ def test_training_restatement_matches_oracle_flow_and_learns():
     with torch.no_grad():
         xs, _ = ft.inverse_torch(v.bijection, torch.randn(4000, 3))
     assert abs(float(xs.var(0).mean()) - 0.5) < 0.12
+
+
+def test_adaptive_imh_host_logic():
+    """Strategy routing and the host-side draws of AdaptiveIMH (imh.py:39-45,147-160)."""
+    from nfmc_amd.sample import create_sampler
+    from nfmc_amd.samplers import imh
+    from nfmc_amd.util import get_supported_samplers
+    from oracle import samplers as osamp
+    assert 'adaptive_imh' in get_supported_samplers()
+    s = create_sampler(lambda x: torch.sum(x ** 2, dim=-1), event_shape=(5,), strategy='adaptive_imh', flow='realnvp',
+                       param_kwargs={'n_iterations': 7, 'store_samples': False})
+    assert isinstance(s, imh.AdaptiveIMH) and s.params.n_iterations == 7 and s.params.store_samples is True
+    for u in (0.0, 0.013, 0.4, 0.77, 0.999999):
+        for m in (0, 3, 120):
+            assert imh.bounded_geom_index(0.025, m, u) == osamp.bounded_geom_index(0.025, m, u)
+    h = imh.HostDraws(None, [0.25, 0.5], [3])
+    assert (h.rand(), h.randint(0, 5), h.rand()) == (0.25, 3, 0.5)
+    with pytest.raises(ValueError):
+        imh.IMHParameters(train_distribution='nope')

@@ -85,6 +85,21 @@ def test_imh(name, d, nl):
     _check(tr, fx)
 
 
+@pytest.mark.parametrize('name,dist,d', [('adaptive_imh_d6', 'uniform', 6), ('adaptive_imh_geom_d5', 'bounded_geom', 5)])
+def test_adaptive_imh(name, dist, d):
+    """AdaptiveIMH.sample (imh.py:103-181) incl. the per-iteration one-epoch refits: host draws replayed."""
+    fx = load_golden(name)
+    flow = golden_flow(fx, d)
+    host = osamp.ReplayHostDraws(fx['noise/host_uniforms'], fx['noise/host_ints'])
+    tr = osamp.adaptive_imh_sample(torch.from_numpy(fx['x0']), opot.sum_squares, flow, int(fx['n_iterations']),
+                                   adaptation_dropoff=float(fx['adaptation_dropoff']), train_distribution=dist,
+                                   noise=_noise(fx), host=host)
+    _check(tr, fx)
+    assert tr.n_refits > 0 and not host.uniforms and not host.ints
+    for k, v in flow.state_dict().items():
+        np.testing.assert_allclose(v.numpy(), fx['flow_final/' + k], atol=ATOL, rtol=0)
+
+
 def test_neutra_hmc():
     fx = load_golden('neutra_hmc_d6')
     flow = golden_flow(fx, 6)
