@@ -224,8 +224,9 @@ class MCMCStatistics:
 class MCMCSamples:
     """Kept states `(n_kept, n_chains, *event_shape)`; semantics of base.py:215-271.
 
-    Two ways in: `add(x)` (host-driven, like the reference) and `reserve(...)` + `slot_view(...)`, which
-    hands the kernels a device buffer to write steps into directly.
+    The samplers let the kernels write every step of a launch straight into a device buffer `(k, n, d)` and
+    `add` it once per launch; rows stay on the device (`as_device_tensor`) until `.samples` is read, which is the
+    only device-to-host copy (the reference does one `.cpu()` per step, base.py:257).
     """
 
     def __init__(self, event_shape, store_samples: bool = True, thinning: int = 1, max_samples: int = None):

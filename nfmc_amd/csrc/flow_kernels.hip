@@ -237,7 +237,7 @@ static int check_flow(const NfmcRealNVP* f) {
     if (f->d < 2 && f->n_coupling > 0) return NFMC_ESHAPE;
     if (f->d > 512) return NFMC_ESHAPE;
     if (f->n_hidden > 128) return NFMC_EUNSUPPORTED;
-    if (!(f->min_scale >= 0.f && f->min_scale < 1.f)) return NFMC_EINVAL;
+    if (!(f->min_scale >= 0.f && f->min_scale <= 1.f)) return NFMC_EINVAL;   // 1 = additive coupling (exp(-inf) + 1)
     if (f->n_coupling > 0 && f->layer_stride < nfmc_realnvp_layer_floats(f->d, f->n_hidden, f->n_hidden_layers))
         return NFMC_EINVAL;
     return NFMC_OK;

@@ -18,12 +18,15 @@ import torch
 from .flows import MIN_SCALE, AffineCoupling, ElementwiseAffine, ReversePermutation
 
 
-def _coupling_params(layer: AffineCoupling, x_a):
+def _coupling_params(layer: AffineCoupling, x_a, min_scale=MIN_SCALE):
     h = x_a
     for lin in layer.conditioner[:-1]:
         h = torch.tanh(lin(h))
     h = layer.conditioner[-1](h)
-    alpha = torch.exp(h[:, :layer.d_b] / 2 + math.log(1 - MIN_SCALE)) + MIN_SCALE
+    if min_scale >= 1.0:    # additive coupling (NICE)
+        alpha = torch.ones_like(h[:, :layer.d_b])
+    else:
+        alpha = torch.exp(h[:, :layer.d_b] / 2 + math.log(1 - min_scale)) + min_scale
     return alpha, h[:, layer.d_b:] / 2
 
 
@@ -39,7 +42,7 @@ def forward_torch(bijection, x):
         elif isinstance(layer, ReversePermutation):
             h = h.flip(-1)
         else:
-            alpha, beta = _coupling_params(layer, h[:, :layer.d_a])
+            alpha, beta = _coupling_params(layer, h[:, :layer.d_a], bijection.min_scale)
             h = torch.cat([h[:, :layer.d_a], alpha * h[:, layer.d_a:] + beta], dim=1)
             ld = ld + torch.log(alpha).sum(-1)
     return h, ld
@@ -56,7 +59,7 @@ def inverse_torch(bijection, z):
         elif isinstance(layer, ReversePermutation):
             h = h.flip(-1)
         else:
-            alpha, beta = _coupling_params(layer, h[:, :layer.d_a])
+            alpha, beta = _coupling_params(layer, h[:, :layer.d_a], bijection.min_scale)
             h = torch.cat([h[:, :layer.d_a], (h[:, layer.d_a:] - beta) / alpha], dim=1)
             ld = ld - torch.log(alpha).sum(-1)
     return h, ld

@@ -62,6 +62,8 @@ class AffineCoupling(nn.Module):
 class RealNVP(nn.Module):
     """[ElementwiseAffine] + n_layers x [ReversePermutation, AffineCoupling] + [ElementwiseAffine]."""
 
+    min_scale = MIN_SCALE   # scale = exp(u/2 + log(1 - min_scale)) + min_scale
+
     def __init__(self, event_shape, n_layers: int = 2, conditioner_kwargs: Optional[dict] = None, **kwargs):
         super().__init__()
         if isinstance(event_shape, int):
@@ -145,7 +147,7 @@ class RealNVP(nn.Module):
             ea0, ea1 = self.layers[0], self.layers[-1]
             keep = [weights] + [t.detach().float().contiguous().to(device)
                                 for t in (ea0.log_scale, ea0.shift, ea1.log_scale, ea1.shift)]
-        st = hip.NfmcRealNVP(d, self.n_coupling, H, nhl, MIN_SCALE, 0, hip.ptr(keep[1]), hip.ptr(keep[2]),
+        st = hip.NfmcRealNVP(d, self.n_coupling, H, nhl, float(self.min_scale), 0, hip.ptr(keep[1]), hip.ptr(keep[2]),
                              hip.ptr(keep[3]), hip.ptr(keep[4]), hip.ptr(keep[0]), stride)
         self._pack_cache = (key, (st, keep))
         return self._pack_cache[1]
@@ -175,6 +177,14 @@ class RealNVP(nn.Module):
         hip.check(hip.lib().nfmc_realnvp_inverse_f32(C.byref(st), hip.ptr(zf), n, hip.ptr(x), hip.ptr(ld), None, None,
                                                      hip.stream()), 'nfmc_realnvp_inverse_f32')
         return x.reshape(n, *self.event_shape), ld
+
+
+class NICE(RealNVP):
+    """Additive (volume-preserving) couplings behind the same kernels (nfmc/util.py:13 'nice'): the RealNVP
+    stack with min_scale = 1, for which scale = exp(u/2 + log 0) + 1 = 1 and log-scale = 0 EXACTLY; the
+    scale half of the conditioner output is carried but inert (zero gradient)."""
+
+    min_scale = 1.0
 
 
 class Flow(nn.Module):

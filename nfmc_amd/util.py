@@ -1,13 +1,14 @@
 """Flow-spec strings and the Metropolis log-ratio (nfmc/util.py:189-215, 218-281, 382-392).
 
-Only the `realnvp` family is on this build's path; the reference's other ~59 architecture names live in
-torchflows and raise a clear error here instead of silently mapping to something else.
+The half-split coupling flows `realnvp` and `nice` are on this build's path; the reference's other ~58
+architecture names live in torchflows and raise a clear error here instead of silently mapping to something else.
 """
 import json
 from typing import Dict, List
 
 FLOW_NAMES: Dict[str, List[str]] = {
     'realnvp': ['realnvp', 'real_nvp', 'rnvp'],  # nfmc/util.py:6
+    'nice': ['nice'],                            # nfmc/util.py:13
 }
 
 
@@ -34,7 +35,7 @@ def parse_flow_string(flow_string: str):
 
 def create_flow_object(flow_string: str, event_shape, **kwargs):
     """nfmc/util.py:218-281,379 for the realnvp branch."""
-    from .flows import Flow, RealNVP
+    from .flows import NICE, Flow, RealNVP
     data = parse_flow_string(flow_string)
     name = data['name']
     kwargs.update(data['kwargs'])
@@ -42,7 +43,8 @@ def create_flow_object(flow_string: str, event_shape, **kwargs):
         raise ValueError
     if not is_flow_supported(name):
         raise ValueError(f"flow '{name}' is outside this build's path (supported: {get_supported_normalizing_flows()})")
-    return Flow(RealNVP(event_shape, **kwargs))
+    cls = NICE if name in FLOW_NAMES['nice'] else RealNVP
+    return Flow(cls(event_shape, **kwargs))
 
 
 def metropolis_acceptance_log_ratio(log_prob_target_curr, log_prob_target_prime, log_prob_proposal_curr,

@@ -62,6 +62,8 @@ class ReversePermutation(nn.Module):
 
 
 class AffineCoupling(nn.Module):
+    additive = False   # NICE: scale fixed to 1, the scale half of the conditioner output is inert
+
     def __init__(self, d, n_hidden=None, n_layers=2):
         super().__init__()
         self.d_a = d // 2
@@ -76,7 +78,10 @@ class AffineCoupling(nn.Module):
             h = torch.tanh(lin(h))
         h = self.conditioner[-1](h)
         u_alpha, u_beta = h[:, :self.d_b], h[:, self.d_b:]
-        alpha = torch.exp(u_alpha / 2 + math.log(1 - MIN_SCALE)) + MIN_SCALE
+        if self.additive:
+            alpha = torch.ones_like(u_alpha)
+        else:
+            alpha = torch.exp(u_alpha / 2 + math.log(1 - MIN_SCALE)) + MIN_SCALE
         return alpha, u_beta / 2
 
     def forward(self, x):
@@ -122,6 +127,17 @@ class RealNVP(nn.Module):
             h, ld = layer.inverse(h)
             logdet = logdet + ld
         return h.reshape(z.shape), logdet
+
+
+class NICE(RealNVP):
+    """Additive couplings (nfmc/util.py:13 'nice'): the same stack, every coupling scale = 1, logdet of the
+    couplings = 0.  Build-defined like RealNVP above (torchflows absent)."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        for m in self.layers:
+            if isinstance(m, AffineCoupling):
+                m.additive = True
 
 
 class Flow(nn.Module):

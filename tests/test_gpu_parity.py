@@ -254,6 +254,68 @@ FLOW_CASES = [(6, 2, None, 2), (7, 3, 5, 3), (25, 2, None, 2), (64, 2, None, 2),
               (100, 4, 100, 5), (64, 2, 64, 1), (128, 2, 128, 2), (30, 2, 40, 3)]   # wide conditioners
 
 
+@pytest.mark.parametrize('d,nl,nh,cl', [(6, 2, None, 2), (64, 3, 16, 2), (64, 2, 64, 2), (33, 4, 7, 1)])
+def test_nice_flow_matches_oracle(dev, d, nl, nh, cl):
+    """'nice' (nfmc/util.py:13): additive couplings through the same kernels (min_scale = 1): forward / inverse /
+    log_prob vs the oracle, exact volume preservation of the couplings, round trip, sampling and NeuTra gradient."""
+    from nfmc_amd.flows import NICE, Flow
+    from nfmc_amd.util import create_flow_object
+    from oracle import flow as oflow
+    ck = {'n_layers': cl}
+    if nh is not None:
+        ck['n_hidden'] = nh
+    torch.manual_seed(d + nl)
+    of = oflow.perturb_(oflow.Flow(oflow.NICE((d,), n_layers=nl, conditioner_kwargs=ck)), 9, 0.4, 0.8)
+    f = create_flow_object('nice', (d,), n_layers=nl, conditioner_kwargs=ck)
+    assert isinstance(f.bijection, NICE)
+    f.load_state_dict(of.state_dict())
+    x = torch.randn(300, d) * 0.8
+    with torch.no_grad():
+        z0, ld0 = of.bijection.forward(x)
+        lp0 = of.log_prob(x)
+    z, ld = f.bijection.forward(x)
+    np.testing.assert_allclose(z.cpu().numpy(), z0.numpy(), atol=2e-5, rtol=0)
+    np.testing.assert_allclose(ld.cpu().numpy(), ld0.numpy(), atol=2e-5, rtol=0)
+    np.testing.assert_allclose(f.log_prob(x).cpu().numpy(), lp0.numpy(), atol=1e-4, rtol=1e-5)
+    # couplings preserve volume exactly: logdet is the two elementwise layers' constant
+    const = float((of.bijection.layers[0].log_scale.sum() + of.bijection.layers[-1].log_scale.sum()).detach())
+    assert float((ld.cpu() - const).abs().max()) < 1e-5 * max(1.0, abs(const))
+    assert float((ld.cpu() - ld.cpu()[0]).abs().max()) == 0.0   # bit-identical for every row
+    xb, ldi = f.bijection.inverse(z)
+    np.testing.assert_allclose(xb.cpu().numpy(), x.numpy(), atol=2e-5, rtol=0)
+    np.testing.assert_allclose(ldi.cpu().numpy(), -ld.cpu().numpy(), atol=1e-5, rtol=0)
+    xs, lq = f.sample(500, return_log_prob=True)
+    np.testing.assert_allclose(lq.cpu().numpy(), f.log_prob(xs).cpu().numpy(), atol=2e-4, rtol=1e-5)
+
+
+def test_nice_neutra_and_jump_strategies(dev):
+    """The adjusted-target gradient through additive couplings vs autograd of the oracle, and a jump run."""
+    from nfmc_amd import sample
+    from nfmc_amd.flows import NICE, Flow
+    from nfmc_amd.potentials import SumOfSquares
+    from nfmc_amd.samplers.neutra import NeuTraHMC, NeuTraKernel, NeuTraParameters
+    from oracle import flow as oflow
+    from oracle import potentials as opot
+    from oracle import samplers as osamp
+    d = 8
+    torch.manual_seed(5)
+    of = oflow.perturb_(oflow.Flow(oflow.NICE((d,))), 3, 0.4, 0.8)
+    f = Flow(NICE((d,)))
+    f.load_state_dict(of.state_dict())
+    s = NeuTraHMC((d,), SumOfSquares((d,)), kernel=NeuTraKernel((d,), flow=f), params=NeuTraParameters(n_iterations=2))
+    z = torch.randn(64, d)
+    u, g = s._potential_grad(z.to(dev))
+    zz = z.clone().requires_grad_(True)
+    u0 = osamp.neutra_adjusted_target(of, opot.sum_squares, (d,))(zz)
+    g0, = torch.autograd.grad(u0.sum(), zz)
+    np.testing.assert_allclose(u.cpu().numpy(), u0.detach().numpy(), atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(g.cpu().numpy(), g0.numpy(), atol=5e-5, rtol=1e-4)
+    torch.manual_seed(0)
+    out = sample(lambda x: torch.sum(x ** 2, dim=-1), event_shape=(d,), strategy='jump_mala', flow='nice', n_chains=256,
+                 n_iterations=5, show_progress=False, inner_param_kwargs={'n_iterations': 10})
+    assert torch.isfinite(out.samples).all() and out.statistics.n_attempted_jumps == 5 * 256
+
+
 @pytest.mark.parametrize('d,nl,nh,cl', FLOW_CASES)
 def test_flow_matches_oracle_and_known_answers(dev, d, nl, nh, cl):
     from nfmc_amd.flows import Flow, RealNVP

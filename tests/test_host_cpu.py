@@ -335,3 +335,28 @@ def test_adaptive_imh_host_logic():
     assert (h.rand(), h.randint(0, 5), h.rand()) == (0.25, 3, 0.5)
     with pytest.raises(ValueError):
         imh.IMHParameters(train_distribution='nope')
+
+
+def test_nice_flow_string_and_training_restatement():
+    """'nice' (nfmc/util.py:13): additive couplings; differentiable restatement equals the oracle's NICE."""
+    from nfmc_amd.flows import NICE
+    from nfmc_amd.util import create_flow_object, get_supported_normalizing_flows, is_flow_supported
+    from nfmc_amd import flow_training as ft
+    from oracle import flow as oflow
+    assert is_flow_supported('nice') and 'nice' in get_supported_normalizing_flows()
+    f = create_flow_object('nice%{"n_layers": 3}', (6,))
+    assert isinstance(f.bijection, NICE) and f.bijection.min_scale == 1.0 and len(f.bijection.layers) == 2 + 2 * 3
+    torch.manual_seed(0)
+    of = oflow.perturb_(oflow.Flow(oflow.NICE((6,), n_layers=3)), 3, 0.4)
+    f.load_state_dict(of.state_dict())
+    x = torch.randn(30, 6)
+    with torch.no_grad():
+        z, ld = ft.forward_torch(f.bijection, x)
+        zo, ldo = of.bijection.forward(x)
+        xi, ldi = ft.inverse_torch(f.bijection, z)
+    np.testing.assert_allclose(z.numpy(), zo.numpy(), atol=1e-6)
+    np.testing.assert_allclose(ld.numpy(), ldo.numpy(), atol=1e-6)
+    np.testing.assert_allclose(xi.numpy(), x.numpy(), atol=1e-5)
+    np.testing.assert_allclose(ldi.numpy(), -ld.numpy(), atol=1e-6)
+    const = float(of.bijection.layers[0].log_scale.sum() + of.bijection.layers[-1].log_scale.sum())
+    assert float((ldo - const).abs().max()) < 1e-6
