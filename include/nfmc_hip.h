@@ -77,9 +77,23 @@ typedef struct {
     unsigned long long* counters; /* (NFMC_CNT_WORDS,) */
     double* scratch;              /* per-workgroup partials, >= nfmc_stats_scratch_bytes(d) bytes */
     int64_t scratch_bytes;
+    int32_t defer;                /* 0: every call folds its partials into sum_x / sum_x2 / counters before it
+                                     returns control of the stream (one extra small kernel per call).
+                                     1: the call only ADDS its per-workgroup partials to `scratch`, which the caller
+                                     zeroed once; nfmc_stats_fold_f32 folds them later (one fold per sample() instead
+                                     of one per launch).  Supported by K1, K2, the flow-MH kernels and K7; the NeuTra
+                                     entry points return NFMC_EUNSUPPORTED. */
+    int32_t tail_slot;            /* defer = 1 only: 0 = accepted / non-finite counts are MCMC counts, 2 = this call
+                                     is a jump (they go to the jump counters at fold time) */
 } NfmcStats;
 
 int64_t nfmc_stats_scratch_bytes(int32_t d);
+
+/* Fold the deferred partials in stats->scratch into sum_x, sum_x2 and counters (+= ; ATTEMPTED += attempted), the
+ * jump slots into jump_counters (may be NULL; ATTEMPTED += jump_attempted), and zero the scratch again.  The
+ * fold order is fixed (run-to-run bitwise equal).  d = flattened event size the partials were produced with. */
+int nfmc_stats_fold_f32(const NfmcStats* stats, int32_t d, uint64_t attempted, unsigned long long* jump_counters,
+                        uint64_t jump_attempted, nfmc_stream_t stream);
 
 /* ---- RealNVP (the build's spec: DESIGN.md "RealNVP spec"; stands in for torchflows.RealNVP,
  * call sites nfmc/util.py:280-281). */

@@ -87,6 +87,16 @@ __device__ __forceinline__ float dpp_add(float v) {
     return v + __int_as_float(moved);
 }
 
+// Per-lane select with the condition in an SGPR pair (mask = __ballot(cond)).  Measured on gfx950
+// (tools/ubench.hip, profiles/): the VOP2 form the compiler shrinks `c ? a : b` to, v_cndmask_b32_e32 with the
+// implicit vcc, issues at 6.6x a v_fma (~22 cycles per wave instruction); the VOP3 form is 1.3x.  Hot loops
+// that select a whole register row on one condition (the Metropolis update) use this.
+__device__ __forceinline__ float select_f32(uint64_t mask, float if_true, float if_false) {
+    float r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_false), "v"(if_true), "s"(mask));
+    return r;
+}
+
 template <int LPC>
 __device__ __forceinline__ float group_allreduce(float v) {
     if constexpr (LPC >= 2) v = dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]  : lane ^ 1
@@ -245,8 +255,11 @@ __device__ __forceinline__ void store_row(float* __restrict__ base, int64_t row,
 // kernel folds the slab into the accumulators in a fixed order (no atomics: run-to-run bitwise equal).
 template <int CPL, int LPC>
 __device__ __forceinline__ void block_stats_flush(const float (&sx)[CPL], const float (&sxx)[CPL], uint32_t accepted,
-                                                  uint32_t nonfinite, double* __restrict__ scratch,
+                                                  uint32_t nonfinite, const NfmcStats& st,
                                                   uint32_t jump_accepted = 0, uint32_t jump_nonfinite = 0) {
+    double* __restrict__ scratch = st.scratch;
+    const bool defer = st.defer != 0;
+    const int slot = defer ? st.tail_slot : 0;   // deferred jumps book their counts in the jump slots
     constexpr int DP = CPL * LPC;
     __shared__ double red[kWavesPerBlock][2 * DP + kStatTail];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -261,10 +274,10 @@ __device__ __forceinline__ void block_stats_flush(const float (&sx)[CPL], const 
         }
     }
     if (lane == 0) {
-        red[wave][2 * DP + 0] = (double)accepted;
-        red[wave][2 * DP + 1] = (double)nonfinite;
-        red[wave][2 * DP + 2] = (double)jump_accepted;
-        red[wave][2 * DP + 3] = (double)jump_nonfinite;
+        red[wave][2 * DP + 0] = slot == 0 ? (double)accepted : 0.0;
+        red[wave][2 * DP + 1] = slot == 0 ? (double)nonfinite : 0.0;
+        red[wave][2 * DP + 2] = slot == 0 ? (double)jump_accepted : (double)accepted;
+        red[wave][2 * DP + 3] = slot == 0 ? (double)jump_nonfinite : (double)nonfinite;
     }
     __syncthreads();
     double* out = scratch + (size_t)blockIdx.x * (2 * DP + kStatTail);
@@ -272,7 +285,7 @@ __device__ __forceinline__ void block_stats_flush(const float (&sx)[CPL], const 
         double s = 0.0;
 #pragma unroll
         for (int w = 0; w < kWavesPerBlock; ++w) s += red[w][t];
-        out[t] = s;
+        out[t] = defer ? out[t] + s : s;   // one owner thread per (workgroup, column): no race, fixed order
     }
 }
 
@@ -280,7 +293,15 @@ __device__ __forceinline__ void block_stats_flush(const float (&sx)[CPL], const 
 // 32 columns x 8 row-slices (loads coalesced across columns, 8 independent chains per column), and the 8
 // partials of a column are added in slice order, so the result does not depend on timing.
 constexpr int kFinishCols = 32, kFinishSlices = 32, kFinishBlock = kFinishCols * kFinishSlices;
-static __global__ void __launch_bounds__(kFinishBlock) stats_finish_kernel(const double* __restrict__ scratch,
+template <bool ZERO>
+static __device__ __forceinline__ double take(double* p) {
+    const double v = *p;
+    if (ZERO) *p = 0.0;
+    return v;
+}
+
+template <bool ZERO = false>
+static __global__ void __launch_bounds__(kFinishBlock) stats_finish_kernel(double* __restrict__ scratch,
                                                                            int nblocks, int dp, int d, NfmcStats st,
                                                                            unsigned long long attempted,
                                                                            unsigned long long* jump_counters = nullptr,
@@ -293,12 +314,12 @@ static __global__ void __launch_bounds__(kFinishBlock) stats_finish_kernel(const
     if (t < width) {
         int b = slice;
         for (; b + 3 * kFinishSlices < nblocks; b += 4 * kFinishSlices) {
-            p0 += scratch[(size_t)b * width + t];
-            p1 += scratch[(size_t)(b + kFinishSlices) * width + t];
-            p2 += scratch[(size_t)(b + 2 * kFinishSlices) * width + t];
-            p3 += scratch[(size_t)(b + 3 * kFinishSlices) * width + t];
+            p0 += take<ZERO>(scratch + (size_t)b * width + t);
+            p1 += take<ZERO>(scratch + (size_t)(b + kFinishSlices) * width + t);
+            p2 += take<ZERO>(scratch + (size_t)(b + 2 * kFinishSlices) * width + t);
+            p3 += take<ZERO>(scratch + (size_t)(b + 3 * kFinishSlices) * width + t);
         }
-        for (; b < nblocks; b += kFinishSlices) p0 += scratch[(size_t)b * width + t];
+        for (; b < nblocks; b += kFinishSlices) p0 += take<ZERO>(scratch + (size_t)b * width + t);
     }
     part[slice][col] = (p0 + p1) + (p2 + p3);
     __syncthreads();
@@ -327,6 +348,17 @@ static __global__ void __launch_bounds__(kFinishBlock) stats_finish_kernel(const
 inline int stats_finish_grid(int dp) { return (2 * dp + kStatTail + kFinishCols - 1) / kFinishCols; }
 
 inline int64_t stats_scratch_doubles(int dp) { return (int64_t)kMaxGrid * (2 * dp + kStatTail); }
+
+inline int padded_d(int d);
+
+// Deferred statistics (NfmcStats.defer): every kernel of a run must lay its slabs out with the same width,
+// 2 * padded_d(d) + kStatTail, and the scratch must hold kMaxGrid of them (nfmc_stats_fold_f32 reads them all).
+inline int check_defer(const NfmcStats& s, int dp, int d) {
+    if (!s.sum_x || !s.defer) return 0;
+    if (dp != padded_d(d) || (s.tail_slot != 0 && s.tail_slot != 2)) return -1;
+    if (s.scratch_bytes < stats_scratch_doubles(dp) * (int64_t)sizeof(double)) return -1;
+    return 0;
+}
 
 inline int padded_d(int d) {
     int p = 4;

@@ -90,14 +90,13 @@ __global__ void __launch_bounds__(kBlock) flow_mh_b_kernel(NfmcFlowMhArgs a, int
                 n_bad += (uint32_t)__popcll(__ballot(active && !(fabsf(lr) <= 3.0e38f)) & leaders);
             }
             accept = accept && active;
-            n_acc += (uint32_t)__popcll(__ballot(accept) & leaders);
-            if (accept) {
-                f_x = f_xp;
-                u_x = u_xp;
-            }
+            const uint64_t am = __ballot(accept);
+            n_acc += (uint32_t)__popcll(am & leaders);
+            f_x = select_f32(am, f_xp, f_x);
+            u_x = select_f32(am, u_xp, u_x);
 #pragma unroll
             for (int i = 0; i < CPL; ++i) {
-                x[i] = accept ? xp[i] : x[i];                                 // jump.py:231 / imh.py:232-233
+                x[i] = select_f32(am, xp[i], x[i]);                                // jump.py:231 / imh.py:232-233
                 sx[i] += x[i];
                 sxx[i] = fmaf(x[i], x[i], sxx[i]);
             }
@@ -110,7 +109,7 @@ __global__ void __launch_bounds__(kBlock) flow_mh_b_kernel(NfmcFlowMhArgs a, int
         store_row<CPL, LPC, FAST>(a.x, row, d, g, active, x);
         if (g == 0 && active) a.logq[row] = f_x;
     }
-    if (a.stats.sum_x) block_stats_flush<CPL, LPC>(sx, sxx, n_acc, n_bad, a.stats.scratch);
+    if (a.stats.sum_x) block_stats_flush<CPL, LPC>(sx, sxx, n_acc, n_bad, a.stats);
 }
 
 struct BCfg {
@@ -172,6 +171,7 @@ int flow_mh_b_launch(const NfmcFlowMhArgs& a, hipStream_t st, int* grid_out, int
     const int grid = (int)(tiles < gcap ? tiles : gcap);
     if (a.stats.sum_x && a.stats.scratch_bytes < (int64_t)grid * (2 * dp + kStatTail) * (int64_t)sizeof(double))
         return NFMC_ESCRATCH;
+    if (check_defer(a.stats, dp, d)) return NFMC_EINVAL;
     int rc = NFMC_EUNSUPPORTED;
 #define M(CPL, LPC)                                                                      \
     if (c.cpl == CPL && c.lpc == LPC)                                                    \

@@ -212,19 +212,22 @@ __global__ void __launch_bounds__(kFlowBlock) flow_mh_kernel(NfmcFlowMhArgs a, i
             n_bad += __shfl_xor(n_bad, m, kWave);
         }
         double* out = a.stats.scratch + (size_t)blockIdx.x * (2 * dp + kStatTail);
-        for (int c = lane; c < 2 * dp + kStatTail; c += kWave) out[c] = 0.0;
+        const bool defer = a.stats.defer != 0;   // deferred: add to the caller-zeroed slab (nfmc_stats_fold_f32)
+        const int slot = defer ? a.stats.tail_slot : 0;
+        if (!defer)
+            for (int c = lane; c < 2 * dp + kStatTail; c += kWave) out[c] = 0.0;
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < kMaxSlots; ++k) {
             const int c = lane + 64 * k;
             if (c < d) {
-                out[c] = sx[k];
-                out[dp + c] = sxx[k];
+                out[c] = defer ? out[c] + sx[k] : sx[k];
+                out[dp + c] = defer ? out[dp + c] + sxx[k] : sxx[k];
             }
         }
         if (lane == 0) {
-            out[2 * dp] = (double)n_acc;
-            out[2 * dp + 1] = (double)n_bad;
+            out[2 * dp + slot] = defer ? out[2 * dp + slot] + (double)n_acc : (double)n_acc;
+            out[2 * dp + slot + 1] = defer ? out[2 * dp + slot + 1] + (double)n_bad : (double)n_bad;
         }
     }
 }
@@ -346,6 +349,7 @@ extern "C" int nfmc_flow_mh_steps_f32(const NfmcFlowMhArgs* args, nfmc_stream_t 
         grid = (int)(tiles < kMaxGrid ? tiles : kMaxGrid);
         if (a.stats.sum_x && a.stats.scratch_bytes < (int64_t)grid * (2 * dp + kStatTail) * (int64_t)sizeof(double))
             return NFMC_ESCRATCH;
+        if (check_defer(a.stats, dp, d)) return NFMC_EINVAL;
         const size_t lds = (size_t)2 * 64 * tile_stride(d) * sizeof(float) + hbuf_bytes(a.flow.n_hidden);
         NFMC_HP_DISPATCH(nfmc_realnvp_padded_hidden(a.flow.n_hidden), {
             if ((rc = set_lds(flow_mh_kernel<HP>, lds))) return rc;
@@ -355,8 +359,8 @@ extern "C" int nfmc_flow_mh_steps_f32(const NfmcFlowMhArgs* args, nfmc_stream_t 
         return rc;
     }
     NFMC_HIP_CHECK_LAUNCH();
-    if (a.stats.sum_x) {
-        hipLaunchKernelGGL(stats_finish_kernel, dim3(stats_finish_grid(dp)), dim3(kFinishBlock), 0, st, a.stats.scratch, grid, dp, d, a.stats,
+    if (a.stats.sum_x && !a.stats.defer) {
+        hipLaunchKernelGGL(stats_finish_kernel<false>, dim3(stats_finish_grid(dp)), dim3(kFinishBlock), 0, st, a.stats.scratch, grid, dp, d, a.stats,
                            (unsigned long long)a.n * (unsigned long long)a.n_steps);
         NFMC_HIP_CHECK_LAUNCH();
     }

@@ -86,9 +86,10 @@ __global__ void __launch_bounds__(kBlock) select_kernel(NfmcSelectArgs a, int64_
         float x[CPL], xp[CPL];
         load_row<CPL, LPC, false>(a.x, row, d, g, active, x);
         load_row<CPL, LPC, false>(a.x_prime, row, d, g, active, xp);
+        const uint64_t am = __ballot(accept);
 #pragma unroll
         for (int i = 0; i < CPL; ++i) {
-            x[i] = accept ? xp[i] : x[i];
+            x[i] = select_f32(am, xp[i], x[i]);
             sx[i] += x[i];
             sxx[i] = fmaf(x[i], x[i], sxx[i]);
         }
@@ -106,7 +107,7 @@ __global__ void __launch_bounds__(kBlock) select_kernel(NfmcSelectArgs a, int64_
         n_acc += __shfl_xor(n_acc, m, kWave);
         n_bad += __shfl_xor(n_bad, m, kWave);
     }
-    if (a.stats.sum_x) block_stats_flush<CPL, LPC>(sx, sxx, n_acc, n_bad, a.stats.scratch);
+    if (a.stats.sum_x) block_stats_flush<CPL, LPC>(sx, sxx, n_acc, n_bad, a.stats);
 }
 
 // ---- Langevin proposal / log-ratio from external U, grad U ------------------------------------------
@@ -201,10 +202,25 @@ extern "C" int nfmc_moments_update_f32(const float* x, int64_t rows, int32_t d, 
     int grid = (int)(rows < 1024 ? (rows + 3) / 4 : 256);
     if (grid < 1) grid = 1;
     if (stats->scratch_bytes < (int64_t)grid * (2 * dp + kStatTail) * (int64_t)sizeof(double)) return NFMC_ESCRATCH;
+    if (stats->defer) return NFMC_EUNSUPPORTED;   // K7 alone always folds at once
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(moments_kernel, dim3(grid), dim3(kBlock), 0, st, x, rows, (int)d, dp, stats->scratch);
     NFMC_HIP_CHECK_LAUNCH();
-    hipLaunchKernelGGL(stats_finish_kernel, dim3(stats_finish_grid(dp)), dim3(kFinishBlock), 0, st, stats->scratch, grid, dp, (int)d, *stats, 0ull);
+    hipLaunchKernelGGL(stats_finish_kernel<false>, dim3(stats_finish_grid(dp)), dim3(kFinishBlock), 0, st, stats->scratch, grid, dp, (int)d, *stats, 0ull);
+    NFMC_HIP_CHECK_LAUNCH();
+    return NFMC_OK;
+}
+
+extern "C" int nfmc_stats_fold_f32(const NfmcStats* stats, int32_t d, uint64_t attempted,
+                                   unsigned long long* jump_counters, uint64_t jump_attempted, nfmc_stream_t stream) {
+    if (!stats || !stats->sum_x || !stats->sum_x2 || !stats->counters || !stats->scratch) return NFMC_EINVAL;
+    if (d <= 0) return NFMC_EINVAL;
+    if (d > 1024) return NFMC_ESHAPE;
+    const int dp = padded_d(d);
+    if (stats->scratch_bytes < stats_scratch_doubles(dp) * (int64_t)sizeof(double)) return NFMC_ESCRATCH;
+    hipLaunchKernelGGL(stats_finish_kernel<true>, dim3(stats_finish_grid(dp)), dim3(kFinishBlock), 0, (hipStream_t)stream,
+                       stats->scratch, kMaxGrid, dp, (int)d, *stats, (unsigned long long)attempted, jump_counters,
+                       (unsigned long long)jump_attempted);
     NFMC_HIP_CHECK_LAUNCH();
     return NFMC_OK;
 }
@@ -231,6 +247,7 @@ extern "C" int nfmc_mh_accept_select_f32(const NfmcSelectArgs* args, nfmc_stream
     const int grid = (int)(tiles < kMaxGrid ? tiles : kMaxGrid);
     if (a.stats.sum_x && a.stats.scratch_bytes < (int64_t)grid * (2 * dp + kStatTail) * (int64_t)sizeof(double))
         return NFMC_ESCRATCH;
+    if (check_defer(a.stats, dp, a.d)) return NFMC_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     if (cpl == 4) {
         switch (lpc) {
@@ -248,8 +265,8 @@ extern "C" int nfmc_mh_accept_select_f32(const NfmcSelectArgs* args, nfmc_stream
         launch_select<16, 64>(a, tiles, grid, st);
     }
     NFMC_HIP_CHECK_LAUNCH();
-    if (a.stats.sum_x) {
-        hipLaunchKernelGGL(stats_finish_kernel, dim3(stats_finish_grid(dp)), dim3(kFinishBlock), 0, st, a.stats.scratch, grid, dp, a.d, a.stats,
+    if (a.stats.sum_x && !a.stats.defer) {
+        hipLaunchKernelGGL(stats_finish_kernel<false>, dim3(stats_finish_grid(dp)), dim3(kFinishBlock), 0, st, a.stats.scratch, grid, dp, a.d, a.stats,
                            (unsigned long long)a.n);
         NFMC_HIP_CHECK_LAUNCH();
     }

@@ -432,6 +432,7 @@ extern "C" int nfmc_neutra_potential_grad_f32(const NfmcRealNVP* flow, const Nfm
 extern "C" int nfmc_neutra_hmc_steps_f32(const NfmcNeutraHmcArgs* args, nfmc_stream_t stream) {
     if (!args) return NFMC_EINVAL;
     NfmcNeutraHmcArgs a = *args;
+    if (a.stats.sum_x && a.stats.defer) return NFMC_EUNSUPPORTED;   // NeuTra folds its statistics per call
     if (a.flow.n_hidden > 32) {
         if (!a.z || a.n <= 0 || a.n_steps <= 0 || a.n_leapfrog <= 0 || !(a.step_size > 0.f)) return NFMC_EINVAL;
         if (a.n_steps > NFMC_MAX_STEPS_PER_CALL) return NFMC_ESHAPE;
@@ -461,7 +462,7 @@ extern "C" int nfmc_neutra_hmc_steps_f32(const NfmcNeutraHmcArgs* args, nfmc_str
     })
     NFMC_HIP_CHECK_LAUNCH();
     if (a.stats.sum_x) {
-        hipLaunchKernelGGL(stats_finish_kernel, dim3(stats_finish_grid(dp)), dim3(kFinishBlock), 0, st, a.stats.scratch,
+        hipLaunchKernelGGL(stats_finish_kernel<false>, dim3(stats_finish_grid(dp)), dim3(kFinishBlock), 0, st, a.stats.scratch,
                            grid, dp, d, a.stats, (unsigned long long)a.n * (unsigned long long)a.n_steps);
         NFMC_HIP_CHECK_LAUNCH();
     }

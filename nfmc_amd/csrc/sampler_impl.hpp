@@ -165,8 +165,9 @@ __device__ __forceinline__ bool jump_once(float (&x)[CPL], const FlowB<CPL, LPC,
         bad = active && !(fabsf(lr) <= 3.0e38f);
     }
     accept = accept && active;
+    const uint64_t am = __ballot(accept);
 #pragma unroll
-    for (int i = 0; i < CPL; ++i) x[i] = accept ? xp[i] : x[i];                          // jump.py:231
+    for (int i = 0; i < CPL; ++i) x[i] = select_f32(am, xp[i], x[i]);                    // jump.py:231
     lr_out = lr;
     return accept;
 }
@@ -255,10 +256,11 @@ __global__ void __launch_bounds__(kBlock, NFMC_WPE) mala_kernel(NfmcMalaArgs a, 
                 n_bad += (uint32_t)__popcll(__ballot(active && !(fabsf(lr) <= 3.0e38f)) & leaders);
             }
             accept = accept && active;
-            n_acc += (uint32_t)__popcll(__ballot(accept) & leaders);
+            const uint64_t am = __ballot(accept);
+            n_acc += (uint32_t)__popcll(am & leaders);
 #pragma unroll
             for (int i = 0; i < CPL; ++i) {
-                x[i] = accept ? xp[i] : x[i];  // mcmc/base.py:77
+                x[i] = select_f32(am, xp[i], x[i]);  // mcmc/base.py:77
                 sx[i] += x[i];
                 sxx[i] = fmaf(x[i], x[i], sxx[i]);
             }
@@ -289,7 +291,7 @@ __global__ void __launch_bounds__(kBlock, NFMC_WPE) mala_kernel(NfmcMalaArgs a, 
         }
         store_row<CPL, LPC, FAST>(a.x, row, d, g, active, x);
     }
-    if (a.stats.sum_x) block_stats_flush<CPL, LPC>(sx, sxx, n_acc, n_bad, a.stats.scratch, j_acc, j_bad);
+    if (a.stats.sum_x) block_stats_flush<CPL, LPC>(sx, sxx, n_acc, n_bad, a.stats, j_acc, j_bad);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -368,10 +370,11 @@ __global__ void __launch_bounds__(kBlock, NFMC_WPE) hmc_kernel(NfmcHmcArgs a, in
                 n_bad += (uint32_t)__popcll(__ballot(active && !(fabsf(lr) <= 3.0e38f)) & leaders);
             }
             accept = accept && active;
-            n_acc += (uint32_t)__popcll(__ballot(accept) & leaders);
+            const uint64_t am = __ballot(accept);
+            n_acc += (uint32_t)__popcll(am & leaders);
 #pragma unroll
             for (int i = 0; i < CPL; ++i) {
-                x[i] = accept ? q[i] : x[i];
+                x[i] = select_f32(am, q[i], x[i]);
                 sx[i] += x[i];
                 sxx[i] = fmaf(x[i], x[i], sxx[i]);
             }
@@ -402,7 +405,7 @@ __global__ void __launch_bounds__(kBlock, NFMC_WPE) hmc_kernel(NfmcHmcArgs a, in
         }
         store_row<CPL, LPC, FAST>(a.x, row, d, g, active, x);
     }
-    if (a.stats.sum_x) block_stats_flush<CPL, LPC>(sx, sxx, n_acc, n_bad, a.stats.scratch, j_acc, j_bad);
+    if (a.stats.sum_x) block_stats_flush<CPL, LPC>(sx, sxx, n_acc, n_bad, a.stats, j_acc, j_bad);
 }
 
 

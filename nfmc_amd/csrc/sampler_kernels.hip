@@ -100,6 +100,7 @@ extern "C" int nfmc_mala_steps_f32(const NfmcMalaArgs* args, nfmc_stream_t strea
     const int grid = (int)(tiles < kMaxGrid ? tiles : kMaxGrid);
     if (a.stats.sum_x && a.stats.scratch_bytes < (int64_t)grid * (2 * dp + kStatTail) * (int64_t)sizeof(double))
         return NFMC_ESCRATCH;
+    if (check_defer(a.stats, dp, a.d)) return NFMC_EINVAL;
     const float sqrt2h = (float)sqrt(2.0 * (double)a.step_size);  // math.sqrt(2*step_size), langevin.py:75
     const JumpDev jd = jump_dev(a.jump);
     unsigned long long* jc = a.jump ? a.jump->counters : nullptr;
@@ -109,8 +110,8 @@ extern "C" int nfmc_mala_steps_f32(const NfmcMalaArgs* args, nfmc_stream_t strea
                               : launch_mala_j8(a, jd, c, fast, tiles, grid, sqrt2h, st));
     if (rc) return rc;
     NFMC_HIP_CHECK_LAUNCH();
-    if (a.stats.sum_x) {
-        hipLaunchKernelGGL(stats_finish_kernel, dim3(stats_finish_grid(dp)), dim3(kFinishBlock), 0, st, a.stats.scratch,
+    if (a.stats.sum_x && !a.stats.defer) {
+        hipLaunchKernelGGL(stats_finish_kernel<false>, dim3(stats_finish_grid(dp)), dim3(kFinishBlock), 0, st, a.stats.scratch,
                            grid, dp, a.d, a.stats, (unsigned long long)a.n * (unsigned long long)a.n_steps, jc,
                            (unsigned long long)a.n);
         NFMC_HIP_CHECK_LAUNCH();
@@ -134,6 +135,7 @@ extern "C" int nfmc_hmc_steps_f32(const NfmcHmcArgs* args, nfmc_stream_t stream)
     const int grid = (int)(tiles < kMaxGrid ? tiles : kMaxGrid);
     if (a.stats.sum_x && a.stats.scratch_bytes < (int64_t)grid * (2 * dp + kStatTail) * (int64_t)sizeof(double))
         return NFMC_ESCRATCH;
+    if (check_defer(a.stats, dp, a.d)) return NFMC_EINVAL;
     const JumpDev jd = jump_dev(a.jump);
     unsigned long long* jc = a.jump ? a.jump->counters : nullptr;
     a.jump = nullptr;
@@ -141,8 +143,8 @@ extern "C" int nfmc_hmc_steps_f32(const NfmcHmcArgs* args, nfmc_stream_t stream)
                   : (jhp == 4 ? launch_hmc_j4(a, jd, c, fast, tiles, grid, st) : launch_hmc_j8(a, jd, c, fast, tiles, grid, st));
     if (rc) return rc;
     NFMC_HIP_CHECK_LAUNCH();
-    if (a.stats.sum_x) {
-        hipLaunchKernelGGL(stats_finish_kernel, dim3(stats_finish_grid(dp)), dim3(kFinishBlock), 0, st, a.stats.scratch,
+    if (a.stats.sum_x && !a.stats.defer) {
+        hipLaunchKernelGGL(stats_finish_kernel<false>, dim3(stats_finish_grid(dp)), dim3(kFinishBlock), 0, st, a.stats.scratch,
                            grid, dp, a.d, a.stats, (unsigned long long)a.n * (unsigned long long)a.n_steps, jc,
                            (unsigned long long)a.n);
         NFMC_HIP_CHECK_LAUNCH();

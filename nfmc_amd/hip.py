@@ -34,7 +34,7 @@ class NfmcRng(C.Structure):
 
 class NfmcStats(C.Structure):
     _fields_ = [('sum_x', c_fp), ('sum_x2', c_fp), ('counters', c_fp), ('scratch', c_fp),
-                ('scratch_bytes', C.c_int64)]
+                ('scratch_bytes', C.c_int64), ('defer', C.c_int32), ('tail_slot', C.c_int32)]
 
 
 class NfmcRealNVP(C.Structure):
@@ -111,6 +111,7 @@ SYMBOLS = [
     ('nfmc_langevin_log_ratio_f32', C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, C.c_float, C.c_int64,
                                               C.c_int32, c_fp, c_fp]),
     ('nfmc_moments_update_f32', C.c_int, [c_fp, C.c_int64, C.c_int32, C.POINTER(NfmcStats), c_fp]),
+    ('nfmc_stats_fold_f32', C.c_int, [C.POINTER(NfmcStats), C.c_int32, C.c_uint64, c_fp, C.c_uint64, c_fp]),
     ('nfmc_philox_normals_f32', C.c_int, [C.POINTER(NfmcRng), C.c_int32, C.c_int64, C.c_int32, c_fp, c_fp]),
     ('nfmc_philox_uniforms_f32', C.c_int, [C.POINTER(NfmcRng), C.c_int32, C.c_int64, c_fp, c_fp]),
     ('nfmc_limits', C.c_int, [C.POINTER(NfmcLimits)]),
@@ -179,29 +180,87 @@ def limits():
 
 
 class DeviceStats:
-    """Device-resident accumulators behind NfmcStats (fp64 sums, u64 counters, scratch slab)."""
+    """Device-resident accumulators behind NfmcStats (fp64 sums, u64 counters, scratch slabs).
+
+    Deferred mode (`struct(defer=True, attempted=...)`): the sampling kernels only add their per-workgroup
+    partials to the zeroed scratch and ONE fold (nfmc_stats_fold_f32) runs when the totals are read, instead
+    of one fold kernel per launch.  `sum_x`, `sum_x2`, `counters` and `jump_counters` fold lazily, and a
+    non-deferred `struct()` folds first, so the two modes can be mixed freely within a run.
+    """
 
     def __init__(self, d, device):
         self.d = d
-        self.sum_x = torch.zeros(d, dtype=torch.float64, device=device)
-        self.sum_x2 = torch.zeros(d, dtype=torch.float64, device=device)
-        self.counters = torch.zeros(CNT_WORDS, dtype=torch.int64, device=device)
+        self.device = device
+        self._sum_x = torch.zeros(d, dtype=torch.float64, device=device)
+        self._sum_x2 = torch.zeros(d, dtype=torch.float64, device=device)
+        self._counters = torch.zeros(CNT_WORDS, dtype=torch.int64, device=device)
+        self._jump_counters = torch.zeros(CNT_WORDS, dtype=torch.int64, device=device)
         nbytes = int(lib().nfmc_stats_scratch_bytes(d))
-        self.scratch = torch.empty(nbytes // 8, dtype=torch.float64, device=device)
+        self.scratch = torch.zeros(nbytes // 8, dtype=torch.float64, device=device)
+        self._pending = False
+        self._attempted = 0
+        self._jump_attempted = 0
 
-    def struct(self):
-        return NfmcStats(ptr(self.sum_x, torch.float64), ptr(self.sum_x2, torch.float64),
-                         ptr(self.counters, torch.int64), ptr(self.scratch, torch.float64),
-                         self.scratch.numel() * 8)
+    def _raw(self, defer=0, tail_slot=0, counters=None):
+        return NfmcStats(ptr(self._sum_x, torch.float64), ptr(self._sum_x2, torch.float64),
+                         ptr(self._counters if counters is None else counters, torch.int64),
+                         ptr(self.scratch, torch.float64), self.scratch.numel() * 8, defer, tail_slot)
+
+    def struct(self, defer=False, attempted=0, jump=False, jump_attempted=0):
+        """NfmcStats for one launch.  defer=True: `attempted` = chain-transitions this launch attempts (the fold
+        books them; `jump_attempted` those of a jump fused behind it); jump=True: the launch is a jump (accept
+        counts go to `jump_counters`).  NFMC_STATS_DEFER=0 turns deferral off (A/B measurements)."""
+        if not defer or os.environ.get('NFMC_STATS_DEFER', '1') == '0':
+            self.fold()
+            return self._raw(counters=self._jump_counters if jump else None)
+        self._pending = True
+        if jump:
+            self._jump_attempted += int(attempted)
+        else:
+            self._attempted += int(attempted)
+            self._jump_attempted += int(jump_attempted)
+        return self._raw(1, 2 if jump else 0)
+
+    def fold(self):
+        if not self._pending:
+            return
+        st = self._raw()
+        check(lib().nfmc_stats_fold_f32(C.byref(st), self.d, self._attempted, ptr(self._jump_counters, torch.int64),
+                                        self._jump_attempted, stream()), 'nfmc_stats_fold_f32')
+        self._pending = False
+        self._attempted = 0
+        self._jump_attempted = 0
+
+    @property
+    def sum_x(self):
+        self.fold()
+        return self._sum_x
+
+    @property
+    def sum_x2(self):
+        self.fold()
+        return self._sum_x2
+
+    @property
+    def counters(self):
+        self.fold()
+        return self._counters
+
+    @property
+    def jump_counters(self):
+        self.fold()
+        return self._jump_counters
 
     def zero_(self):
-        self.sum_x.zero_()
-        self.sum_x2.zero_()
-        self.counters.zero_()
+        self.fold()
+        self._sum_x.zero_()
+        self._sum_x2.zero_()
+        self._counters.zero_()
+        self._jump_counters.zero_()
 
 
 def null_stats():
-    return NfmcStats(None, None, None, None, 0)
+    return NfmcStats(None, None, None, None, 0, 0, 0)
 
 
 def make_rng(seed, chain_offset, step0, replay_normals=None, replay_uniforms=None):

@@ -95,7 +95,8 @@ class FixedIMH(AbstractIMH):
             k = min(limit, T - done) if fused else 1
             view = buf[done:done + k] if buf is not None else None
             if fused:
-                launch_flow_mh(run, flow, pot, logq, k, done, done > 0, True, run.stats.struct(), view)
+                launch_flow_mh(run, flow, pot, logq, k, done, done > 0, True,
+                               run.stats.struct(defer=True, attempted=n * k), view)
             else:
                 split_flow_mh(run, flow, self.target, event_shape, done, True, run.stats.struct(), logq=logq)
                 if view is not None:
@@ -199,7 +200,8 @@ class AdaptiveIMH(AbstractIMH):
                 if time.time() - t0 >= time_limit_seconds:
                     break
             if fused:
-                launch_flow_mh(run, flow, pot, logq, 1, i, False, True, run.stats.struct(), buf[i:i + 1])   # :121-134
+                launch_flow_mh(run, flow, pot, logq, 1, i, False, True,
+                               run.stats.struct(defer=True, attempted=n), buf[i:i + 1])              # :121-134
             else:
                 split_flow_mh(run, flow, self.target, event_shape, i, True, run.stats.struct())
                 buf[i].copy_(run.x)

@@ -89,14 +89,14 @@ def flow_fits_jump_tail(flow) -> bool:
     return isinstance(bij, RealNVP) and bij.n_hidden <= 8 and bij.d <= 512 and bij.n_hidden_layers <= 4
 
 
-def make_jump_tail(run: Run, flow, adjusted, jump_counters):
+def make_jump_tail(run: Run, flow, adjusted):
     """NfmcJumpTail for the transition right after an inner launch (+ keep-alive references)."""
     st, keep = flow.bijection.packed(run.dev)
     t = hip.NfmcJumpTail()
     t.flow = st
     t.adjusted = 1 if adjusted else 0
-    t.counters = hip.ptr(jump_counters, torch.int64)
-    t._keep = [keep, jump_counters]
+    t.counters = hip.ptr(run.stats._jump_counters, torch.int64)
+    t._keep = [keep]
     return t
 
 
@@ -225,9 +225,6 @@ class JumpNFMC(Sampler):
         buf = torch.empty(T * (K + 1), n, d, dtype=torch.float32, device=run.dev) if self.params.store_samples else None
         fit_buf = torch.empty(K, n, d, dtype=torch.float32, device=run.dev) if (self.params.fit_nf and buf is None) else None
         logq = torch.empty(n, dtype=torch.float32, device=run.dev)
-        jump_counters = torch.zeros(hip.CNT_WORDS, dtype=torch.int64, device=run.dev)
-        jstats = run.stats.struct()
-        jstats.counters = hip.ptr(jump_counters, torch.int64)
 
         t0 = time.time()
         done = 0
@@ -247,7 +244,7 @@ class JumpNFMC(Sampler):
                     last = off + k == K
                     tail = None
                     if last and tail_ok:
-                        tail = make_jump_tail(run, flow, self.params.adjusted_jumps, jump_counters)
+                        tail = make_jump_tail(run, flow, self.params.adjusted_jumps)
                     if tail is not None:  # k inner rows + the jump row, contiguous in the store
                         view = buf[base + off:base + off + k + 1] if buf is not None else None
                     else:
@@ -278,9 +275,11 @@ class JumpNFMC(Sampler):
             if tail_done:
                 pass
             elif fused:
-                launch_flow_mh(run, flow, pot, logq, 1, base + K, False, self.params.adjusted_jumps, jstats, jview)
+                launch_flow_mh(run, flow, pot, logq, 1, base + K, False, self.params.adjusted_jumps,
+                               run.stats.struct(defer=True, attempted=n, jump=True), jview)
             else:
-                split_flow_mh(run, flow, self.target, event_shape, base + K, self.params.adjusted_jumps, jstats)
+                split_flow_mh(run, flow, self.target, event_shape, base + K, self.params.adjusted_jumps,
+                              run.stats.struct(jump=True))
                 if jview is not None:
                     jview[0].copy_(run.x)
             done = i + 1
@@ -291,7 +290,7 @@ class JumpNFMC(Sampler):
         run.sync()
         inner._cur_run = None
         cnt = run.stats.counters.cpu()
-        jc = jump_counters.cpu()
+        jc = run.stats.jump_counters.cpu()
         calls, grads = inner._counts(n, K * done)
         st = out.statistics
         st.update_counters(n_accepted_trajectories=int(cnt[hip.CNT_ACCEPTED]),

@@ -266,7 +266,7 @@ class Langevin(MetropolisSampler):
         a.inv_mass_diag = hip.ptr(imd)
         a.pot = pot.descriptor(run.dev)
         a.rng = run.rng(step0, k, adjusted=self.params.adjustment)
-        a.stats = run.stats.struct()
+        a.stats = run.stats.struct(defer=True, attempted=run.n * k, jump_attempted=run.n if jump is not None else 0)
         a.samples = hip.ptr(samples) if samples is not None else None
         a.masks_out = hip.ptr(masks_out, torch.uint8) if masks_out is not None else None
         a.log_ratio_out = hip.ptr(log_ratio_out) if log_ratio_out is not None else None
@@ -440,7 +440,7 @@ class HMC(MetropolisSampler):
         a.inv_mass_diag = hip.ptr(imd)
         a.pot = pot.descriptor(run.dev)
         a.rng = run.rng(step0, k, adjusted=self.params.adjustment)
-        a.stats = run.stats.struct()
+        a.stats = run.stats.struct(defer=True, attempted=run.n * k, jump_attempted=run.n if jump is not None else 0)
         a.samples = hip.ptr(samples) if samples is not None else None
         a.masks_out = hip.ptr(masks_out, torch.uint8) if masks_out is not None else None
         a.log_ratio_out = hip.ptr(log_ratio_out) if log_ratio_out is not None else None

@@ -57,6 +57,10 @@ BENCH_KERNEL(k_mul_f32, asm volatile("v_mul_f32 %0, %0, %0\n v_mul_f32 %1, %1, %
 BENCH_KERNEL(k_cos, asm volatile("v_cos_f32 %0, %0\n v_cos_f32 %1, %1\n v_cos_f32 %2, %2\n v_cos_f32 %3, %3" : "+v"(fa), "+v"(fb), "+v"(fc), "+v"(fd));)
 BENCH_KERNEL(k_fmac_e32, asm volatile("v_fmac_f32 %0, %1, %2\n v_fmac_f32 %1, %2, %3\n v_fmac_f32 %2, %3, %0\n v_fmac_f32 %3, %0, %1" : "+v"(fa), "+v"(fb), "+v"(fc), "+v"(fd));)
 
+BENCH_KERNEL(k_cndmask_e64vcc, asm volatile("v_cndmask_b32_e64 %0, %0, %1, vcc\n v_cndmask_b32_e64 %1, %1, %2, vcc\n v_cndmask_b32_e64 %2, %2, %3, vcc\n v_cndmask_b32_e64 %3, %3, %0, vcc" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));)
+BENCH_KERNEL(k_cndmask_ind, asm volatile("v_cndmask_b32_e32 %0, %0, %4, vcc\n v_cndmask_b32_e32 %1, %1, %5, vcc\n v_cndmask_b32_e32 %2, %2, %6, vcc\n v_cndmask_b32_e32 %3, %3, %7, vcc" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e), "v"(f), "v"(g), "v"(h));)
+BENCH_KERNEL(k_cndmask_setvcc, asm volatile("s_mov_b64 vcc, %4\n v_cndmask_b32_e32 %0, %0, %1, vcc\n v_cndmask_b32_e32 %1, %1, %2, vcc\n v_cndmask_b32_e32 %2, %2, %3, vcc\n v_cndmask_b32_e32 %3, %3, %0, vcc" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "s"(sm) : "vcc");)
+
 struct Ent { const char* name; void (*fn)(uint32_t*, int); };
 
 int main() {
@@ -71,7 +75,7 @@ int main() {
                   {"v_cvt_f32_u32", k_cvt_u2f}, {"v_cndmask_b32", k_cndmask}, {"v_add_f32_dpp", k_dpp},
                   {"v_cndmask(sgpr)", k_cndmask_s}, {"v_bfi_b32", k_bfi}, {"v_pk_fma_f32", k_pk_fma}, {"v_pk_mul_f32", k_pk_mul},
                   {"v_pk_add_f32", k_pk_add}, {"v_and_or_b32", k_and_or}, {"v_mul_f32", k_mul_f32}, {"v_cos_f32", k_cos},
-                  {"v_fmac_f32(e32)", k_fmac_e32}};
+                  {"v_fmac_f32(e32)", k_fmac_e32}, {"cndmask e64 vcc", k_cndmask_e64vcc}, {"cndmask e32 indep", k_cndmask_ind}, {"cndmask e32 vcc set", k_cndmask_setvcc}};
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
