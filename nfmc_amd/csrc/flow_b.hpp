@@ -38,7 +38,9 @@ struct FlowImage {
     __host__ __device__ static int layer_floats(int n_hl) { return DP * HP + HP + (n_hl - 1) * (HP * HP + HP) + DP * RS; }
     __host__ __device__ static int total_floats(int n_hl, int n_coupling) { return n_coupling * layer_floats(n_hl) + 4 * DP; }
 
-    // all `nthreads` threads of the workgroup; blob layout: flow_device.hpp (W1T | b1 | [WhT | bh] | W3 | b3)
+    // all `nthreads` threads of the workgroup; blob layout: flow_device.hpp (W1T | b1 | [WhT | bh] | W3 | b3).
+    // One thread builds one slot's rows (no per-element index arithmetic): staging used to cost ~13 us per
+    // workgroup at d = 256 (two integer divisions per element), most of the jump kernel's time.
     __device__ static void stage(float* __restrict__ img, const NfmcRealNVP& f, int nthreads) {
         const int d = f.d, d_a = d / 2, d_b = d - d_a, n_hl = f.n_hidden_layers;
         const int lf = layer_floats(n_hl);
@@ -49,29 +51,34 @@ struct FlowImage {
             const float* W3 = W + d_a * HP + nmid;
             const float* b3 = W3 + 2 * d_b * HP;
             float* o = img + l * lf;
-            for (int t = threadIdx.x; t < DP * HP; t += nthreads) {
-                const int s = t / HP, k = t - s * HP;
+            float* o3 = o + DP * HP + nmid;
+            for (int s = threadIdx.x; s < DP; s += nthreads) {
                 const int c = coord_of<CPL, LPC>(s % LPC, s / LPC);
                 const int j = rev ? d - 1 - c : c;
-                o[t] = (c < d && j < d_a) ? W[j * HP + k] : 0.f;
+                const bool src = c < d && j < d_a, tgt = c < d && j >= d_a;
+                const float* w1 = W + (src ? j : 0) * HP;
+                const int tt = tgt ? j - d_a : 0;
+                const float* wa = W3 + tt * HP;
+                const float* wb = W3 + (d_b + tt) * HP;
+                float r1[HP], r3[RS];
+#pragma unroll
+                for (int k = 0; k < HP; ++k) {
+                    r1[k] = src ? w1[k] : 0.f;
+                    r3[k] = tgt ? wa[k] : 0.f;
+                    r3[HP + k] = tgt ? wb[k] : 0.f;
+                }
+                r3[2 * HP] = tgt ? b3[tt] : 0.f;
+                r3[2 * HP + 1] = tgt ? b3[d_b + tt] : 0.f;
+                r3[2 * HP + 2] = tgt ? 1.f : 0.f;
+                r3[2 * HP + 3] = 0.f;
+#pragma unroll
+                for (int k = 0; k < HP; k += 4)
+                    *reinterpret_cast<float4*>(o + s * HP + k) = make_float4(r1[k], r1[k + 1], r1[k + 2], r1[k + 3]);
+#pragma unroll
+                for (int k = 0; k < RS; k += 4)
+                    *reinterpret_cast<float4*>(o3 + s * RS + k) = make_float4(r3[k], r3[k + 1], r3[k + 2], r3[k + 3]);
             }
             for (int t = threadIdx.x; t < nmid; t += nthreads) o[DP * HP + t] = W[d_a * HP + t];
-            float* o3 = o + DP * HP + nmid;
-            for (int t = threadIdx.x; t < DP * RS; t += nthreads) {
-                const int s = t / RS, k = t - s * RS;
-                const int c = coord_of<CPL, LPC>(s % LPC, s / LPC);
-                const int j = rev ? d - 1 - c : c;
-                float v = 0.f;
-                if (c < d && j >= d_a) {
-                    const int tt = j - d_a;
-                    if (k < HP) v = W3[tt * HP + k];
-                    else if (k < 2 * HP) v = W3[(d_b + tt) * HP + (k - HP)];
-                    else if (k == 2 * HP) v = b3[tt];
-                    else if (k == 2 * HP + 1) v = b3[d_b + tt];
-                    else if (k == 2 * HP + 2) v = 1.f;
-                }
-                o3[t] = v;
-            }
         }
         float* ea = img + f.n_coupling * lf;
         const bool revl = (f.n_coupling & 1) != 0;
@@ -91,11 +98,20 @@ struct FlowImage {
 // on the latent side position p holds logical coordinate (odd #reversals ? d-1-p : p), as in flow_device.hpp).
 // LEAN: scheduling fences between coordinates keep the weight loads from being hoisted en bloc, so the flow
 // code adds few live registers to a kernel whose hot loop is something else (jump tail of the samplers).
-template <int CPL, int LPC, int HP, bool LEAN = false>
+// EXACT: d == CPL * LPC with CPL >= 8, so the first CPL/2 registers of every lane are the first half of the
+// coordinates and the rest the second half: a layer's sources and targets are whole register ranges, known at
+// compile time per layer parity, and only those rows of the image are read (half the LDS traffic, half the
+// multiply-adds, and far fewer live registers than the generic path, which reads a zero row instead).
+template <int CPL, int LPC, int HP, bool LEAN = false, bool EXACT = false>
 struct FlowB {
     using Img = FlowImage<CPL, LPC, HP>;
     static constexpr int DP = CPL * LPC;
+    static_assert(!EXACT || CPL >= 8, "EXACT needs whole register quads per half");
+    // wave-uniform weights are read through the scalar cache (s_load -> SGPR operands): constant address space
+    typedef const float __attribute__((address_space(4))) cfloat;
     const float* img;  // LDS
+    const cfloat* mid;  // global: b1 | [WhT | bh] x (n_hl - 1) of layer 0
+    int64_t gstride;
     int n_hl, n_coupling, lf, g;
     float m, log1m;
 
@@ -107,6 +123,8 @@ struct FlowB {
         m = f.min_scale;
         log1m = __logf(1.f - f.min_scale);
         g = g_;
+        mid = (const cfloat*)(uintptr_t)(f.weights + (f.d / 2) * HP);
+        gstride = f.layer_stride;
     }
 
     // Make the image pointer opaque to the optimiser.  The weights are loop-invariant across the chain tiles of
@@ -115,15 +133,18 @@ struct FlowB {
     __device__ __forceinline__ void launder() { asm volatile("" : "+v"(img)); }
 
     // one coupling layer in place; INVERSE: x_b = (z_b - beta)/alpha.  Returns this lane's share of the logdet.
-    template <bool INVERSE>
-    __device__ __forceinline__ float coupling(float (&x)[CPL], int l) const {
+    // REV: the layer sees logical coordinate j at physical position d-1-j (even layers); only used when EXACT.
+    template <bool INVERSE, bool REV>
+    __device__ __forceinline__ float coupling_impl(float (&x)[CPL], int l) const {
+        constexpr int S0 = EXACT ? (REV ? CPL / 2 : 0) : 0, S1 = EXACT ? S0 + CPL / 2 : CPL;       // source registers
+        constexpr int T0 = EXACT ? (REV ? 0 : CPL / 2) : 0, T1 = EXACT ? T0 + CPL / 2 : CPL;       // target registers
         const float* W1 = img + l * lf + g * HP;
-        const float* b1 = img + l * lf + DP * HP;
+        const cfloat* b1 = mid + l * gstride;
         float h[HP];
 #pragma unroll
         for (int k = 0; k < HP; ++k) h[k] = 0.f;
 #pragma unroll
-        for (int i = 0; i < CPL; ++i) {  // zero rows for coordinates that are not sources of this layer
+        for (int i = S0; i < S1; ++i) {  // generic path: zero rows for coordinates that are not sources of this layer
             const float* w = W1 + i * LPC * HP;
 #pragma unroll
             for (int k = 0; k < HP; ++k) h[k] = fmaf(w[k], x[i], h[k]);
@@ -131,10 +152,10 @@ struct FlowB {
         }
 #pragma unroll
         for (int k = 0; k < HP; ++k) h[k] = fast_tanh(group_allreduce<LPC>(h[k]) + b1[k]);
-        const float* Wh = b1 + HP;
+        const cfloat* Wh = b1 + HP;
         for (int hl = 1; hl < n_hl; ++hl) {
             float t[HP];
-            const float* bh = Wh + HP * HP;
+            const cfloat* bh = Wh + HP * HP;
 #pragma unroll
             for (int k = 0; k < HP; ++k) t[k] = bh[k];
 #pragma unroll
@@ -145,10 +166,10 @@ struct FlowB {
             for (int k = 0; k < HP; ++k) h[k] = fast_tanh(t[k]);
             Wh = bh + HP;
         }
-        const float* W3 = Wh + g * Img::RS;
+        const float* W3 = img + l * lf + DP * HP + (HP + (n_hl - 1) * (HP * HP + HP)) + g * Img::RS;
         float ld = 0.f;
 #pragma unroll
-        for (int i = 0; i < CPL; ++i) {
+        for (int i = T0; i < T1; ++i) {
             const float* w = W3 + i * LPC * Img::RS;
             float ua = w[2 * HP], ub = w[2 * HP + 1];
 #pragma unroll
@@ -156,14 +177,23 @@ struct FlowB {
                 ua = fmaf(w[k], h[k], ua);
                 ub = fmaf(w[HP + k], h[k], ub);
             }
-            // pass-through and padding coordinates (flag 0) stay bitwise unchanged
-            const float alpha = w[2 * HP + 2] != 0.f ? fast_exp(fmaf(0.5f, ua, log1m)) + m : 1.f;
+            // generic path: pass-through and padding coordinates (flag 0) stay bitwise unchanged
+            const float alpha = (EXACT || w[2 * HP + 2] != 0.f) ? fast_exp(fmaf(0.5f, ua, log1m)) + m : 1.f;
             const float beta = 0.5f * ub;
             ld += fast_ln(alpha);
             x[i] = INVERSE ? (x[i] - beta) * __builtin_amdgcn_rcpf(alpha) : fmaf(alpha, x[i], beta);
-            if constexpr (LEAN) __builtin_amdgcn_sched_barrier(0);
+            if constexpr (LEAN || EXACT) __builtin_amdgcn_sched_barrier(0);
         }
         return INVERSE ? -ld : ld;
+    }
+
+    template <bool INVERSE>
+    __device__ __forceinline__ float coupling(float (&x)[CPL], int l) const {
+        if constexpr (EXACT) {
+            return (l & 1) == 0 ? coupling_impl<INVERSE, true>(x, l) : coupling_impl<INVERSE, false>(x, l);
+        } else {
+            return coupling_impl<INVERSE, false>(x, l);
+        }
     }
 
     // x -> z (z left in physical positions); returns this lane's share of logdet_forward

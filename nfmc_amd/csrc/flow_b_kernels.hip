@@ -7,7 +7,10 @@
 namespace nfmc {
 
 template <int CPL, int LPC, int HP, template <int, int, bool> class Pot, bool FAST>
-__global__ void __launch_bounds__(kBlock) flow_mh_b_kernel(NfmcFlowMhArgs a, int64_t tiles) {
+#ifndef NFMC_FLOWB_WPE
+#define NFMC_FLOWB_WPE 1
+#endif
+__global__ void __launch_bounds__(kBlock, NFMC_FLOWB_WPE) flow_mh_b_kernel(NfmcFlowMhArgs a, int64_t tiles) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int CPW = kWave / LPC;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -16,7 +19,7 @@ __global__ void __launch_bounds__(kBlock) flow_mh_b_kernel(NfmcFlowMhArgs a, int
     const int64_t n = a.n;
     FlowImage<CPL, LPC, HP>::stage(lds, a.flow, kBlock);
     __syncthreads();
-    FlowB<CPL, LPC, HP> fl;
+    FlowB<CPL, LPC, HP, false, (FAST && CPL >= 8)> fl;
     fl.init(lds, a.flow, g);
     Pot<CPL, LPC, FAST> pot;
     pot.init(a.pot, g, d);
