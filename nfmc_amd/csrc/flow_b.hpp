@@ -102,6 +102,22 @@ struct FlowImage {
 // coordinates and the rest the second half: a layer's sources and targets are whole register ranges, known at
 // compile time per layer parity, and only those rows of the image are read (half the LDS traffic, half the
 // multiply-adds, and far fewer live registers than the generic path, which reads a zero row instead).
+// N floats (N % 4 == 0) from a 16-byte aligned LDS row as ds_read_b128.  Left to itself the compiler reads the
+// image rows with ds_read2_b32 (it cannot see the alignment): 4x the LDS instructions, and at a row stride of
+// 12 or 20 floats every one of them is a 4-way bank conflict -- the register flow kernels were LDS-bound on it.
+template <int N>
+__device__ __forceinline__ void load_row16(float (&w)[N], const float* __restrict__ row) {
+    static_assert(N % 4 == 0, "rows are whole 16-byte groups");
+#pragma unroll
+    for (int k = 0; k < N; k += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(__builtin_assume_aligned(row + k, 16));
+        w[k] = v.x;
+        w[k + 1] = v.y;
+        w[k + 2] = v.z;
+        w[k + 3] = v.w;
+    }
+}
+
 template <int CPL, int LPC, int HP, bool LEAN = false, bool EXACT = false>
 struct FlowB {
     using Img = FlowImage<CPL, LPC, HP>;
@@ -145,7 +161,8 @@ struct FlowB {
         for (int k = 0; k < HP; ++k) h[k] = 0.f;
 #pragma unroll
         for (int i = S0; i < S1; ++i) {  // generic path: zero rows for coordinates that are not sources of this layer
-            const float* w = W1 + i * LPC * HP;
+            float w[HP];
+            load_row16<HP>(w, W1 + i * LPC * HP);
 #pragma unroll
             for (int k = 0; k < HP; ++k) h[k] = fmaf(w[k], x[i], h[k]);
             if constexpr (LEAN) __builtin_amdgcn_sched_barrier(0);
@@ -170,7 +187,8 @@ struct FlowB {
         float ld = 0.f;
 #pragma unroll
         for (int i = T0; i < T1; ++i) {
-            const float* w = W3 + i * LPC * Img::RS;
+            float w[Img::RS];
+            load_row16<Img::RS>(w, W3 + i * LPC * Img::RS);
             float ua = w[2 * HP], ub = w[2 * HP + 1];
 #pragma unroll
             for (int k = 0; k < HP; ++k) {
