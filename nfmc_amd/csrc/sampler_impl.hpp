@@ -214,13 +214,32 @@ __global__ void __launch_bounds__(kBlock, NFMC_WPE) mala_kernel(NfmcMalaArgs a, 
         float x[CPL];
         load_row<CPL, LPC, FAST>(a.x, row, d, g, active, x);
         AcceptUniform au;
+        float sq = 0.f, sq_prop = 0.f;   // FAST quadratic: this lane's share of |x|^2 (current state / proposal)
+        if constexpr (Pot<CPL, LPC, FAST>::kQuadratic && FAST) {
+#pragma unroll
+            for (int i = 0; i < CPL; ++i) sq = fmaf(x[i], x[i], sq);
+        }
 
         for (int s = 0; s < a.n_steps; ++s) {
             float e[CPL], xp[CPL];
             draw_normals<CPL, LPC>(a.rng, kTagNoise, gchain, row, n, d, g, s, e);
             bool accept = true;
             float lr = 0.f;
-            if constexpr (Pot<CPL, LPC, FAST>::kQuadratic) {
+            if constexpr (Pot<CPL, LPC, FAST>::kQuadratic && FAST) {
+                // FAST: scalar a, b = 0, unit mass.  The ratio below, a^2 h (sum_j x_j^2 - sum_j x'_j^2), needs only
+                // this lane's share of |x'|^2: the share of |x|^2 is carried from the previous transition (`sq`,
+                // replaced by the proposal's on acceptance).  3 VALU instructions per coordinate for proposal + ratio.
+                float sp0 = 0.f, sp1 = 0.f;
+#pragma unroll
+                for (int i = 0; i < CPL; i += 2) {
+                    xp[i] = fmaf(mc.C2(i), e[i], fmaf(mc.CG(i), x[i], x[i]));              // langevin.py:74-76 / mh.py:55
+                    xp[i + 1] = fmaf(mc.C2(i + 1), e[i + 1], fmaf(mc.CG(i + 1), x[i + 1], x[i + 1]));
+                    sp0 = fmaf(xp[i], xp[i], sp0);
+                    sp1 = fmaf(xp[i + 1], xp[i + 1], sp1);
+                }
+                sq_prop = sp0 + sp1;
+                lr = mc.KAP(0) * (sq - sq_prop);
+            } else if constexpr (Pot<CPL, LPC, FAST>::kQuadratic) {
                 // U = sum a (x-b)^2: with t = x - b, t' = x' - b the reference's ratio (langevin.py:88-105)
                 //   (u - u') + [q(x'|x) - q(x|x')]   collapses term by term to   a^2 (h/m^2) (t^2 - t'^2)
                 // (expand tf = d + 2 a hA t, tb = -d + 2 a hA t', d = t' - t; invA hA = h): same value, 7
@@ -258,6 +277,7 @@ __global__ void __launch_bounds__(kBlock, NFMC_WPE) mala_kernel(NfmcMalaArgs a, 
             accept = accept && active;
             const uint64_t am = __ballot(accept);
             n_acc += (uint32_t)__popcll(am & leaders);
+            if constexpr (Pot<CPL, LPC, FAST>::kQuadratic && FAST) sq = select_f32(am, sq_prop, sq);
 #pragma unroll
             for (int i = 0; i < CPL; ++i) {
                 x[i] = select_f32(am, xp[i], x[i]);  // mcmc/base.py:77

@@ -59,8 +59,10 @@ static int check_common(const Args* a) {
 
 template <class Args>
 static bool fast_path(const Args* a, const Cfg& c) {
+    // the FAST kernels assume a scalar potential with b = 0 (the carried |x|^2 of the Langevin ratio)
     return a->d == c.cpl * c.lpc && a->inv_mass_diag == nullptr && a->pot.a == nullptr && a->pot.b == nullptr &&
-           aligned16(a->x) && (!a->samples || aligned16(a->samples));
+           (a->pot.kind != NFMC_POT_QUADRATIC || a->pot.b_scalar == 0.f) && aligned16(a->x) &&
+           (!a->samples || aligned16(a->samples));
 }
 
 static JumpDev jump_dev(const NfmcJumpTail* j) {
