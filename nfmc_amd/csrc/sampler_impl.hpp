@@ -367,6 +367,20 @@ __global__ void __launch_bounds__(kBlock, NFMC_WPE) hmc_kernel(NfmcHmcArgs a, in
                     dh += pot.term(ctx, i, x[i]) + 0.5f * (p[i] * p[i] * mc.M(i));  // hmc.py:103-106
                 }
             }
+            if constexpr (Pot<CPL, LPC, FAST>::kQuadratic && FAST) {
+                // scalar a, b = 0, unit mass: (h/2) grad U(q) = (h/2 * 2a) q, one fused multiply-add per half step
+                // (for a = 1 bitwise the reference's h/2 * (2 q): both scalings are exact powers of two)
+                const float cq = hh * (2.f * pot.aa(0));
+                for (int l = 0; l < a.n_leapfrog; ++l) {  // hmc.py:67-71, both half steps kept separate
+#pragma unroll
+                    for (int i = 0; i < CPL; ++i) {
+                        p[i] = fmaf(-cq, q[i], p[i]);
+                        q[i] = fmaf(h, p[i], q[i]);
+                    }
+#pragma unroll
+                    for (int i = 0; i < CPL; ++i) p[i] = fmaf(-cq, q[i], p[i]);
+                }
+            } else
             for (int l = 0; l < a.n_leapfrog; ++l) {  // hmc.py:67-71, both half steps kept separate
                 const auto c0 = pot.prepare(q, g, d);
 #pragma unroll
