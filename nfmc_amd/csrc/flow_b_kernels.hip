@@ -148,10 +148,11 @@ int flow_mh_b_launch(const NfmcFlowMhArgs& a, hipStream_t st, int* grid_out, int
     const int d = a.flow.d;
     const int hp = a.flow.n_hidden <= 4 ? 4 : 8;
     if (a.flow.n_hidden > 8 || d > 512) return NFMC_EUNSUPPORTED;
-    // smallest capacity; at equal capacity CPL = 8 for many chains (fewer redundant hidden-stack evaluations),
-    // CPL = 4 for few (twice the lanes: IMH at n = 8192 0.345 vs 0.376 ms per 100 transitions)
+    // smallest capacity; at equal capacity CPL = 8 (exact-fit layouts read only their source / target rows;
+    // IMH d = 64, 1000 transitions: 3.23 vs 3.64 ms at n = 8192, 4.2 vs 6.5 ms at n = 16384) except for very
+    // few chains, where twice the lanes per chain win (n = 4096: 3.30 vs 3.40 ms)
     BCfg c = {0, 0};
-    const int want_cpl = a.n <= 16384 ? 4 : 8;
+    const int want_cpl = a.n <= 4096 ? 4 : 8;
     for (const BCfg& k : kBCfgs) {
         if (k.cpl * k.lpc < d) continue;
         if (c.cpl == 0 || k.cpl * k.lpc < c.cpl * c.lpc || (k.cpl * k.lpc == c.cpl * c.lpc && k.cpl == want_cpl)) c = k;

@@ -1,0 +1,36 @@
+"""Per-kernel means of the rocprofv3 --pmc passes written by tools/profile_bench.sh -> JSON on stdout."""
+import csv, glob, json, os, sys
+from collections import defaultdict
+
+
+def short(name):
+    for key in ('mala_kernel', 'flow_mh_b_kernel', 'stats_finish_kernel', 'hmc_kernel'):
+        if key in name:
+            return key
+    return None
+
+
+def main(root):
+    acc = defaultdict(lambda: defaultdict(list))
+    meta = {}
+    for path in glob.glob(os.path.join(root, 'pmc_*', '**', '*counter_collection.csv'), recursive=True):
+        with open(path) as fh:
+            for row in csv.DictReader(fh):
+                k = short(row.get('Kernel_Name', ''))
+                if k is None:
+                    continue
+                acc[k][row['Counter_Name']].append(float(row['Counter_Value']))
+                meta.setdefault(k, {'kernel': row['Kernel_Name'][:90], 'vgpr': row.get('VGPR_Count'),
+                                    'sgpr': row.get('SGPR_Count'), 'lds': row.get('LDS_Block_Size'),
+                                    'grid': row.get('Grid_Size'), 'wg': row.get('Workgroup_Size')})
+    out = {}
+    for k, counters in acc.items():
+        out[k] = dict(meta[k])
+        for c, vals in sorted(counters.items()):
+            out[k][c] = sum(vals) / len(vals)
+        out[k]['launches_sampled'] = max(len(v) for v in counters.values())
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == '__main__':
+    main(sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out/prof')
