@@ -812,3 +812,24 @@ def test_two_rank_sharded_sampling_matches_single_process(dev, tmp_path):
         assert r['calls'] == ref.statistics.n_target_calls
         np.testing.assert_allclose(r['mean'].numpy(), ref.mean.numpy(), atol=1e-6)
         np.testing.assert_allclose(r['second'].numpy(), ref.second_moment.numpy(), atol=1e-6)
+
+
+def test_integration_stub_runs_and_matches_the_package(dev):
+    """INTEGRATION.md's reference-side binding, executed verbatim, equals nfmc_amd's MALA with the same seed."""
+    from test_host_cpu import _integration_stub_namespace
+    from nfmc_amd.potentials import SumOfSquares
+    from nfmc_amd.samplers import mcmc
+    ns = _integration_stub_namespace()
+    n, d, k, h, seed = 512, 64, 25, 0.25, 1234
+    torch.manual_seed(0)
+    x0 = torch.randn(n, d)
+    x = x0.to(dev).clone()
+    sum_x, sum_x2, counters = ns['mala_steps_sum_squares'](x, k, h, seed)
+    torch.cuda.synchronize()
+    s = mcmc.MALA((d,), SumOfSquares((d,)), mcmc.LangevinKernel(event_size=d, step_size=h),
+                  mcmc.LangevinParameters(n_iterations=k, store_samples=False))
+    s.seed = seed
+    out = s.sample(x0, show_progress=False)
+    assert torch.equal(out.running_samples.last_sample.reshape(n, d).cpu(), x.cpu())
+    assert int(counters[0]) == out.statistics.n_accepted_trajectories and int(counters[1]) == n * k
+    np.testing.assert_allclose((sum_x / (n * k)).cpu().numpy(), out.mean.numpy().astype(np.float64), atol=1e-6)

@@ -360,3 +360,24 @@ def test_nice_flow_string_and_training_restatement():
     np.testing.assert_allclose(ldi.numpy(), -ld.numpy(), atol=1e-6)
     const = float(of.bijection.layers[0].log_scale.sum() + of.bijection.layers[-1].log_scale.sum())
     assert float((ldo - const).abs().max()) < 1e-6
+
+
+def _integration_stub_namespace():
+    """The ctypes stub INTEGRATION.md shows for the reference, executed as written (library path filled in)."""
+    import re
+    from nfmc_amd import hip
+    text = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    block = re.search(r"```python\n(# nfmc/algorithms/sampling/mcmc/_hip\.py.*?)```", text, re.S).group(1)
+    block = block.replace("C.CDLL('libnfmc_hip.so')", "C.CDLL(%r)" % hip.LIB_PATH)
+    ns = {}
+    exec(compile(block, 'INTEGRATION.md', 'exec'), ns)
+    return ns
+
+
+def test_integration_stub_structs_match_the_header():
+    import ctypes as C
+    from nfmc_amd import hip
+    ns = _integration_stub_namespace()
+    for name in ('NfmcPotential', 'NfmcRng', 'NfmcStats', 'NfmcMalaArgs'):
+        assert C.sizeof(ns[name]) == C.sizeof(getattr(hip, name)), name
+        assert [f[0] for f in ns[name]._fields_] == [f[0] for f in getattr(hip, name)._fields_], name
