@@ -236,8 +236,6 @@ __global__ void __launch_bounds__(kNeutraBlock) neutra_hmc_kernel(NfmcNeutraHmcA
         tile_load(zt, stride, a.z, r0, n, d, rev);
         __syncthreads();
         float u_cur = adjusted_potential_grad_row<HP>(zr, wr, gr, f, g, a.pot);  // U~(z), grad at the current state
-        float uniform4_unused = 0.f;
-        (void)uniform4_unused;
         uint4 ur = make_uint4(0, 0, 0, 0);
         for (int s = 0; s < a.n_steps; ++s) {
             // momentum p = eps / sqrt(m)  (hmc.py:100); tile columns are latent positions: logical c <-> col latent_col(c)

@@ -256,7 +256,7 @@ class JumpNFMC(Sampler):
                         tail.replay_latent = hip.ptr(lat[0].contiguous())
                         tail.replay_uniform = hip.ptr(un[0].contiguous()) if un is not None else None
                         tail._keep += [lat, un]
-                        inner._launch_with_rng(run, pot, k, rng_inner, view, jump=tail)
+                        inner._launch(run, pot, k, base + off, view, jump=tail, rng=rng_inner)
                     else:
                         inner._launch(run, pot, k, base + off, view, jump=tail)
                     tail_done = tail is not None

@@ -114,20 +114,11 @@ class MCMCSampler(Sampler):
         raise NotImplementedError
 
     # ---- fused launch of k transitions; implemented by Langevin / HMC
-    def _launch(self, run: Run, pot, k, step0, samples, masks_out=None, log_ratio_out=None, jump=None):
+    def _launch(self, run: Run, pot, k, step0, samples, masks_out=None, log_ratio_out=None, jump=None, rng=None):
         raise NotImplementedError
 
     def _counts(self, n, k):
         raise NotImplementedError
-
-    def _launch_with_rng(self, run: Run, pot, k, rng, samples, jump=None):
-        """`_launch` with an NfmcRng prepared by the caller (replay bookkeeping of fused jump tails)."""
-        orig = run.rng
-        run.rng = lambda step0, kk=0, adjusted=True: rng
-        try:
-            self._launch(run, pot, k, 0, samples, jump=jump)
-        finally:
-            run.rng = orig
 
     def warmup(self, x0, show_progress: bool = True, time_limit_seconds=None) -> MCMCOutput:
         # mcmc/base.py:39-54
@@ -257,7 +248,7 @@ class Langevin(MetropolisSampler):
         per = 2 * n if self.params.adjustment else n  # langevin.py:116-120
         return per * k, per * k
 
-    def _launch(self, run, pot, k, step0, samples, masks_out=None, log_ratio_out=None, jump=None):
+    def _launch(self, run, pot, k, step0, samples, masks_out=None, log_ratio_out=None, jump=None, rng=None):
         a = hip.NfmcMalaArgs()
         a.x, a.n, a.d, a.n_steps = hip.ptr(run.x), run.n, run.d, k
         a.step_size = float(self.kernel.step_size)
@@ -265,7 +256,8 @@ class Langevin(MetropolisSampler):
         imd = imd_tensor(self.kernel, run.dev)
         a.inv_mass_diag = hip.ptr(imd)
         a.pot = pot.descriptor(run.dev)
-        a.rng = run.rng(step0, k, adjusted=self.params.adjustment)
+        # `rng`: an NfmcRng prepared by the caller (replay bookkeeping of fused jump tails)
+        a.rng = rng if rng is not None else run.rng(step0, k, adjusted=self.params.adjustment)
         a.stats = run.stats.struct(defer=True, attempted=run.n * k, jump_attempted=run.n if jump is not None else 0)
         a.samples = hip.ptr(samples) if samples is not None else None
         a.masks_out = hip.ptr(masks_out, torch.uint8) if masks_out is not None else None
@@ -430,7 +422,7 @@ class HMC(MetropolisSampler):
         calls = grads + (2 * n if self.params.adjustment else 0)
         return calls * k, grads * k
 
-    def _launch(self, run, pot, k, step0, samples, masks_out=None, log_ratio_out=None, jump=None):
+    def _launch(self, run, pot, k, step0, samples, masks_out=None, log_ratio_out=None, jump=None, rng=None):
         a = hip.NfmcHmcArgs()
         a.x, a.n, a.d, a.n_steps = hip.ptr(run.x), run.n, run.d, k
         a.step_size = float(self.kernel.step_size)
@@ -439,7 +431,8 @@ class HMC(MetropolisSampler):
         imd = imd_tensor(self.kernel, run.dev)
         a.inv_mass_diag = hip.ptr(imd)
         a.pot = pot.descriptor(run.dev)
-        a.rng = run.rng(step0, k, adjusted=self.params.adjustment)
+        # `rng`: an NfmcRng prepared by the caller (replay bookkeeping of fused jump tails)
+        a.rng = rng if rng is not None else run.rng(step0, k, adjusted=self.params.adjustment)
         a.stats = run.stats.struct(defer=True, attempted=run.n * k, jump_attempted=run.n if jump is not None else 0)
         a.samples = hip.ptr(samples) if samples is not None else None
         a.masks_out = hip.ptr(masks_out, torch.uint8) if masks_out is not None else None
