@@ -1,15 +1,18 @@
 // RealNVP with WIDE conditioners (33 <= n_hidden <= 128) on the matrix cores.
 //
-// v_mfma_f32_32x32x2_f32 (exact fp32, 64 flop/clk/SIMD) with the roles
-//     A = weights   lane l holds A[i = 32*mo + (l & 31)][k]            (LDS image, ds_read_b128 = 4 k-steps)
-//     B = activations, chains on the N axis: lane l holds B[k][chain = l & 31], k chosen by l >> 5
-// A wave owns 32 chains.  Every per-chain vector (state, gradient, hidden activations) lives in the MFMA
-// C/D layout ("C layout"): tile m, register t, half h = l >> 5 hold element
-//     r = 32 m + (t & 3) + 8 (t >> 2) + 4 h        of chain l & 31.
-// With that layout the accumulator tile of one layer IS the B operand of the next: register t of tile m
-// pairs rows (R, R+4) across the two lane halves, so k-step t multiplies with A columns (R, R+4), which
-// is exactly what one 16-byte LDS read per lane delivers for four consecutive t.  No activation ever moves
-// between lanes or through LDS; only weights are staged (once per GEMM per workgroup of 128 chains).
+// v_mfma_f32_16x16x4_f32 (exact fp32; 32 cycles, 1024 MAC -> 64 flop/clk/SIMD, the fp32 peak) with the roles
+//     A = weights   lane l holds A[i = 16*mo + (l & 15)][k]            (LDS image, one ds_read_b128 = 4 k-steps)
+//     B = activations, chains on the N axis: lane l holds B[k][chain = l & 15], k chosen by q = l >> 4
+// A wave owns 16 chains; a workgroup is 8 waves = 128 chains, two waves per SIMD (<= 256 VGPRs), so one wave's
+// LDS / barrier / elementwise phases hide behind the other's MFMAs (the 32-chain-per-wave first version ran at
+// one wave per SIMD with spills: 55 % of wave cycles in s_waitcnt/s_barrier, MfmaUtil 24 %, profiles/).
+// Every per-chain vector (state, gradient, hidden activations) lives in the MFMA C/D layout ("C layout"):
+// tile m (16 elements), register r, lane group q hold element
+//     e = 16 m + 4 q + r        of chain l & 15.
+// With that layout the accumulator tile of one layer IS the B operand of the next: k-step r of tile m pairs
+// the four lane groups with k = 16 m + 4 q + r, so the A operand of lane (i, q) for r = 0..3 is the four
+// consecutive weights A[i][16 m + 4 q .. +3]: one 16-byte LDS read.  No activation ever moves between lanes
+// or through LDS; only weights are staged (once per GEMM per workgroup of 128 chains).
 //
 // Weight blob per coupling layer for this path (both orientations, so the transposed products of the
 // reverse sweep also read rows): HP = 64 or 128, d = 64 or 128 (d_a = d_b = d/2):
@@ -20,10 +23,10 @@
 
 namespace nfmc {
 
-using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-constexpr int kMfmaBlock = 256;      // 4 waves x 32 chains
+constexpr int kMfmaBlock = 512;      // 8 waves x 16 chains
+constexpr int kMfmaWaves = kMfmaBlock / 64;
 constexpr int kMfmaChains = 128;     // chains per workgroup
 
 struct MLayer {
@@ -57,17 +60,26 @@ __device__ __forceinline__ MLayer mfma_layer(const float* base, int d, int hp, i
 
 // ---- staging: global (rows x K, row-major) -> LDS image [rows][K+4]; optional reversal of rows / columns
 // inside blocks (a reversed coupling layer sees logical coordinate j at physical position d-1-j).
-__device__ __forceinline__ void stage_matrix(float* __restrict__ img, const float* __restrict__ W, int rows, int K,
-                                             bool rev_rows, int rblk, bool rev_cols, int cblk) {
-    const int ld = K + 4, k4 = K >> 2;
-    for (int idx = threadIdx.x; idx < rows * k4; idx += kMfmaBlock) {
-        const int r = idx / k4, c = (idx - r * k4) << 2;
+// All extents are powers of two known at compile time, so the index arithmetic is shifts and masks (with
+// run-time extents each element cost several integer divisions: as much VALU time as the GEMM it fed).
+template <int K, int RBLK, int CBLK>
+__device__ __forceinline__ void stage_matrix(float* __restrict__ img, const float* __restrict__ W, int rows,
+                                             bool rev_rows, bool rev_cols) {
+    constexpr int ld = K + 4, k4 = K >> 2;
+    static_assert((K & (K - 1)) == 0 && (RBLK & (RBLK - 1)) == 0 && (CBLK & (CBLK - 1)) == 0, "power-of-two extents");
+    // The copy addresses depend only on the thread index, so LICM would hoist the address arithmetic of EVERY
+    // staging call of the kernel above the tile loop and keep hundreds of VGPRs live through all the GEMMs
+    // (measured: ~2 KB of scratch per lane).  An opaque copy of the index pins the arithmetic to the call.
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    for (int idx = tid; idx < rows * k4; idx += kMfmaBlock) {
+        const int r = idx / k4, c = (idx % k4) << 2;
         const f32x4 v = *reinterpret_cast<const f32x4*>(W + (size_t)r * K + c);
-        const int rr = rev_rows ? (r / rblk) * rblk + (rblk - 1 - (r % rblk)) : r;
+        const int rr = rev_rows ? (r / RBLK) * RBLK + (RBLK - 1 - (r % RBLK)) : r;
         if (!rev_cols) {
             *reinterpret_cast<f32x4*>(img + rr * ld + c) = v;
         } else {
-            const int cc = (c / cblk) * cblk + (cblk - 4 - (c % cblk));
+            const int cc = (c / CBLK) * CBLK + (CBLK - 4 - (c % CBLK));
             f32x4 w;
             w[0] = v[3];
             w[1] = v[2];
@@ -78,115 +90,97 @@ __device__ __forceinline__ void stage_matrix(float* __restrict__ img, const floa
     }
 }
 
-__device__ __forceinline__ void stage_vector(float* __restrict__ dst, const float* __restrict__ b, int len, bool rev,
-                                             int blk) {
-    for (int i = threadIdx.x; i < len; i += kMfmaBlock) dst[rev ? (i / blk) * blk + (blk - 1 - (i % blk)) : i] = b[i];
+template <int BLK>
+__device__ __forceinline__ void stage_vector(float* __restrict__ dst, const float* __restrict__ b, int len, bool rev) {
+    static_assert((BLK & (BLK - 1)) == 0, "power-of-two block");
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));   // as in stage_matrix
+    for (int i = tid; i < len; i += kMfmaBlock) dst[rev ? (i / BLK) * BLK + (BLK - 1 - (i % BLK)) : i] = b[i];
 }
 
-// ---- one 32-row output tile: acc += A[32*mo .. +31][0 .. 32*TK) x act
+// ---- one 16-row output tile: acc += A[16*mo .. +15][0 .. 16*TK) x act ; arow = img + (16*mo + col)*ld + 4*q
 template <int TK>
-__device__ __forceinline__ void gemm_tile(f32x16& acc, const float* __restrict__ arow, const f32x16 (&act)[TK]) {
+__device__ __forceinline__ void gemm_tile(f32x4& acc, const float* __restrict__ arow, const f32x4 (&act)[TK]) {
 #pragma unroll
     for (int mk = 0; mk < TK; ++mk) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(arow + 32 * mk + 8 * q);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], act[mk][4 * q + 0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], act[mk][4 * q + 1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], act[mk][4 * q + 2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], act[mk][4 * q + 3], acc, 0, 0, 0);
-        }
+        const f32x4 a = *reinterpret_cast<const f32x4*>(arow + 16 * mk);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], act[mk][0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], act[mk][1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], act[mk][2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], act[mk][3], acc, 0, 0, 0);
     }
+    // Keep the scheduler from hoisting the next tiles' A-fragment reads above this tile's MFMAs: with every
+    // output tile unrolled that costs ~32 VGPRs per tile and spills; the partner wave on the SIMD covers the
+    // LDS latency instead.
+    __builtin_amdgcn_sched_barrier(0);
 }
 
-// bias / parameter tile in C layout from an LDS (or global) vector: element 32*mo + 8q + 4h + j -> reg 4q+j
-__device__ __forceinline__ f32x16 vec_tile(const float* __restrict__ v, int mo, int half) {
-    f32x16 t;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(v + 32 * mo + 8 * q + 4 * half);
-        t[4 * q + 0] = a[0];
-        t[4 * q + 1] = a[1];
-        t[4 * q + 2] = a[2];
-        t[4 * q + 3] = a[3];
-    }
-    return t;
+// tile of a vector in C layout: elements 16*mo + 4*q + (0..3)
+__device__ __forceinline__ f32x4 vec_tile(const float* __restrict__ v, int mo, int q) {
+    return *reinterpret_cast<const f32x4*>(v + 16 * mo + 4 * q);
 }
 
-// same from a global vector indexed by LOGICAL coordinate, when the tile position p holds logical d-1-p
-__device__ __forceinline__ f32x16 vec_tile_rev(const float* __restrict__ v, int mo, int half, int d) {
-    f32x16 t;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int p0 = 32 * mo + 8 * q + 4 * half;
-        const f32x4 a = *reinterpret_cast<const f32x4*>(v + (d - 4 - p0));
-        t[4 * q + 0] = a[3];
-        t[4 * q + 1] = a[2];
-        t[4 * q + 2] = a[1];
-        t[4 * q + 3] = a[0];
-    }
+// same from a vector indexed by LOGICAL coordinate when tile position p holds logical d-1-p
+__device__ __forceinline__ f32x4 vec_tile_rev(const float* __restrict__ v, int mo, int q, int d) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(v + (d - 4 - (16 * mo + 4 * q)));
+    f32x4 t;
+    t[0] = a[3];
+    t[1] = a[2];
+    t[2] = a[1];
+    t[3] = a[0];
     return t;
 }
 
 // ---- (n, d) row-major <-> C-layout tiles of this lane's chain.  `rev`: the array is in LOGICAL latent order
 // and tile position p holds logical d-1-p (flows with an odd number of reversals, see latent_col).
 template <int TD>
-__device__ __forceinline__ void load_ctiles(f32x16 (&x)[TD], const float* __restrict__ base, int64_t row, int d,
-                                            int half, bool rev) {
+__device__ __forceinline__ void load_ctiles(f32x4 (&x)[TD], const float* __restrict__ base, int64_t row, int d, int q,
+                                            bool rev) {
     const float* r = base + row * d;
 #pragma unroll
-    for (int m = 0; m < TD; ++m) x[m] = rev ? vec_tile_rev(r, m, half, d) : vec_tile(r, m, half);
+    for (int m = 0; m < TD; ++m) x[m] = rev ? vec_tile_rev(r, m, q, d) : vec_tile(r, m, q);
 }
 
 template <int TD>
-__device__ __forceinline__ void store_ctiles(const f32x16 (&x)[TD], float* __restrict__ base, int64_t row, int d,
-                                             int half, bool rev) {
+__device__ __forceinline__ void store_ctiles(const f32x4 (&x)[TD], float* __restrict__ base, int64_t row, int d,
+                                             int q, bool rev) {
     float* r = base + row * d;
 #pragma unroll
     for (int m = 0; m < TD; ++m) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int p0 = 32 * m + 8 * q + 4 * half;
+        const int p0 = 16 * m + 4 * q;
+        if (!rev) {
+            *reinterpret_cast<f32x4*>(r + p0) = x[m];
+        } else {
             f32x4 a;
-            if (!rev) {
-                a[0] = x[m][4 * q + 0];
-                a[1] = x[m][4 * q + 1];
-                a[2] = x[m][4 * q + 2];
-                a[3] = x[m][4 * q + 3];
-                *reinterpret_cast<f32x4*>(r + p0) = a;
-            } else {
-                a[3] = x[m][4 * q + 0];
-                a[2] = x[m][4 * q + 1];
-                a[1] = x[m][4 * q + 2];
-                a[0] = x[m][4 * q + 3];
-                *reinterpret_cast<f32x4*>(r + (d - 4 - p0)) = a;
-            }
+            a[3] = x[m][0];
+            a[2] = x[m][1];
+            a[1] = x[m][2];
+            a[0] = x[m][3];
+            *reinterpret_cast<f32x4*>(r + (d - 4 - p0)) = a;
         }
     }
 }
 
-__device__ __forceinline__ float sum16(const f32x16& v) {
-    float s = 0.f;
-#pragma unroll
-    for (int t = 0; t < 16; ++t) s += v[t];
-    return s;
-}
-
-__device__ __forceinline__ float pair_sum(float v) { return v + __shfl_xor(v, 32, kWave); }  // both halves of a chain
-
-__device__ __forceinline__ f32x16 tanh16(f32x16 v) {
-#pragma unroll
-    for (int t = 0; t < 16; ++t) v[t] = fast_tanh(v[t]);
+// sum over the four lanes (q = 0..3) that share a chain
+__device__ __forceinline__ float chain_sum(float v) {
+    v += __shfl_xor(v, 16, kWave);
+    v += __shfl_xor(v, 32, kWave);
     return v;
 }
 
-// LDS carve-up (floats): two weight images of 128 x 132 and a 256-float vector area
+__device__ __forceinline__ f32x4 tanh4(f32x4 v) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) v[t] = fast_tanh(v[t]);
+    return v;
+}
+
+// LDS carve-up: two weight images of 128 x 132 floats, a 256-float vector area, per-wave statistics
 constexpr int kImgFloats = 128 * 132;
 constexpr int kVecFloats = 256;
-constexpr int kMfmaStatDoubles = 4 * (2 * 128 + 2);
+constexpr int kMfmaStatDoubles = kMfmaWaves * (2 * 128 + 2);
 constexpr size_t kMfmaLdsBytes = (size_t)(2 * kImgFloats + kVecFloats) * sizeof(float) + kMfmaStatDoubles * sizeof(double);
 
-// entry points of neutra_mfma.hip used by the C ABI in neutra_kernels.hip / flow_kernels.hip
+// entry points of neutra_mfma.hip used by the C ABI in neutra_kernels.hip
 int nfmc_mfma_supported(int32_t d, int32_t n_hidden, int32_t n_hidden_layers);
 int nfmc_neutra_potential_grad_mfma_f32(const NfmcRealNVP* flow, const NfmcPotential* pot, const float* z, int64_t n,
                                         float* u_out, float* grad_out, nfmc_stream_t stream);
@@ -194,31 +188,31 @@ int nfmc_neutra_hmc_steps_mfma_f32(const NfmcNeutraHmcArgs* args, float* scratch
                                    nfmc_stream_t stream);
 
 // Conditioner hidden stack in C layout: h1 = tanh(W1 x_src + b1), h2 = tanh(Wh h1 + bh).  Workgroup-collective
-// (stages weights, barriers inside).  `src` are the TD/2 source tiles of the layer input.
+// (stages weights, barriers inside).  `src` are the source tiles of the layer input (TS = d_a / 16).
 template <int TS, int TH, int NHL>
-__device__ __forceinline__ void hidden_stack(const f32x16 (&src)[TS], f32x16 (&h1)[TH], f32x16 (&h2)[TH],
-                                             const MLayer& L, int hp, int d_a, bool rev, float* img0, float* vec,
-                                             int col, int half) {
+__device__ __forceinline__ void hidden_stack(const f32x4 (&src)[TS], f32x4 (&h1)[TH], f32x4 (&h2)[TH], const MLayer& L,
+                                             bool rev, float* img0, float* vec, int col, int q) {
+    constexpr int hp = 16 * TH, d_a = 16 * TS;
     __syncthreads();
-    stage_matrix(img0, L.W1, hp, d_a, false, 1, rev, d_a);
-    stage_vector(vec, L.b1, hp, false, 1);
+    stage_matrix<d_a, 1, d_a>(img0, L.W1, hp, false, rev);
+    stage_vector<1>(vec, L.b1, hp, false);
     __syncthreads();
 #pragma unroll
     for (int mo = 0; mo < TH; ++mo) {
-        h1[mo] = vec_tile(vec, mo, half);
-        gemm_tile<TS>(h1[mo], img0 + (32 * mo + col) * (d_a + 4) + 4 * half, src);
-        h1[mo] = tanh16(h1[mo]);
+        h1[mo] = vec_tile(vec, mo, q);
+        gemm_tile<TS>(h1[mo], img0 + (16 * mo + col) * (d_a + 4) + 4 * q, src);
+        h1[mo] = tanh4(h1[mo]);
     }
     if constexpr (NHL > 1) {
         __syncthreads();
-        stage_matrix(img0, L.Wh, hp, hp, false, 1, false, 1);
-        stage_vector(vec, L.bh, hp, false, 1);
+        stage_matrix<hp, 1, 1>(img0, L.Wh, hp, false, false);
+        stage_vector<1>(vec, L.bh, hp, false);
         __syncthreads();
 #pragma unroll
         for (int mo = 0; mo < TH; ++mo) {
-            h2[mo] = vec_tile(vec, mo, half);
-            gemm_tile<TH>(h2[mo], img0 + (32 * mo + col) * (hp + 4) + 4 * half, h1);
-            h2[mo] = tanh16(h2[mo]);
+            h2[mo] = vec_tile(vec, mo, q);
+            gemm_tile<TH>(h2[mo], img0 + (16 * mo + col) * (hp + 4) + 4 * q, h1);
+            h2[mo] = tanh4(h2[mo]);
         }
     }
 }

@@ -2,6 +2,7 @@
 // NeuTra-HMC leapfrog around it, for RealNVP conditioners of width 33..128 (BASELINE config 4: d = 128,
 // n_hidden = 128).  Layout and GEMM scheme: mfma_device.hpp.  Replaces neutra.py:58-68 + hmc.py:40-77,96-126.
 //
+// 16 chains per wave (v_mfma_f32_16x16x4_f32), 8 waves = 128 chains per workgroup, two waves per SIMD.
 // One trajectory = n_leapfrog launches of `neutra_leapfrog_mfma_kernel`; the first also draws the
 // momentum and records H0, the last also does the Hamiltonian test, the masked update and the statistics.
 // Between launches zq / p / grad live in caller-supplied scratch (HBM): 3 tiles read + 3 written per
@@ -12,76 +13,76 @@ namespace nfmc {
 
 // ---- closed-form potential and gradient in C layout (tile position = coordinate of x)
 template <int TD>
-__device__ __forceinline__ float potential_value_grad_c(const f32x16 (&x)[TD], f32x16 (&g)[TD], const NfmcPotential& p,
+__device__ __forceinline__ float potential_value_grad_c(const f32x4 (&x)[TD], f32x4 (&g)[TD], const NfmcPotential& p,
                                                         int half, int lane) {
-    constexpr int d = 32 * TD;
+    constexpr int d = 16 * TD;
     if (p.kind == NFMC_POT_FUNNEL) {
-        const float x0 = __shfl(x[0][0], lane & 31, kWave);  // coordinate 0 = tile 0, reg 0, half 0
+        const float x0 = __shfl(x[0][0], lane & 15, kWave);  // coordinate 0 = tile 0, reg 0, lane group 0
         float s = 0.f;
 #pragma unroll
         for (int m = 0; m < TD; ++m)
 #pragma unroll
-            for (int t = 0; t < 16; ++t) s = fmaf(x[m][t], (m == 0 && t == 0 && half == 0) ? 0.f : x[m][t], s);
-        s = pair_sum(s);
+            for (int t = 0; t < 4; ++t) s = fmaf(x[m][t], (m == 0 && t == 0 && half == 0) ? 0.f : x[m][t], s);
+        s = chain_sum(s);
         const float inv_s2 = 1.f / (p.a_scalar * p.a_scalar);
         const float e = fast_exp(-x0);
         const float hd = 0.5f * (float)(d - 1);
 #pragma unroll
         for (int m = 0; m < TD; ++m)
 #pragma unroll
-            for (int t = 0; t < 16; ++t) g[m][t] = x[m][t] * e;
+            for (int t = 0; t < 4; ++t) g[m][t] = x[m][t] * e;
         if (half == 0) g[0][0] = x0 * inv_s2 - 0.5f * e * s + hd;
         return 0.5f * x0 * x0 * inv_s2 + 0.5f * e * s + hd * x0;
     }
     float u = 0.f;
 #pragma unroll
     for (int m = 0; m < TD; ++m) {
-        f32x16 a, b;
+        f32x4 a, b;
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
+        for (int t = 0; t < 4; ++t) {
             a[t] = p.a_scalar;
             b[t] = p.b_scalar;
         }
         if (p.a) a = vec_tile(p.a, m, half);
         if (p.b) b = vec_tile(p.b, m, half);
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
+        for (int t = 0; t < 4; ++t) {
             const float dlt = x[m][t] - b[t];
             u = fmaf(a[t] * dlt, dlt, u);
             g[m][t] = 2.f * a[t] * dlt;
         }
     }
-    return pair_sum(u);
+    return chain_sum(u);
 }
 
 // ---- inverse coupling layer, forward sweep (v -> y): returns this lane's share of the layer's logdet_inverse
 template <int TD, int TH, int NHL, bool REV>
-__device__ __forceinline__ float coupling_inverse_c(f32x16 (&x)[TD], const MLayer& L, float mscale, float log1m,
+__device__ __forceinline__ float coupling_inverse_c(f32x4 (&x)[TD], const MLayer& L, float mscale, float log1m,
                                                     float* lds, int col, int half) {
-    constexpr int TS = TD / 2, SRC0 = REV ? TS : 0, TGT0 = REV ? 0 : TS, D2 = 16 * TD, hp = 32 * TH;
+    constexpr int TS = TD / 2, SRC0 = REV ? TS : 0, TGT0 = REV ? 0 : TS, D2 = 8 * TD, hp = 16 * TH;
     float* img0 = lds;
     float* vec = lds + 2 * kImgFloats;
-    f32x16 src[TS], h1[TH], h2[TH];
+    f32x4 src[TS], h1[TH], h2[TH];
 #pragma unroll
     for (int ms = 0; ms < TS; ++ms) src[ms] = x[SRC0 + ms];
-    hidden_stack<TS, TH, NHL>(src, h1, h2, L, hp, D2, REV, img0, vec, col, half);
+    hidden_stack<TS, TH, NHL>(src, h1, h2, L, REV, img0, vec, col, half);
     __syncthreads();
-    stage_matrix(img0, L.W3, 2 * D2, hp, REV, D2, false, 1);
-    stage_vector(vec, L.b3, 2 * D2, REV, D2);
+    stage_matrix<hp, D2, 1>(img0, L.W3, 2 * D2, REV, false);
+    stage_vector<D2>(vec, L.b3, 2 * D2, REV);
     __syncthreads();
     float ld = 0.f;
 #pragma unroll
     for (int mt = 0; mt < TS; ++mt) {
-        f32x16 ua = vec_tile(vec, mt, half), ub = vec_tile(vec, TS + mt, half);
+        f32x4 ua = vec_tile(vec, mt, half), ub = vec_tile(vec, TS + mt, half);
         if constexpr (NHL > 1) {
-            gemm_tile<TH>(ua, img0 + (32 * mt + col) * (hp + 4) + 4 * half, h2);
-            gemm_tile<TH>(ub, img0 + (32 * (TS + mt) + col) * (hp + 4) + 4 * half, h2);
+            gemm_tile<TH>(ua, img0 + (16 * mt + col) * (hp + 4) + 4 * half, h2);
+            gemm_tile<TH>(ub, img0 + (16 * (TS + mt) + col) * (hp + 4) + 4 * half, h2);
         } else {
-            gemm_tile<TH>(ua, img0 + (32 * mt + col) * (hp + 4) + 4 * half, h1);
-            gemm_tile<TH>(ub, img0 + (32 * (TS + mt) + col) * (hp + 4) + 4 * half, h1);
+            gemm_tile<TH>(ua, img0 + (16 * mt + col) * (hp + 4) + 4 * half, h1);
+            gemm_tile<TH>(ub, img0 + (16 * (TS + mt) + col) * (hp + 4) + 4 * half, h1);
         }
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
+        for (int t = 0; t < 4; ++t) {
             const float alpha = fast_exp(fmaf(0.5f, ua[t], log1m)) + mscale;
             x[TGT0 + mt][t] = (x[TGT0 + mt][t] - 0.5f * ub[t]) * __builtin_amdgcn_rcpf(alpha);
             ld -= fast_ln(alpha);
@@ -90,42 +91,47 @@ __device__ __forceinline__ float coupling_inverse_c(f32x16 (&x)[TD], const MLaye
     return ld;
 }
 
-// ---- reverse sweep through one inverse coupling layer: (y, dL/dy) -> (v, dL/dv); L = U(x) + sum log alpha
+// ---- reverse sweep through one inverse coupling layer: (y, dL/dy) -> (v, dL/dv); L = U(x) + sum log alpha.
+// Register budget (two waves per SIMD, 256 VGPRs): x, g and at most TWO hidden-width tile sets are live at any
+// point -- with two hidden layers the first layer's activations are not kept across the transposed products but
+// rebuilt tile by tile where tanh' is needed (one extra W1 product, +7 % multiply-adds, instead of 32 registers).
 template <int TD, int TH, int NHL, bool REV>
-__device__ __forceinline__ void coupling_inverse_backward_c(f32x16 (&x)[TD], f32x16 (&g)[TD], const MLayer& L,
+__device__ __forceinline__ void coupling_inverse_backward_c(f32x4 (&x)[TD], f32x4 (&g)[TD], const MLayer& L,
                                                             float mscale, float log1m, float* lds, int col,
                                                             int half) {
-    constexpr int TS = TD / 2, SRC0 = REV ? TS : 0, TGT0 = REV ? 0 : TS, D2 = 16 * TD, hp = 32 * TH;
+    constexpr int TS = TD / 2, SRC0 = REV ? TS : 0, TGT0 = REV ? 0 : TS, D2 = 8 * TD, hp = 16 * TH;
     float* img0 = lds;
     float* img1 = lds + kImgFloats;
     float* vec = lds + 2 * kImgFloats;
-    f32x16 src[TS], h1[TH], h2[TH];
+    f32x4 hl[TH];   // activations of the LAST hidden layer
+    {
+        f32x4 src[TS], h1[TH];
 #pragma unroll
-    for (int ms = 0; ms < TS; ++ms) src[ms] = x[SRC0 + ms];
-    hidden_stack<TS, TH, NHL>(src, h1, h2, L, hp, D2, REV, img0, vec, col, half);
+        for (int ms = 0; ms < TS; ++ms) src[ms] = x[SRC0 + ms];
+        if constexpr (NHL > 1) {
+            hidden_stack<TS, TH, NHL>(src, h1, hl, L, REV, img0, vec, col, half);
+        } else {
+            hidden_stack<TS, TH, NHL>(src, hl, h1, L, REV, img0, vec, col, half);
+        }
+    }
     __syncthreads();
-    stage_matrix(img0, L.W3, 2 * D2, hp, REV, D2, false, 1);
-    stage_matrix(img1, L.W3T, hp, 2 * D2, false, 1, REV, D2);
-    stage_vector(vec, L.b3, 2 * D2, REV, D2);
+    stage_matrix<hp, D2, 1>(img0, L.W3, 2 * D2, REV, false);
+    stage_matrix<2 * D2, 1, D2>(img1, L.W3T, hp, false, REV);
+    stage_vector<D2>(vec, L.b3, 2 * D2, REV);
     __syncthreads();
-    f32x16 dh[TH];
+    f32x4 dh[TH];
 #pragma unroll
     for (int mo = 0; mo < TH; ++mo)
 #pragma unroll
-        for (int t = 0; t < 16; ++t) dh[mo][t] = 0.f;
+        for (int t = 0; t < 4; ++t) dh[mo][t] = 0.f;
 #pragma unroll
     for (int mt = 0; mt < TS; ++mt) {
-        f32x16 ua = vec_tile(vec, mt, half), ub = vec_tile(vec, TS + mt, half);
-        if constexpr (NHL > 1) {
-            gemm_tile<TH>(ua, img0 + (32 * mt + col) * (hp + 4) + 4 * half, h2);
-            gemm_tile<TH>(ub, img0 + (32 * (TS + mt) + col) * (hp + 4) + 4 * half, h2);
-        } else {
-            gemm_tile<TH>(ua, img0 + (32 * mt + col) * (hp + 4) + 4 * half, h1);
-            gemm_tile<TH>(ub, img0 + (32 * (TS + mt) + col) * (hp + 4) + 4 * half, h1);
-        }
-        f32x16 du[1], dv[1];
+        f32x4 ua = vec_tile(vec, mt, half), ub = vec_tile(vec, TS + mt, half);
+        gemm_tile<TH>(ua, img0 + (16 * mt + col) * (hp + 4) + 4 * half, hl);
+        gemm_tile<TH>(ub, img0 + (16 * (TS + mt) + col) * (hp + 4) + 4 * half, hl);
+        f32x4 du[1], dv[1];
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
+        for (int t = 0; t < 4; ++t) {
             const float alpha = fast_exp(fmaf(0.5f, ua[t], log1m)) + mscale;
             const float beta = 0.5f * ub[t];
             const float ra = __builtin_amdgcn_rcpf(alpha);
@@ -139,56 +145,61 @@ __device__ __forceinline__ void coupling_inverse_backward_c(f32x16 (&x)[TD], f32
         }
 #pragma unroll
         for (int mo = 0; mo < TH; ++mo) {  // dh += W3^T[:, alpha rows of tile mt] du + W3^T[:, beta rows] dv
-            const float* arow = img1 + (32 * mo + col) * (2 * D2 + 4) + 4 * half;
-            gemm_tile<1>(dh[mo], arow + 32 * mt, du);
-            gemm_tile<1>(dh[mo], arow + D2 + 32 * mt, dv);
+            const float* arow = img1 + (16 * mo + col) * (2 * D2 + 4) + 4 * half;
+            gemm_tile<1>(dh[mo], arow + 16 * mt, du);
+            gemm_tile<1>(dh[mo], arow + D2 + 16 * mt, dv);
         }
     }
-    // back through the hidden stack (weights in the transposed orientation)
+#pragma unroll
+    for (int mo = 0; mo < TH; ++mo)   // through tanh of the last hidden layer; its activations die here
+#pragma unroll
+        for (int t = 0; t < 4; ++t) dh[mo][t] *= (1.f - hl[mo][t] * hl[mo][t]);
     if constexpr (NHL > 1) {
-#pragma unroll
-        for (int mo = 0; mo < TH; ++mo)
-#pragma unroll
-            for (int t = 0; t < 16; ++t) dh[mo][t] *= (1.f - h2[mo][t] * h2[mo][t]);
+        // dL/dh1 = Wh^T dpre2, then tanh'(pre1) with h1 = tanh(W1 src + b1) rebuilt one tile at a time
         __syncthreads();
-        stage_matrix(img0, L.WhT, hp, hp, false, 1, false, 1);
+        stage_matrix<hp, 1, 1>(img0, L.WhT, hp, false, false);
+        stage_matrix<D2, 1, D2>(img1, L.W1, hp, false, REV);
+        stage_vector<1>(vec, L.b1, hp, false);
         __syncthreads();
-        f32x16 d1[TH];
+        f32x4 src[TS];
+#pragma unroll
+        for (int ms = 0; ms < TS; ++ms) src[ms] = x[SRC0 + ms];
 #pragma unroll
         for (int mo = 0; mo < TH; ++mo) {
+            f32x4 acc, h1t = vec_tile(vec, mo, half);
 #pragma unroll
-            for (int t = 0; t < 16; ++t) d1[mo][t] = 0.f;
-            gemm_tile<TH>(d1[mo], img0 + (32 * mo + col) * (hp + 4) + 4 * half, dh);
+            for (int t = 0; t < 4; ++t) acc[t] = 0.f;
+            gemm_tile<TH>(acc, img0 + (16 * mo + col) * (hp + 4) + 4 * half, dh);
+            gemm_tile<TS>(h1t, img1 + (16 * mo + col) * (D2 + 4) + 4 * half, src);
+            h1t = tanh4(h1t);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) hl[mo][t] = acc[t] * (1.f - h1t[t] * h1t[t]);
         }
 #pragma unroll
-        for (int mo = 0; mo < TH; ++mo) dh[mo] = d1[mo];
+        for (int mo = 0; mo < TH; ++mo) dh[mo] = hl[mo];
     }
-#pragma unroll
-    for (int mo = 0; mo < TH; ++mo)
-#pragma unroll
-        for (int t = 0; t < 16; ++t) dh[mo][t] *= (1.f - h1[mo][t] * h1[mo][t]);
     __syncthreads();
-    stage_matrix(img0, L.W1T, D2, hp, REV, D2, false, 1);
+    stage_matrix<hp, D2, 1>(img0, L.W1T, D2, REV, false);
     __syncthreads();
 #pragma unroll
-    for (int ms = 0; ms < TS; ++ms) gemm_tile<TH>(g[SRC0 + ms], img0 + (32 * ms + col) * (hp + 4) + 4 * half, dh);
+    for (int ms = 0; ms < TS; ++ms) gemm_tile<TH>(g[SRC0 + ms], img0 + (16 * ms + col) * (hp + 4) + 4 * half, dh);
 }
 
-// ---- U~(z), grad U~(z) for the wave's 32 chains.  x: in z (tile positions in latent order), out z again
+// ---- U~(z), grad U~(z) for the wave's 16 chains.  x: in z (tile positions in latent order), out z again
 // (rebuilt through the inverse of every step); g: gradient in the same positions.  Workgroup-collective.
 template <int TD, int TH, int NHL>
-__device__ __forceinline__ float adjusted_grad_c(f32x16 (&x)[TD], f32x16 (&g)[TD], const NfmcRealNVP& f,
+__device__ __forceinline__ float adjusted_grad_c(f32x4 (&x)[TD], f32x4 (&g)[TD], const NfmcRealNVP& f,
                                                  const NfmcPotential& pot, float* lds, int col, int half, int lane) {
-    constexpr int d = 32 * TD, hp = 32 * TH;
+    constexpr int d = 16 * TD, hp = 16 * TH;
     const bool rev_last = (f.n_coupling & 1) != 0;
     const float log1m = __logf(1.f - f.min_scale);
     float ldp = 0.f;
 #pragma unroll
     for (int m = 0; m < TD; ++m) {  // EA1^-1
-        const f32x16 ls = rev_last ? vec_tile_rev(f.ea1_log_scale, m, half, d) : vec_tile(f.ea1_log_scale, m, half);
-        const f32x16 sh = rev_last ? vec_tile_rev(f.ea1_shift, m, half, d) : vec_tile(f.ea1_shift, m, half);
+        const f32x4 ls = rev_last ? vec_tile_rev(f.ea1_log_scale, m, half, d) : vec_tile(f.ea1_log_scale, m, half);
+        const f32x4 sh = rev_last ? vec_tile_rev(f.ea1_shift, m, half, d) : vec_tile(f.ea1_shift, m, half);
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
+        for (int t = 0; t < 4; ++t) {
             x[m][t] = (x[m][t] - sh[t]) * fast_exp(-ls[t]);
             ldp -= ls[t];
         }
@@ -200,9 +211,9 @@ __device__ __forceinline__ float adjusted_grad_c(f32x16 (&x)[TD], f32x16 (&g)[TD
     }
 #pragma unroll
     for (int m = 0; m < TD; ++m) {  // EA0^-1
-        const f32x16 ls = vec_tile(f.ea0_log_scale, m, half), sh = vec_tile(f.ea0_shift, m, half);
+        const f32x4 ls = vec_tile(f.ea0_log_scale, m, half), sh = vec_tile(f.ea0_shift, m, half);
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
+        for (int t = 0; t < 4; ++t) {
             x[m][t] = (x[m][t] - sh[t]) * fast_exp(-ls[t]);
             ldp -= ls[t];
         }
@@ -211,9 +222,9 @@ __device__ __forceinline__ float adjusted_grad_c(f32x16 (&x)[TD], f32x16 (&g)[TD
     // reverse sweep
 #pragma unroll
     for (int m = 0; m < TD; ++m) {
-        const f32x16 ls = vec_tile(f.ea0_log_scale, m, half), sh = vec_tile(f.ea0_shift, m, half);
+        const f32x4 ls = vec_tile(f.ea0_log_scale, m, half), sh = vec_tile(f.ea0_shift, m, half);
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
+        for (int t = 0; t < 4; ++t) {
             g[m][t] *= fast_exp(-ls[t]);
             x[m][t] = fmaf(fast_exp(ls[t]), x[m][t], sh[t]);
         }
@@ -225,33 +236,33 @@ __device__ __forceinline__ float adjusted_grad_c(f32x16 (&x)[TD], f32x16 (&g)[TD
     }
 #pragma unroll
     for (int m = 0; m < TD; ++m) {
-        const f32x16 ls = rev_last ? vec_tile_rev(f.ea1_log_scale, m, half, d) : vec_tile(f.ea1_log_scale, m, half);
-        const f32x16 sh = rev_last ? vec_tile_rev(f.ea1_shift, m, half, d) : vec_tile(f.ea1_shift, m, half);
+        const f32x4 ls = rev_last ? vec_tile_rev(f.ea1_log_scale, m, half, d) : vec_tile(f.ea1_log_scale, m, half);
+        const f32x4 sh = rev_last ? vec_tile_rev(f.ea1_shift, m, half, d) : vec_tile(f.ea1_shift, m, half);
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
+        for (int t = 0; t < 4; ++t) {
             g[m][t] *= fast_exp(-ls[t]);
             x[m][t] = fmaf(fast_exp(ls[t]), x[m][t], sh[t]);
         }
     }
-    return u - pair_sum(ldp);
+    return u - chain_sum(ldp);
 }
 
 // ------------------------------------------------------------------------------------------------
 template <int TD, int TH, int NHL>
-__global__ void __launch_bounds__(kMfmaBlock) neutra_grad_mfma_kernel(NfmcRealNVP f, NfmcPotential pot,
+__global__ void __launch_bounds__(kMfmaBlock, 2) neutra_grad_mfma_kernel(NfmcRealNVP f, NfmcPotential pot,
                                                                       const float* __restrict__ z, int64_t n,
                                                                       float* __restrict__ u_out,
                                                                       float* __restrict__ grad_out, int64_t tiles) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int d = 32 * TD;
+    constexpr int d = 16 * TD;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int col = lane & 31, half = lane >> 5;
+    const int col = lane & 15, half = lane >> 4;
     const bool rev = (f.n_coupling & 1) != 0;
     for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        const int64_t row = tile * kMfmaChains + wave * 32 + col;
+        const int64_t row = tile * kMfmaChains + wave * 16 + col;
         const bool active = row < n;
         const int64_t rrow = active ? row : n - 1;
-        f32x16 x[TD], g[TD];
+        f32x4 x[TD], g[TD];
         load_ctiles<TD>(x, z, rrow, d, half, rev);
         const float u = adjusted_grad_c<TD, TH, NHL>(x, g, f, pot, lds, col, half, lane);
         if (active) {
@@ -270,100 +281,101 @@ struct LeapArgs {
 
 // mass / momentum helpers in C layout: tile position pos <-> logical latent coordinate (rev ? d-1-pos : pos)
 template <int TD>
-__device__ __forceinline__ void mass_tiles(f32x16 (&m)[TD], const float* imd, int half, bool rev) {
-    constexpr int d = 32 * TD;
+__device__ __forceinline__ void mass_tiles(f32x4 (&m)[TD], const float* imd, int half, bool rev) {
+    constexpr int d = 16 * TD;
 #pragma unroll
     for (int k = 0; k < TD; ++k) {
         if (imd) m[k] = rev ? vec_tile_rev(imd, k, half, d) : vec_tile(imd, k, half);
         else
 #pragma unroll
-            for (int t = 0; t < 16; ++t) m[k][t] = 1.f;
+            for (int t = 0; t < 4; ++t) m[k][t] = 1.f;
     }
 }
 
 template <int TD, int TH, int NHL>
-__global__ void __launch_bounds__(kMfmaBlock) neutra_leapfrog_mfma_kernel(LeapArgs A, int64_t tiles, int dp) {
+__global__ void __launch_bounds__(kMfmaBlock, 2) neutra_leapfrog_mfma_kernel(LeapArgs A, int64_t tiles, int dp) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int d = 32 * TD;
+    constexpr int d = 16 * TD;
     const NfmcNeutraHmcArgs& a = A.a;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int col = lane & 31, half = lane >> 5;
+    const int col = lane & 15, half = lane >> 4;
     const bool rev = (a.flow.n_coupling & 1) != 0;
     const int64_t n = a.n;
     const float h = a.step_size, hh = a.step_size / 2;
     const int s = A.step;
 
     // statistics accumulate in LDS behind the weight images (nothing extra stays live across the GEMMs)
-    double* red = reinterpret_cast<double*>(lds + 2 * kImgFloats + kVecFloats);  // [4 waves][2*d + 2]
+    double* red = reinterpret_cast<double*>(lds + 2 * kImgFloats + kVecFloats);  // [8 waves][2*d + 2]
     uint32_t n_acc = 0, n_bad = 0;
     if (A.last) {
-        for (int i = threadIdx.x; i < 4 * (2 * d + 2); i += kMfmaBlock) red[i] = 0.0;
+        for (int i = threadIdx.x; i < kMfmaWaves * (2 * d + 2); i += kMfmaBlock) red[i] = 0.0;
         __syncthreads();
     }
 
     for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        const int64_t row = tile * kMfmaChains + wave * 32 + col;
-        const bool active = row < n;
-        const int64_t rrow = active ? row : n - 1;
-        f32x16 x[TD], g[TD], mass[TD];
-        mass_tiles<TD>(mass, a.inv_mass_diag, half, rev);
+        const int64_t row_in = tile * kMfmaChains + wave * 16 + col;
+        const bool active = row_in < n;
+        const int64_t rrow_in = active ? row_in : n - 1;
+        f32x4 x[TD], g[TD];
         {
-            f32x16 p[TD];
+            f32x4 p[TD], mass[TD];
+            mass_tiles<TD>(mass, a.inv_mass_diag, half, rev);
             if (A.first) {
-                load_ctiles<TD>(x, a.z, rrow, d, half, rev);
-                load_ctiles<TD>(g, A.gz, rrow, d, half, rev);
+                load_ctiles<TD>(x, a.z, rrow_in, d, half, rev);
+                load_ctiles<TD>(g, A.gz, rrow_in, d, half, rev);
                 float kin = 0.f;
-                const uint32_t gchain = (uint32_t)(a.rng.chain_offset + (uint64_t)rrow);
+                const uint32_t gchain = (uint32_t)(a.rng.chain_offset + (uint64_t)rrow_in);
 #pragma unroll
                 for (int m = 0; m < TD; ++m) {
+                    const int p0 = 16 * m + 4 * half;  // tile position of this lane's 4-block (= one Philox block)
+                    float zz[4];
+                    if (a.rng.replay_normals) {
+                        const float* src = a.rng.replay_normals + ((int64_t)s * n + rrow_in) * d;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int p0 = 32 * m + 8 * q + 4 * half;  // tile position of this 4-block
-                        float zz[4];
-                        if (a.rng.replay_normals) {
-                            const float* src = a.rng.replay_normals + ((int64_t)s * n + rrow) * d;
+                        for (int j = 0; j < 4; ++j) zz[j] = src[rev ? d - 1 - (p0 + j) : p0 + j];
+                    } else {
+                        const int blk = rev ? (d - 4 - p0) >> 2 : p0 >> 2;
+                        float w[4];
+                        philox_normal4(gchain, a.rng.step0 + (uint32_t)s, (uint32_t)blk, kTagNoise, (uint32_t)a.rng.seed,
+                                       (uint32_t)(a.rng.seed >> 32), w);
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) zz[j] = src[rev ? d - 1 - (p0 + j) : p0 + j];
-                        } else {
-                            const int blk = rev ? (d - 4 - p0) >> 2 : p0 >> 2;
-                            float w[4];
-                            philox_normal4(gchain, a.rng.step0 + (uint32_t)s, (uint32_t)blk, kTagNoise,
-                                           (uint32_t)a.rng.seed, (uint32_t)(a.rng.seed >> 32), w);
+                        for (int j = 0; j < 4; ++j) zz[j] = rev ? w[3 - j] : w[j];
+                    }
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) zz[j] = rev ? w[3 - j] : w[j];
-                        }
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float mm = mass[m][4 * q + j];
-                            const float v = zz[j] * (1.f / sqrtf(mm));   // hmc.py:100
-                            p[m][4 * q + j] = v;
-                            kin = fmaf(v * v, mm, kin);
-                        }
+                    for (int j = 0; j < 4; ++j) {
+                        const float mm = mass[m][j];
+                        const float v = zz[j] * (1.f / sqrtf(mm));   // hmc.py:100
+                        p[m][j] = v;
+                        kin = fmaf(v * v, mm, kin);
                     }
                 }
-                kin = pair_sum(kin);
-                if (active && half == 0) A.h0[row] = A.uz[row] + 0.5f * kin;  // hmc.py:103-106
+                kin = chain_sum(kin);
+                if (active && half == 0) A.h0[row_in] = A.uz[row_in] + 0.5f * kin;  // hmc.py:103-106
             } else {
-                load_ctiles<TD>(x, A.zq, rrow, d, half, rev);
-                load_ctiles<TD>(g, A.g, rrow, d, half, rev);
-                load_ctiles<TD>(p, A.p, rrow, d, half, rev);
+                load_ctiles<TD>(x, A.zq, rrow_in, d, half, rev);
+                load_ctiles<TD>(g, A.g, rrow_in, d, half, rev);
+                load_ctiles<TD>(p, A.p, rrow_in, d, half, rev);
             }
 #pragma unroll
             for (int m = 0; m < TD; ++m)
 #pragma unroll
-                for (int t = 0; t < 16; ++t) {  // hmc.py:68-70
+                for (int t = 0; t < 4; ++t) {  // hmc.py:68-70
                     p[m][t] = fmaf(-hh, g[m][t], p[m][t]);
                     x[m][t] = fmaf(h, p[m][t] * mass[m][t], x[m][t]);
                 }
-            if (active) store_ctiles<TD>(p, A.p, row, d, half, rev);  // momentum is not live across the GEMMs
+            if (active) store_ctiles<TD>(p, A.p, row_in, d, half, rev);  // momentum is not live across the GEMMs
         }
         const float u = adjusted_grad_c<TD, TH, NHL>(x, g, a.flow, a.pot, lds, col, half, lane);
-        f32x16 p[TD];
+        // everything below addresses HBM by the row index: an opaque copy keeps that address arithmetic from
+        // being computed before the gradient and held in registers through it (cf. stage_matrix)
+        int64_t row = row_in, rrow = rrow_in;
+        asm volatile("" : "+v"(row), "+v"(rrow));
+        f32x4 p[TD];
         load_ctiles<TD>(p, A.p, rrow, d, half, rev);
 #pragma unroll
         for (int m = 0; m < TD; ++m)
 #pragma unroll
-            for (int t = 0; t < 16; ++t) p[m][t] = fmaf(-hh, g[m][t], p[m][t]);  // hmc.py:71
+            for (int t = 0; t < 4; ++t) p[m][t] = fmaf(-hh, g[m][t], p[m][t]);  // hmc.py:71
         if (!A.last) {
             if (active) {
                 store_ctiles<TD>(x, A.zq, row, d, half, rev);
@@ -377,11 +389,13 @@ __global__ void __launch_bounds__(kMfmaBlock) neutra_leapfrog_mfma_kernel(LeapAr
         float lr = 0.f;
         if (a.adjust) {
             float kin = 0.f;
+            f32x4 mass[TD];
+            mass_tiles<TD>(mass, a.inv_mass_diag, half, rev);
 #pragma unroll
             for (int m = 0; m < TD; ++m)
 #pragma unroll
-                for (int t = 0; t < 16; ++t) kin = fmaf(p[m][t] * p[m][t], mass[m][t], kin);
-            kin = pair_sum(kin);
+                for (int t = 0; t < 4; ++t) kin = fmaf(p[m][t] * p[m][t], mass[m][t], kin);
+            kin = chain_sum(kin);
             lr = A.h0[rrow] - (u + 0.5f * kin);  // hmc.py:107-111
             float uni;
             if (a.rng.replay_uniforms) {
@@ -396,7 +410,7 @@ __global__ void __launch_bounds__(kMfmaBlock) neutra_leapfrog_mfma_kernel(LeapAr
             if (active && half == 0 && !(fabsf(lr) <= 3.0e38f)) n_bad++;
         }
         accept = accept && active;
-        f32x16 zc[TD];
+        f32x4 zc[TD];
         if (accept) {
 #pragma unroll
             for (int m = 0; m < TD; ++m) zc[m] = x[m];
@@ -416,19 +430,19 @@ __global__ void __launch_bounds__(kMfmaBlock) neutra_leapfrog_mfma_kernel(LeapAr
             }
             if (a.samples) store_ctiles<TD>(zc, a.samples + (int64_t)s * n * d, row, d, half, rev);
         }
-        if (a.stats.sum_x) {  // sums over the 32 chains of the wave (lanes with equal half), kept per wave in LDS
+        if (a.stats.sum_x) {  // sums over the 16 chains of the wave (lanes of one lane group), kept per wave in LDS
 #pragma unroll
             for (int m = 0; m < TD; ++m)
 #pragma unroll
-                for (int t = 0; t < 16; ++t) {
+                for (int t = 0; t < 4; ++t) {
                     const float zv = active ? zc[m][t] : 0.f;
                     double v1 = (double)zv, v2 = (double)zv * (double)zv;
-                    for (int k = 1; k < 32; k <<= 1) {
+                    for (int k = 1; k < 16; k <<= 1) {
                         v1 += __shfl_xor(v1, k, kWave);
                         v2 += __shfl_xor(v2, k, kWave);
                     }
                     if (col == 0) {
-                        const int pos = 32 * m + (t & 3) + 8 * (t >> 2) + 4 * half;
+                        const int pos = 16 * m + 4 * half + t;
                         const int c = rev ? d - 1 - pos : pos;  // logical latent coordinate
                         red[wave * (2 * d + 2) + c] += v1;
                         red[wave * (2 * d + 2) + d + c] += v2;
@@ -437,7 +451,7 @@ __global__ void __launch_bounds__(kMfmaBlock) neutra_leapfrog_mfma_kernel(LeapAr
         }
     }
     if (A.last && a.stats.sum_x) {
-        for (int m = 1; m < 32; m <<= 1) {
+        for (int m = 1; m < 16; m <<= 1) {   // counted on lane group 0 only
             n_acc += __shfl_xor(n_acc, m, kWave);
             n_bad += __shfl_xor(n_bad, m, kWave);
         }
@@ -455,7 +469,7 @@ __global__ void __launch_bounds__(kMfmaBlock) neutra_leapfrog_mfma_kernel(LeapAr
             else if (i == 2 * dp) srci = 2 * d;
             else if (i == 2 * dp + 1) srci = 2 * d + 1;
             if (srci >= 0)
-                for (int w = 0; w < 4; ++w) v += red[w * (2 * d + 2) + srci];
+                for (int w = 0; w < kMfmaWaves; ++w) v += red[w * (2 * d + 2) + srci];
             out[i] = v;
         }
     }
@@ -476,7 +490,7 @@ static int launch_grad(const NfmcRealNVP& f, const NfmcPotential& pot, const flo
 
 template <int TD, int TH, int NHL>
 static int run_hmc(const NfmcNeutraHmcArgs& a, float* scratch, hipStream_t st) {
-    constexpr int d = 32 * TD;
+    constexpr int d = 16 * TD;
     const int64_t n = a.n;
     LeapArgs A;
     A.a = a;
@@ -515,14 +529,14 @@ static int run_hmc(const NfmcNeutraHmcArgs& a, float* scratch, hipStream_t st) {
 using namespace nfmc;
 
 #define NFMC_MFMA_DISPATCH(TDV, THV, NHLV, CALL)                                        \
-    if (TDV == 2 && THV == 2 && NHLV == 1) { constexpr int TD = 2, TH = 2, NHL = 1; CALL; }      \
-    else if (TDV == 2 && THV == 2 && NHLV == 2) { constexpr int TD = 2, TH = 2, NHL = 2; CALL; } \
-    else if (TDV == 2 && THV == 4 && NHLV == 1) { constexpr int TD = 2, TH = 4, NHL = 1; CALL; } \
-    else if (TDV == 2 && THV == 4 && NHLV == 2) { constexpr int TD = 2, TH = 4, NHL = 2; CALL; } \
-    else if (TDV == 4 && THV == 2 && NHLV == 1) { constexpr int TD = 4, TH = 2, NHL = 1; CALL; } \
-    else if (TDV == 4 && THV == 2 && NHLV == 2) { constexpr int TD = 4, TH = 2, NHL = 2; CALL; } \
-    else if (TDV == 4 && THV == 4 && NHLV == 1) { constexpr int TD = 4, TH = 4, NHL = 1; CALL; } \
+    if (TDV == 4 && THV == 4 && NHLV == 1) { constexpr int TD = 4, TH = 4, NHL = 1; CALL; }      \
     else if (TDV == 4 && THV == 4 && NHLV == 2) { constexpr int TD = 4, TH = 4, NHL = 2; CALL; } \
+    else if (TDV == 4 && THV == 8 && NHLV == 1) { constexpr int TD = 4, TH = 8, NHL = 1; CALL; } \
+    else if (TDV == 4 && THV == 8 && NHLV == 2) { constexpr int TD = 4, TH = 8, NHL = 2; CALL; } \
+    else if (TDV == 8 && THV == 4 && NHLV == 1) { constexpr int TD = 8, TH = 4, NHL = 1; CALL; } \
+    else if (TDV == 8 && THV == 4 && NHLV == 2) { constexpr int TD = 8, TH = 4, NHL = 2; CALL; } \
+    else if (TDV == 8 && THV == 8 && NHLV == 1) { constexpr int TD = 8, TH = 8, NHL = 1; CALL; } \
+    else if (TDV == 8 && THV == 8 && NHLV == 2) { constexpr int TD = 8, TH = 8, NHL = 2; CALL; } \
     else return NFMC_EUNSUPPORTED;
 
 // shapes the matrix-core path covers
@@ -534,7 +548,7 @@ int nfmc::nfmc_neutra_potential_grad_mfma_f32(const NfmcRealNVP* flow, const Nfm
                                                    int64_t n, float* u_out, float* grad_out, nfmc_stream_t stream) {
     if (!flow || !pot || !z || n <= 0) return NFMC_EINVAL;
     if (!nfmc_mfma_supported(flow->d, flow->n_hidden, flow->n_hidden_layers)) return NFMC_EUNSUPPORTED;
-    const int td = flow->d / 32, th = nfmc_realnvp_padded_hidden(flow->n_hidden) / 32, nhl = flow->n_hidden_layers;
+    const int td = flow->d / 16, th = nfmc_realnvp_padded_hidden(flow->n_hidden) / 16, nhl = flow->n_hidden_layers;
     int rc = 0;
     NFMC_MFMA_DISPATCH(td, th, nhl, rc = (launch_grad<TD, TH, NHL>(*flow, *pot, z, n, u_out, grad_out, (hipStream_t)stream)))
     if (rc) return rc;
@@ -548,7 +562,7 @@ int nfmc::nfmc_neutra_hmc_steps_mfma_f32(const NfmcNeutraHmcArgs* args, float* s
     const NfmcNeutraHmcArgs& a = *args;
     if (!nfmc_mfma_supported(a.flow.d, a.flow.n_hidden, a.flow.n_hidden_layers)) return NFMC_EUNSUPPORTED;
     if (scratch_bytes < nfmc_neutra_scratch_bytes(a.n, a.flow.d, a.flow.n_hidden)) return NFMC_ESCRATCH;
-    const int td = a.flow.d / 32, th = nfmc_realnvp_padded_hidden(a.flow.n_hidden) / 32, nhl = a.flow.n_hidden_layers;
+    const int td = a.flow.d / 16, th = nfmc_realnvp_padded_hidden(a.flow.n_hidden) / 16, nhl = a.flow.n_hidden_layers;
     int rc = 0;
     NFMC_MFMA_DISPATCH(td, th, nhl, rc = (run_hmc<TD, TH, NHL>(a, scratch, (hipStream_t)stream)))
     return rc;

@@ -19,6 +19,7 @@ import ctypes as C
 import math
 from typing import Optional, Tuple
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -112,38 +113,50 @@ class RealNVP(nn.Module):
         if hp == 0:
             raise ValueError('RealNVP conditioner width %d is beyond the kernels (max 128)' % H)
         with torch.no_grad():
-            blobs = []
-            for cpl in self.couplings:
+            # one preallocated host buffer filled by slice copies (torch.cat of ~1e5 floats spins up the CPU
+            # thread pool: 30-40 ms per call, most of the host time of a sample() with a wide conditioner)
+            flat = np.zeros(max(1, self.n_coupling * stride), dtype=np.float32)   # numpy: single-threaded, no pool
+            for li, cpl in enumerate(self.couplings):
                 lin = list(cpl.conditioner)
-                parts = []
+                cur = [li * stride]
 
-                def padded(w, rows, cols):
-                    out = torch.zeros(rows, cols)
-                    out[:w.shape[0], :w.shape[1]] = w.detach().float().cpu()
-                    return out
+                def put(t, rows=None, cols=None, transpose=False):
+                    """copy t (zero-padded to rows x cols, optionally transposed) at the cursor"""
+                    t = t.detach().float().cpu().numpy()
+                    if t.ndim == 1:
+                        n_out = rows if rows is not None else t.shape[0]
+                        flat[cur[0]:cur[0] + t.shape[0]] = t
+                        cur[0] += n_out
+                        return
+                    if transpose:   # stored as (cols, rows): element (c, r) = t[r, c]
+                        view = flat[cur[0]:cur[0] + rows * cols].reshape(cols, rows)
+                        view[:t.shape[1], :t.shape[0]] = t.T
+                    else:
+                        view = flat[cur[0]:cur[0] + rows * cols].reshape(rows, cols)
+                        view[:t.shape[0], :t.shape[1]] = t
+                    cur[0] += rows * cols
 
-                def padded_vec(b, n):
-                    out = torch.zeros(n)
-                    out[:b.shape[0]] = b.detach().float().cpu()
-                    return out
-
-                w1 = padded(lin[0].weight, hp, d_a)                       # (out, in)
                 if hp > 32:  # matrix-core path: both orientations (csrc/mfma_device.hpp)
-                    parts += [w1.reshape(-1), w1.t().contiguous().reshape(-1), padded_vec(lin[0].bias, hp)]
+                    put(lin[0].weight, hp, d_a)
+                    put(lin[0].weight, hp, d_a, transpose=True)
+                    put(lin[0].bias, hp)
                     for l in lin[1:-1]:
-                        wh = padded(l.weight, hp, hp)
-                        parts += [wh.reshape(-1), wh.t().contiguous().reshape(-1), padded_vec(l.bias, hp)]
-                    w3 = padded(lin[-1].weight, 2 * d_b, hp)
-                    parts += [w3.reshape(-1), w3.t().contiguous().reshape(-1), lin[-1].bias.detach().float().cpu()]
+                        put(l.weight, hp, hp)
+                        put(l.weight, hp, hp, transpose=True)
+                        put(l.bias, hp)
+                    put(lin[-1].weight, 2 * d_b, hp)
+                    put(lin[-1].weight, 2 * d_b, hp, transpose=True)
+                    put(lin[-1].bias)
                 else:        # VALU path: W1T | b1 | [WhT | bh] | W3 | b3
-                    parts += [w1.t().contiguous().reshape(-1), padded_vec(lin[0].bias, hp)]
+                    put(lin[0].weight, hp, d_a, transpose=True)
+                    put(lin[0].bias, hp)
                     for l in lin[1:-1]:
-                        parts += [padded(l.weight, hp, hp).t().contiguous().reshape(-1), padded_vec(l.bias, hp)]
-                    parts += [padded(lin[-1].weight, 2 * d_b, hp).reshape(-1), lin[-1].bias.detach().float().cpu()]
-                blob = torch.cat(parts)
-                assert blob.numel() == stride, (blob.numel(), stride)
-                blobs.append(blob)
-            weights = (torch.cat(blobs) if blobs else torch.zeros(1)).to(device)
+                        put(l.weight, hp, hp, transpose=True)
+                        put(l.bias, hp)
+                    put(lin[-1].weight, 2 * d_b, hp)
+                    put(lin[-1].bias)
+                assert cur[0] == (li + 1) * stride, (cur[0], li, stride)
+            weights = torch.from_numpy(flat).to(device)
             ea0, ea1 = self.layers[0], self.layers[-1]
             keep = [weights] + [t.detach().float().contiguous().to(device)
                                 for t in (ea0.log_scale, ea0.shift, ea1.log_scale, ea1.shift)]

@@ -11,10 +11,13 @@ def run(n, d, nh, cl, L, T, pot='funnel'):
               n_iterations=T, show_progress=False, inner_kernel_kwargs={'n_leapfrog_steps': L, 'step_size': 0.02},
               param_kwargs={'store_samples': False}, seed=1)
     x0 = (0.5 * torch.randn(n, d)).cuda()
-    sample(target, x0=x0[:1024], **{**kw, 'n_iterations': 1})
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    out = sample(target, x0=x0, **kw)
-    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    best = None
+    for rep in range(2):   # first call at this size pays the allocator (hipMalloc of the trajectory scratch)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        out = sample(target, x0=x0, **kw)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    dt = best
     flops = None
     print(f'neutra_hmc n={n} d={d} H={nh} cl={cl} L={L} T={T}: {dt/T*1e3:.2f} ms/step  {n*T/dt/1e6:.3f} M chain-steps/s  acc={out.statistics.acceptance_rate:.2f}', flush=True)
 
