@@ -8,6 +8,7 @@ Like the reference, the stored samples and the running moments are those of the 
 `NeuTraParameters.transform_output=True` opts into x-space samples/moments instead.
 """
 import ctypes as C
+import os
 import time
 from dataclasses import dataclass
 from typing import Optional, Type
@@ -70,6 +71,14 @@ class NeuTra(Sampler):
         adjusted_potential = -(log_prob.reshape(-1) + log_det_inverse.to(log_prob).reshape(-1))
         return (adjusted_potential, x) if return_data else adjusted_potential
 
+    def _min_hidden(self):
+        """Conditioner width to present to the kernels: d = 64 / 128 with one or two hidden layers runs on the
+        matrix cores (csrc/neutra_mfma.hip) also when the flow's own conditioner is narrow (zero-padded)."""
+        bij = self.kernel.flow.bijection
+        ok = (getattr(bij, 'd', 0) in (64, 128) and getattr(bij, 'n_hidden_layers', 0) in (1, 2)
+              and os.environ.get('NFMC_NEUTRA_VALU', '0') != '1')
+        return 64 if ok else 0
+
     def _potential_grad(self, z):
         """U~(z), grad U~(z) from nfmc_neutra_potential_grad_f32 (closed-form targets only)."""
         dev = hip.require_gpu()
@@ -80,7 +89,7 @@ class NeuTra(Sampler):
         if pot is None:
             raise ValueError('NeuTra needs a closed-form potential (nfmc_amd.potentials) for the gradient kernel')
         zf = z.detach().to(dev, torch.float32).reshape(n, -1).contiguous()
-        st, _keep = self.kernel.flow.bijection.packed(dev)
+        st, _keep = self.kernel.flow.bijection.packed(dev, self._min_hidden())
         pd = pot.descriptor(dev)
         u = torch.empty(n, dtype=torch.float32, device=dev)
         g = torch.empty_like(zf)
@@ -119,10 +128,10 @@ class NeuTra(Sampler):
         out = MCMCOutput(event_shape, store_samples=self.params.store_samples)
         T = int(self.params.n_iterations)
         buf = torch.empty(T, n, d, dtype=torch.float32, device=run.dev) if (self.params.store_samples and T > 0) else None
-        st_flow, _keep = self.kernel.flow.bijection.packed(run.dev)
+        st_flow, _keep = self.kernel.flow.bijection.packed(run.dev, self._min_hidden())
         imd = imd_tensor(inner.kernel, run.dev)
         bij = self.kernel.flow.bijection
-        sbytes = int(hip.lib().nfmc_neutra_scratch_bytes(n, d, bij.n_hidden))
+        sbytes = int(hip.lib().nfmc_neutra_scratch_bytes(n, d, max(bij.n_hidden, self._min_hidden())))
         scratch = torch.empty(max(sbytes // 4, 1), dtype=torch.float32, device=run.dev)
         t0 = time.time()
         done = 0

@@ -833,3 +833,46 @@ def test_integration_stub_runs_and_matches_the_package(dev):
     assert torch.equal(out.running_samples.last_sample.reshape(n, d).cpu(), x.cpu())
     assert int(counters[0]) == out.statistics.n_accepted_trajectories and int(counters[1]) == n * k
     np.testing.assert_allclose((sum_x / (n * k)).cpu().numpy(), out.mean.numpy().astype(np.float64), atol=1e-6)
+
+
+@pytest.mark.parametrize('d,cl', [(64, 2), (128, 1)])
+def test_neutra_narrow_conditioner_on_matrix_cores_equals_valu_path(dev, d, cl, monkeypatch):
+    """NeuTra presents a narrow conditioner zero-padded to 64 hidden units so that d = 64 / 128 runs on the
+    matrix-core kernels: the gradient equals the VALU kernels' (and autograd of the oracle) and a run agrees."""
+    from nfmc_amd.flows import Flow, RealNVP
+    from nfmc_amd.potentials import Funnel
+    from nfmc_amd.samplers import mcmc, neutra
+    from oracle import flow as oflow
+    from oracle import potentials as opot
+    from oracle import samplers as osamp
+    ck = {'n_hidden': 6, 'n_layers': cl}
+    torch.manual_seed(d + cl)
+    of = oflow.perturb_(oflow.Flow(oflow.RealNVP((d,), conditioner_kwargs=ck)), 5, 0.3, 0.8)
+    f = Flow(RealNVP((d,), conditioner_kwargs=ck))
+    f.load_state_dict(of.state_dict())
+
+    def make():
+        return neutra.NeuTraHMC((d,), Funnel((d,), 3.0), mcmc.HMCKernel(event_size=d, n_leapfrog_steps=4, step_size=0.02),
+                                mcmc.HMCParameters(), neutra.NeuTraKernel((d,), flow=f),
+                                neutra.NeuTraParameters(n_iterations=3))
+    z = 0.5 * torch.randn(300, d)
+    s = make()
+    assert s._min_hidden() == 64
+    u1, g1 = s._potential_grad(z.to(dev))
+    s.seed = 11
+    out1 = s.sample(z, show_progress=False)
+    monkeypatch.setenv('NFMC_NEUTRA_VALU', '1')
+    s2 = make()
+    assert s2._min_hidden() == 0
+    u2, g2 = s2._potential_grad(z.to(dev))
+    s2.seed = 11
+    out2 = s2.sample(z, show_progress=False)
+    zz = z.clone().requires_grad_(True)
+    u0 = osamp.neutra_adjusted_target(of, opot.funnel(3.0), (d,))(zz)
+    g0, = torch.autograd.grad(u0.sum(), zz)
+    for u, g in ((u1, g1), (u2, g2)):
+        np.testing.assert_allclose(u.cpu().numpy(), u0.detach().numpy(), atol=2e-4, rtol=2e-5)
+        np.testing.assert_allclose(g.cpu().numpy(), g0.numpy(), atol=2e-4, rtol=2e-4)
+    a, b = out1.samples[-1], out2.samples[-1]
+    assert float(((a - b).abs().amax(dim=1) < 1e-3).float().mean()) > 0.97
+    assert out1.statistics.n_attempted_trajectories == out2.statistics.n_attempted_trajectories == 900
