@@ -271,6 +271,10 @@ class MCMCSamples:
             self.n_samples = len(full)
 
     def as_device_tensor(self) -> torch.Tensor:
+        if not self._chunks:   # nothing kept yet (n_iterations = 0): an empty (0, n_chains, *event) tensor
+            if self.last_sample is not None:
+                return self.last_sample.new_empty((0,) + tuple(self.last_sample.shape))
+            return torch.empty((0, 0) + self.event_shape)
         if len(self._chunks) > 1:
             self._chunks = [torch.cat(self._chunks, dim=0)]
         return self._chunks[0]

@@ -876,3 +876,79 @@ def test_neutra_narrow_conditioner_on_matrix_cores_equals_valu_path(dev, d, cl, 
     a, b = out1.samples[-1], out2.samples[-1]
     assert float(((a - b).abs().amax(dim=1) < 1e-3).float().mean()) > 0.97
     assert out1.statistics.n_attempted_trajectories == out2.statistics.n_attempted_trajectories == 900
+
+
+# ------------------------------------------------------------------------------------------ edge cases
+def _sumsq(x):
+    return torch.sum(x ** 2, dim=-1)
+
+
+def test_edge_smallest_and_largest_shapes(dev):
+    """One chain of one coordinate; the widest event the kernels take (d = 1024) and one beyond (ValueError, the
+    reference's error channel); a chain count that is not a multiple of any tile."""
+    from nfmc_amd import sample
+    from nfmc_amd.potentials import SumOfSquares
+    torch.manual_seed(0)
+    out = sample(_sumsq, event_shape=(1,), strategy='mala', n_chains=1, n_iterations=50, show_progress=False)
+    assert out.samples.shape == (50, 1, 1) and torch.isfinite(out.samples).all()
+    out = sample(_sumsq, event_shape=(1,), strategy='hmc', n_chains=1, n_iterations=5, show_progress=False)
+    assert out.samples.shape == (5, 1, 1) and out.statistics.n_attempted_trajectories == 5
+    out = sample(SumOfSquares((1024,)), strategy='mala', n_chains=64, n_iterations=300, show_progress=False,
+                 param_kwargs={'store_samples': False})
+    assert abs(float(out.variance.mean()) - 0.5) < 0.02 and out.mean.shape == (1024,)
+    with pytest.raises(ValueError, match='supported range'):
+        sample(SumOfSquares((1025,)), strategy='mala', n_chains=4, n_iterations=2, show_progress=False)
+    with pytest.raises(ValueError):   # a flow needs at least one pass-through coordinate
+        sample(_sumsq, event_shape=(1,), strategy='imh', n_chains=8, n_iterations=2, show_progress=False)
+    out = sample(SumOfSquares((64,)), strategy='jump_mala', n_chains=100003, n_iterations=2, show_progress=False,
+                 param_kwargs={'store_samples': False}, inner_param_kwargs={'n_iterations': 20})
+    assert out.statistics.n_attempted_trajectories == 100003 * 40 and out.statistics.n_attempted_jumps == 100003 * 2
+
+
+def test_edge_zero_iterations_and_long_runs(dev):
+    """n_iterations = 0 returns empty containers; more transitions than one launch takes (512) are chunked."""
+    from nfmc_amd import sample
+    for strategy in ('mala', 'jump_mala', 'imh'):
+        out = sample(_sumsq, event_shape=(4,), strategy=strategy, n_chains=4, n_iterations=0, show_progress=False)
+        assert out.samples.shape[0] == 0 and out.statistics.n_attempted_trajectories == 0
+    torch.manual_seed(1)
+    out = sample(_sumsq, event_shape=(8,), strategy='mala', n_chains=1000, n_iterations=1300, show_progress=False,
+                 param_kwargs={'store_samples': False})
+    assert out.statistics.n_attempted_trajectories == 1300 * 1000
+    assert abs(float(out.variance.mean()) - 0.5) < 0.01 and float(out.mean.abs().max()) < 0.01
+
+
+def test_edge_nonfinite_states_are_rejected_and_counted(dev):
+    """A NaN / inf coordinate makes the log ratio non-finite: the proposal is rejected (langevin.py:106 compares
+    log u < NaN -> False), the chain keeps its state, the event is counted; healthy chains are unaffected."""
+    from nfmc_amd import sample
+    torch.manual_seed(2)
+    x0 = torch.randn(16, 8)
+    x0[3, 2] = float('nan')
+    x0[5, 0] = float('inf')
+    out = sample(_sumsq, event_shape=(8,), strategy='mala', x0=x0, n_iterations=10, show_progress=False)
+    last = out.samples[-1]
+    assert torch.isnan(last[3, 2]) and torch.isinf(last[5, 0])
+    assert out.statistics.n_nonfinite_log_ratios == 20
+    ok = [i for i in range(16) if i not in (3, 5)]
+    assert torch.isfinite(last[ok]).all() and out.statistics.n_accepted_trajectories > 0
+
+
+def test_edge_c_abi_argument_errors(dev):
+    """Negative status -> ValueError with the library's message; nothing is launched."""
+    import ctypes as C
+    from nfmc_amd import hip
+    a = hip.NfmcMalaArgs()
+    with pytest.raises(ValueError, match='invalid argument'):
+        hip.check(hip.lib().nfmc_mala_steps_f32(C.byref(a), hip.stream()), 'nfmc_mala_steps_f32')
+    x = torch.zeros(4, 8, device=dev)
+    a.x, a.n, a.d, a.n_steps, a.step_size, a.adjust = hip.ptr(x), 4, 8, 100000, 0.1, 1
+    a.pot = hip.NfmcPotential(0, 0, None, None, 1.0, 0.0)
+    with pytest.raises(ValueError):
+        hip.check(hip.lib().nfmc_mala_steps_f32(C.byref(a), hip.stream()), 'nfmc_mala_steps_f32')
+    st = hip.DeviceStats(8, dev)
+    raw = st._raw()
+    raw.scratch_bytes = 16   # too small
+    a.n_steps, a.stats = 4, raw
+    with pytest.raises(ValueError, match='scratch'):
+        hip.check(hip.lib().nfmc_mala_steps_f32(C.byref(a), hip.stream()), 'nfmc_mala_steps_f32')
