@@ -176,9 +176,9 @@ __device__ __forceinline__ f32x4 tanh4(f32x4 v) {
 
 // LDS carve-up: two weight images of 128 x 132 floats, a 256-float vector area, per-wave statistics
 constexpr int kImgFloats = 128 * 132;
-constexpr int kVecFloats = 256;
+constexpr int kVecFloats = 256;          // one bias / vector area per image
 constexpr int kMfmaStatDoubles = kMfmaWaves * (2 * 128 + 2);
-constexpr size_t kMfmaLdsBytes = (size_t)(2 * kImgFloats + kVecFloats) * sizeof(float) + kMfmaStatDoubles * sizeof(double);
+constexpr size_t kMfmaLdsBytes = (size_t)(2 * kImgFloats + 2 * kVecFloats) * sizeof(float) + kMfmaStatDoubles * sizeof(double);
 
 // entry points of neutra_mfma.hip used by the C ABI in neutra_kernels.hip
 int nfmc_mfma_supported(int32_t d, int32_t n_hidden, int32_t n_hidden_layers);
@@ -187,31 +187,52 @@ int nfmc_neutra_potential_grad_mfma_f32(const NfmcRealNVP* flow, const NfmcPoten
 int nfmc_neutra_hmc_steps_mfma_f32(const NfmcNeutraHmcArgs* args, float* scratch, int64_t scratch_bytes,
                                    nfmc_stream_t stream);
 
+// ---- the weight pipeline: two LDS images (+ their vector areas) used STRICTLY ALTERNATELY, one per GEMM.
+// A wave stages the operand of GEMM k right after it finished GEMM k-1, into the image GEMM k-2 read; every
+// wave passed the barrier that closed staging k-1 only after it had finished GEMM k-2, so nobody still reads
+// that image: ONE barrier per GEMM (after its staging), and the staging loads of early waves overlap the
+// MFMAs of late ones.  The alternation must never be broken (also across layers, sweeps and chain tiles).
+struct WeightPipe {
+    float* lds;
+    int buf;
+    __device__ __forceinline__ float* img() const { return lds + buf * kImgFloats; }
+    __device__ __forceinline__ float* vec() const { return lds + 2 * kImgFloats + buf * kVecFloats; }
+    // stage matrix W (rows x K) and, if given, a vector, into the next image; closes with the barrier
+    template <int K, int RBLK, int CBLK, int VBLK>
+    __device__ __forceinline__ void stage(const float* W, int rows, bool rev_rows, bool rev_cols, const float* v,
+                                          int vlen, bool vrev) {
+        buf ^= 1;
+        stage_matrix<K, RBLK, CBLK>(img(), W, rows, rev_rows, rev_cols);
+        if (v) stage_vector<VBLK>(vec(), v, vlen, vrev);
+        __syncthreads();
+    }
+};
+
 // Conditioner hidden stack in C layout: h1 = tanh(W1 x_src + b1), h2 = tanh(Wh h1 + bh).  Workgroup-collective
-// (stages weights, barriers inside).  `src` are the source tiles of the layer input (TS = d_a / 16).
+// (two steps of the weight pipeline).  `src` are the source tiles of the layer input (TS = d_a / 16).
 template <int TS, int TH, int NHL>
 __device__ __forceinline__ void hidden_stack(const f32x4 (&src)[TS], f32x4 (&h1)[TH], f32x4 (&h2)[TH], const MLayer& L,
-                                             bool rev, float* img0, float* vec, int col, int q) {
+                                             bool rev, WeightPipe& wp, int col, int q) {
     constexpr int hp = 16 * TH, d_a = 16 * TS;
-    __syncthreads();
-    stage_matrix<d_a, 1, d_a>(img0, L.W1, hp, false, rev);
-    stage_vector<1>(vec, L.b1, hp, false);
-    __syncthreads();
+    wp.template stage<d_a, 1, d_a, 1>(L.W1, hp, false, rev, L.b1, hp, false);
+    {
+        const float* img = wp.img();
+        const float* vec = wp.vec();
 #pragma unroll
-    for (int mo = 0; mo < TH; ++mo) {
-        h1[mo] = vec_tile(vec, mo, q);
-        gemm_tile<TS>(h1[mo], img0 + (16 * mo + col) * (d_a + 4) + 4 * q, src);
-        h1[mo] = tanh4(h1[mo]);
+        for (int mo = 0; mo < TH; ++mo) {
+            h1[mo] = vec_tile(vec, mo, q);
+            gemm_tile<TS>(h1[mo], img + (16 * mo + col) * (d_a + 4) + 4 * q, src);
+            h1[mo] = tanh4(h1[mo]);
+        }
     }
     if constexpr (NHL > 1) {
-        __syncthreads();
-        stage_matrix<hp, 1, 1>(img0, L.Wh, hp, false, false);
-        stage_vector<1>(vec, L.bh, hp, false);
-        __syncthreads();
+        wp.template stage<hp, 1, 1, 1>(L.Wh, hp, false, false, L.bh, hp, false);
+        const float* img = wp.img();
+        const float* vec = wp.vec();
 #pragma unroll
         for (int mo = 0; mo < TH; ++mo) {
             h2[mo] = vec_tile(vec, mo, q);
-            gemm_tile<TH>(h2[mo], img0 + (16 * mo + col) * (hp + 4) + 4 * q, h1);
+            gemm_tile<TH>(h2[mo], img + (16 * mo + col) * (hp + 4) + 4 * q, h1);
             h2[mo] = tanh4(h2[mo]);
         }
     }

@@ -58,29 +58,25 @@ __device__ __forceinline__ float potential_value_grad_c(const f32x4 (&x)[TD], f3
 // ---- inverse coupling layer, forward sweep (v -> y): returns this lane's share of the layer's logdet_inverse
 template <int TD, int TH, int NHL, bool REV>
 __device__ __forceinline__ float coupling_inverse_c(f32x4 (&x)[TD], const MLayer& L, float mscale, float log1m,
-                                                    float* lds, int col, int half) {
+                                                    WeightPipe& wp, int col, int half) {
     constexpr int TS = TD / 2, SRC0 = REV ? TS : 0, TGT0 = REV ? 0 : TS, D2 = 8 * TD, hp = 16 * TH;
-    float* img0 = lds;
-    float* vec = lds + 2 * kImgFloats;
-    f32x4 src[TS], h1[TH], h2[TH];
+    f32x4 hl[TH];   // activations of the last hidden layer
+    {
+        f32x4 src[TS], h1[TH];
 #pragma unroll
-    for (int ms = 0; ms < TS; ++ms) src[ms] = x[SRC0 + ms];
-    hidden_stack<TS, TH, NHL>(src, h1, h2, L, REV, img0, vec, col, half);
-    __syncthreads();
-    stage_matrix<hp, D2, 1>(img0, L.W3, 2 * D2, REV, false);
-    stage_vector<D2>(vec, L.b3, 2 * D2, REV);
-    __syncthreads();
+        for (int ms = 0; ms < TS; ++ms) src[ms] = x[SRC0 + ms];
+        if constexpr (NHL > 1) hidden_stack<TS, TH, NHL>(src, h1, hl, L, REV, wp, col, half);
+        else hidden_stack<TS, TH, NHL>(src, hl, h1, L, REV, wp, col, half);
+    }
+    wp.template stage<hp, D2, 1, D2>(L.W3, 2 * D2, REV, false, L.b3, 2 * D2, REV);
+    const float* img = wp.img();
+    const float* vec = wp.vec();
     float ld = 0.f;
 #pragma unroll
     for (int mt = 0; mt < TS; ++mt) {
         f32x4 ua = vec_tile(vec, mt, half), ub = vec_tile(vec, TS + mt, half);
-        if constexpr (NHL > 1) {
-            gemm_tile<TH>(ua, img0 + (16 * mt + col) * (hp + 4) + 4 * half, h2);
-            gemm_tile<TH>(ub, img0 + (16 * (TS + mt) + col) * (hp + 4) + 4 * half, h2);
-        } else {
-            gemm_tile<TH>(ua, img0 + (16 * mt + col) * (hp + 4) + 4 * half, h1);
-            gemm_tile<TH>(ub, img0 + (16 * (TS + mt) + col) * (hp + 4) + 4 * half, h1);
-        }
+        gemm_tile<TH>(ua, img + (16 * mt + col) * (hp + 4) + 4 * half, hl);
+        gemm_tile<TH>(ub, img + (16 * (TS + mt) + col) * (hp + 4) + 4 * half, hl);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const float alpha = fast_exp(fmaf(0.5f, ua[t], log1m)) + mscale;
@@ -92,104 +88,108 @@ __device__ __forceinline__ float coupling_inverse_c(f32x4 (&x)[TD], const MLayer
 }
 
 // ---- reverse sweep through one inverse coupling layer: (y, dL/dy) -> (v, dL/dv); L = U(x) + sum log alpha.
-// Register budget (two waves per SIMD, 256 VGPRs): x, g and at most TWO hidden-width tile sets are live at any
-// point -- with two hidden layers the first layer's activations are not kept across the transposed products but
-// rebuilt tile by tile where tanh' is needed (one extra W1 product, +7 % multiply-adds, instead of 32 registers).
+// Seven steps of the weight pipeline (five with one hidden layer), one image each:
+//   W1 -> h1 | Wh -> h2 | W3 -> u_alpha, u_beta of every target tile (then the elementwise backward: du, dv)
+//   | W3^T -> dL/dh_last | Wh^T -> dL/dh1 | W1 again -> tanh'(pre1) tile by tile | W1^T -> dL/dy_source.
+// Register budget (two waves per SIMD, 256 VGPRs): x, g and at most THREE hidden-width tile sets are live at
+// any point (h_last, the du/dv tiles, dL/dh); with two hidden layers the first layer's activations are not kept
+// across the transposed products but rebuilt where tanh' is needed (+7 % multiply-adds instead of 32 registers).
 template <int TD, int TH, int NHL, bool REV>
 __device__ __forceinline__ void coupling_inverse_backward_c(f32x4 (&x)[TD], f32x4 (&g)[TD], const MLayer& L,
-                                                            float mscale, float log1m, float* lds, int col,
+                                                            float mscale, float log1m, WeightPipe& wp, int col,
                                                             int half) {
     constexpr int TS = TD / 2, SRC0 = REV ? TS : 0, TGT0 = REV ? 0 : TS, D2 = 8 * TD, hp = 16 * TH;
-    float* img0 = lds;
-    float* img1 = lds + kImgFloats;
-    float* vec = lds + 2 * kImgFloats;
     f32x4 hl[TH];   // activations of the LAST hidden layer
     {
         f32x4 src[TS], h1[TH];
 #pragma unroll
         for (int ms = 0; ms < TS; ++ms) src[ms] = x[SRC0 + ms];
-        if constexpr (NHL > 1) {
-            hidden_stack<TS, TH, NHL>(src, h1, hl, L, REV, img0, vec, col, half);
-        } else {
-            hidden_stack<TS, TH, NHL>(src, hl, h1, L, REV, img0, vec, col, half);
+        if constexpr (NHL > 1) hidden_stack<TS, TH, NHL>(src, h1, hl, L, REV, wp, col, half);
+        else hidden_stack<TS, TH, NHL>(src, hl, h1, L, REV, wp, col, half);
+    }
+    // conditioner outputs of every target tile, then the elementwise backward of the affine map
+    f32x4 du[TS], dv[TS];
+    {
+        wp.template stage<hp, D2, 1, D2>(L.W3, 2 * D2, REV, false, L.b3, 2 * D2, REV);
+        const float* img = wp.img();
+        const float* vec = wp.vec();
+#pragma unroll
+        for (int mt = 0; mt < TS; ++mt) {
+            f32x4 ua = vec_tile(vec, mt, half), ub = vec_tile(vec, TS + mt, half);
+            gemm_tile<TH>(ua, img + (16 * mt + col) * (hp + 4) + 4 * half, hl);
+            gemm_tile<TH>(ub, img + (16 * (TS + mt) + col) * (hp + 4) + 4 * half, hl);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float alpha = fast_exp(fmaf(0.5f, ua[t], log1m)) + mscale;
+                const float beta = 0.5f * ub[t];
+                const float ra = __builtin_amdgcn_rcpf(alpha);
+                const float y = x[TGT0 + mt][t];
+                const float gv = g[TGT0 + mt][t] * ra;
+                const float d_alpha = fmaf(-gv, y, ra);
+                du[mt][t] = 0.5f * d_alpha * (alpha - mscale);
+                dv[mt][t] = -0.5f * gv;
+                g[TGT0 + mt][t] = gv;
+                x[TGT0 + mt][t] = fmaf(alpha, y, beta);
+            }
         }
     }
-    __syncthreads();
-    stage_matrix<hp, D2, 1>(img0, L.W3, 2 * D2, REV, false);
-    stage_matrix<2 * D2, 1, D2>(img1, L.W3T, hp, false, REV);
-    stage_vector<D2>(vec, L.b3, 2 * D2, REV);
-    __syncthreads();
+    // dL/dh_last = W3^T [du; dv], through tanh of the last hidden layer (its activations die here)
     f32x4 dh[TH];
-#pragma unroll
-    for (int mo = 0; mo < TH; ++mo)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) dh[mo][t] = 0.f;
-#pragma unroll
-    for (int mt = 0; mt < TS; ++mt) {
-        f32x4 ua = vec_tile(vec, mt, half), ub = vec_tile(vec, TS + mt, half);
-        gemm_tile<TH>(ua, img0 + (16 * mt + col) * (hp + 4) + 4 * half, hl);
-        gemm_tile<TH>(ub, img0 + (16 * (TS + mt) + col) * (hp + 4) + 4 * half, hl);
-        f32x4 du[1], dv[1];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const float alpha = fast_exp(fmaf(0.5f, ua[t], log1m)) + mscale;
-            const float beta = 0.5f * ub[t];
-            const float ra = __builtin_amdgcn_rcpf(alpha);
-            const float y = x[TGT0 + mt][t];
-            const float gv = g[TGT0 + mt][t] * ra;
-            const float d_alpha = fmaf(-gv, y, ra);
-            du[0][t] = 0.5f * d_alpha * (alpha - mscale);
-            dv[0][t] = -0.5f * gv;
-            g[TGT0 + mt][t] = gv;
-            x[TGT0 + mt][t] = fmaf(alpha, y, beta);
-        }
-#pragma unroll
-        for (int mo = 0; mo < TH; ++mo) {  // dh += W3^T[:, alpha rows of tile mt] du + W3^T[:, beta rows] dv
-            const float* arow = img1 + (16 * mo + col) * (2 * D2 + 4) + 4 * half;
-            gemm_tile<1>(dh[mo], arow + 16 * mt, du);
-            gemm_tile<1>(dh[mo], arow + D2 + 16 * mt, dv);
-        }
-    }
-#pragma unroll
-    for (int mo = 0; mo < TH; ++mo)   // through tanh of the last hidden layer; its activations die here
-#pragma unroll
-        for (int t = 0; t < 4; ++t) dh[mo][t] *= (1.f - hl[mo][t] * hl[mo][t]);
-    if constexpr (NHL > 1) {
-        // dL/dh1 = Wh^T dpre2, then tanh'(pre1) with h1 = tanh(W1 src + b1) rebuilt one tile at a time
-        __syncthreads();
-        stage_matrix<hp, 1, 1>(img0, L.WhT, hp, false, false);
-        stage_matrix<D2, 1, D2>(img1, L.W1, hp, false, REV);
-        stage_vector<1>(vec, L.b1, hp, false);
-        __syncthreads();
-        f32x4 src[TS];
-#pragma unroll
-        for (int ms = 0; ms < TS; ++ms) src[ms] = x[SRC0 + ms];
+    {
+        wp.template stage<2 * D2, 1, D2, 1>(L.W3T, hp, false, REV, nullptr, 0, false);
+        const float* img = wp.img();
 #pragma unroll
         for (int mo = 0; mo < TH; ++mo) {
-            f32x4 acc, h1t = vec_tile(vec, mo, half);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = 0.f;
-            gemm_tile<TH>(acc, img0 + (16 * mo + col) * (hp + 4) + 4 * half, dh);
-            gemm_tile<TS>(h1t, img1 + (16 * mo + col) * (D2 + 4) + 4 * half, src);
-            h1t = tanh4(h1t);
+            for (int t = 0; t < 4; ++t) dh[mo][t] = 0.f;
+            const float* arow = img + (16 * mo + col) * (2 * D2 + 4) + 4 * half;
+            gemm_tile<TS>(dh[mo], arow, du);
+            gemm_tile<TS>(dh[mo], arow + D2, dv);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) hl[mo][t] = acc[t] * (1.f - h1t[t] * h1t[t]);
+            for (int t = 0; t < 4; ++t) dh[mo][t] *= (1.f - hl[mo][t] * hl[mo][t]);
         }
-#pragma unroll
-        for (int mo = 0; mo < TH; ++mo) dh[mo] = hl[mo];
     }
-    __syncthreads();
-    stage_matrix<hp, D2, 1>(img0, L.W1T, D2, REV, false);
-    __syncthreads();
+    if constexpr (NHL > 1) {
+        // dL/dh1 = Wh^T dpre2 ...
+        {
+            wp.template stage<hp, 1, 1, 1>(L.WhT, hp, false, false, nullptr, 0, false);
+            const float* img = wp.img();
 #pragma unroll
-    for (int ms = 0; ms < TS; ++ms) gemm_tile<TH>(g[SRC0 + ms], img0 + (16 * ms + col) * (hp + 4) + 4 * half, dh);
+            for (int mo = 0; mo < TH; ++mo) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) hl[mo][t] = 0.f;
+                gemm_tile<TH>(hl[mo], img + (16 * mo + col) * (hp + 4) + 4 * half, dh);
+            }
+        }
+        // ... times tanh'(pre1), with h1 = tanh(W1 src + b1) rebuilt one tile at a time
+        {
+            wp.template stage<D2, 1, D2, 1>(L.W1, hp, false, REV, L.b1, hp, false);
+            const float* img = wp.img();
+            const float* vec = wp.vec();
+            f32x4 src[TS];
+#pragma unroll
+            for (int ms = 0; ms < TS; ++ms) src[ms] = x[SRC0 + ms];
+#pragma unroll
+            for (int mo = 0; mo < TH; ++mo) {
+                f32x4 h1t = vec_tile(vec, mo, half);
+                gemm_tile<TS>(h1t, img + (16 * mo + col) * (D2 + 4) + 4 * half, src);
+                h1t = tanh4(h1t);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) dh[mo][t] = hl[mo][t] * (1.f - h1t[t] * h1t[t]);
+            }
+        }
+    }
+    wp.template stage<hp, D2, 1, 1>(L.W1T, D2, REV, false, nullptr, 0, false);
+    const float* img = wp.img();
+#pragma unroll
+    for (int ms = 0; ms < TS; ++ms) gemm_tile<TH>(g[SRC0 + ms], img + (16 * ms + col) * (hp + 4) + 4 * half, dh);
 }
 
 // ---- U~(z), grad U~(z) for the wave's 16 chains.  x: in z (tile positions in latent order), out z again
 // (rebuilt through the inverse of every step); g: gradient in the same positions.  Workgroup-collective.
 template <int TD, int TH, int NHL>
 __device__ __forceinline__ float adjusted_grad_c(f32x4 (&x)[TD], f32x4 (&g)[TD], const NfmcRealNVP& f,
-                                                 const NfmcPotential& pot, float* lds, int col, int half, int lane) {
+                                                 const NfmcPotential& pot, WeightPipe& wp, int col, int half, int lane) {
     constexpr int d = 16 * TD, hp = 16 * TH;
     const bool rev_last = (f.n_coupling & 1) != 0;
     const float log1m = __logf(1.f - f.min_scale);
@@ -206,8 +206,8 @@ __device__ __forceinline__ float adjusted_grad_c(f32x4 (&x)[TD], f32x4 (&g)[TD],
     }
     for (int l = f.n_coupling - 1; l >= 0; --l) {
         const MLayer L = mfma_layer(f.weights + l * f.layer_stride, d, hp, NHL);
-        if ((l & 1) == 0) ldp += coupling_inverse_c<TD, TH, NHL, true>(x, L, f.min_scale, log1m, lds, col, half);
-        else ldp += coupling_inverse_c<TD, TH, NHL, false>(x, L, f.min_scale, log1m, lds, col, half);
+        if ((l & 1) == 0) ldp += coupling_inverse_c<TD, TH, NHL, true>(x, L, f.min_scale, log1m, wp, col, half);
+        else ldp += coupling_inverse_c<TD, TH, NHL, false>(x, L, f.min_scale, log1m, wp, col, half);
     }
 #pragma unroll
     for (int m = 0; m < TD; ++m) {  // EA0^-1
@@ -231,8 +231,8 @@ __device__ __forceinline__ float adjusted_grad_c(f32x4 (&x)[TD], f32x4 (&g)[TD],
     }
     for (int l = 0; l < f.n_coupling; ++l) {
         const MLayer L = mfma_layer(f.weights + l * f.layer_stride, d, hp, NHL);
-        if ((l & 1) == 0) coupling_inverse_backward_c<TD, TH, NHL, true>(x, g, L, f.min_scale, log1m, lds, col, half);
-        else coupling_inverse_backward_c<TD, TH, NHL, false>(x, g, L, f.min_scale, log1m, lds, col, half);
+        if ((l & 1) == 0) coupling_inverse_backward_c<TD, TH, NHL, true>(x, g, L, f.min_scale, log1m, wp, col, half);
+        else coupling_inverse_backward_c<TD, TH, NHL, false>(x, g, L, f.min_scale, log1m, wp, col, half);
     }
 #pragma unroll
     for (int m = 0; m < TD; ++m) {
@@ -258,13 +258,14 @@ __global__ void __launch_bounds__(kMfmaBlock, 2) neutra_grad_mfma_kernel(NfmcRea
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 15, half = lane >> 4;
     const bool rev = (f.n_coupling & 1) != 0;
+    WeightPipe wp{lds, 0};
     for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         const int64_t row = tile * kMfmaChains + wave * 16 + col;
         const bool active = row < n;
         const int64_t rrow = active ? row : n - 1;
         f32x4 x[TD], g[TD];
         load_ctiles<TD>(x, z, rrow, d, half, rev);
-        const float u = adjusted_grad_c<TD, TH, NHL>(x, g, f, pot, lds, col, half, lane);
+        const float u = adjusted_grad_c<TD, TH, NHL>(x, g, f, pot, wp, col, half, lane);
         if (active) {
             if (u_out && half == 0) u_out[row] = u;
             if (grad_out) store_ctiles<TD>(g, grad_out, row, d, half, rev);
@@ -305,7 +306,8 @@ __global__ void __launch_bounds__(kMfmaBlock, 2) neutra_leapfrog_mfma_kernel(Lea
     const int s = A.step;
 
     // statistics accumulate in LDS behind the weight images (nothing extra stays live across the GEMMs)
-    double* red = reinterpret_cast<double*>(lds + 2 * kImgFloats + kVecFloats);  // [8 waves][2*d + 2]
+    double* red = reinterpret_cast<double*>(lds + 2 * kImgFloats + 2 * kVecFloats);  // [8 waves][2*d + 2]
+    WeightPipe wp{lds, 0};
     uint32_t n_acc = 0, n_bad = 0;
     if (A.last) {
         for (int i = threadIdx.x; i < kMfmaWaves * (2 * d + 2); i += kMfmaBlock) red[i] = 0.0;
@@ -365,7 +367,7 @@ __global__ void __launch_bounds__(kMfmaBlock, 2) neutra_leapfrog_mfma_kernel(Lea
                 }
             if (active) store_ctiles<TD>(p, A.p, row_in, d, half, rev);  // momentum is not live across the GEMMs
         }
-        const float u = adjusted_grad_c<TD, TH, NHL>(x, g, a.flow, a.pot, lds, col, half, lane);
+        const float u = adjusted_grad_c<TD, TH, NHL>(x, g, a.flow, a.pot, wp, col, half, lane);
         // everything below addresses HBM by the row index: an opaque copy keeps that address arithmetic from
         // being computed before the gradient and held in registers through it (cf. stage_matrix)
         int64_t row = row_in, rrow = rrow_in;
