@@ -101,18 +101,25 @@ __device__ __forceinline__ void stage_vector(float* __restrict__ dst, const floa
 // ---- one 16-row output tile: acc += A[16*mo .. +15][0 .. 16*TK) x act ; arow = img + (16*mo + col)*ld + 4*q
 template <int TK>
 __device__ __forceinline__ void gemm_tile(f32x4& acc, const float* __restrict__ arow, const f32x4 (&act)[TK]) {
+    // All A fragments of the tile are read first; the fence between the reads and the MFMAs lets the scheduler
+    // move the NEXT tile's reads above this tile's MFMAs (one tile of look-ahead, TK*4 extra registers) but no
+    // further: without any fence it hoists the reads of every tile of the unrolled GEMM and spills.
+    f32x4 a[TK];
+#pragma unroll
+    for (int mk = 0; mk < TK; ++mk) a[mk] = *reinterpret_cast<const f32x4*>(arow + 16 * mk);
+#ifndef NFMC_MFMA_FENCE_END
+    __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
     for (int mk = 0; mk < TK; ++mk) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(arow + 16 * mk);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], act[mk][0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], act[mk][1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], act[mk][2], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], act[mk][3], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mk][0], act[mk][0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mk][1], act[mk][1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mk][2], act[mk][2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mk][3], act[mk][3], acc, 0, 0, 0);
     }
-    // Keep the scheduler from hoisting the next tiles' A-fragment reads above this tile's MFMAs: with every
-    // output tile unrolled that costs ~32 VGPRs per tile and spills; the partner wave on the SIMD covers the
-    // LDS latency instead.
+#ifdef NFMC_MFMA_FENCE_END
     __builtin_amdgcn_sched_barrier(0);
+#endif
 }
 
 // tile of a vector in C layout: elements 16*mo + 4*q + (0..3)
