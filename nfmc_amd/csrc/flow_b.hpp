@@ -18,6 +18,8 @@
 // no index arithmetic and no branches, also for ragged d.
 #pragma once
 
+#include <type_traits>
+
 #include "common.hpp"
 #include "flow_device.hpp"
 
@@ -155,7 +157,13 @@ struct FlowB {
         constexpr int S0 = EXACT ? (REV ? CPL / 2 : 0) : 0, S1 = EXACT ? S0 + CPL / 2 : CPL;       // source registers
         constexpr int T0 = EXACT ? (REV ? 0 : CPL / 2) : 0, T1 = EXACT ? T0 + CPL / 2 : CPL;       // target registers
         const float* W1 = img + l * lf + g * HP;
-        const cfloat* b1 = mid + l * gstride;
+        // hidden-stack weights are wave-uniform: through the scalar cache for HP = 4 (24 SGPRs per layer), from
+        // the LDS image (broadcast 128-bit reads) for HP = 8, where 80 SGPRs per layer would spill to VGPR lanes
+        constexpr bool MID_LDS = HP > 4;
+        using midp = typename std::conditional<MID_LDS, const float*, const cfloat*>::type;
+        midp b1;
+        if constexpr (MID_LDS) b1 = img + l * lf + DP * HP;
+        else b1 = mid + l * gstride;
         float h[HP];
 #pragma unroll
         for (int k = 0; k < HP; ++k) h[k] = 0.f;
@@ -167,18 +175,33 @@ struct FlowB {
             for (int k = 0; k < HP; ++k) h[k] = fmaf(w[k], x[i], h[k]);
             if constexpr (LEAN) __builtin_amdgcn_sched_barrier(0);
         }
+        {
+            float bb[HP];
+            if constexpr (MID_LDS) load_row16<HP>(bb, b1);
+            else
 #pragma unroll
-        for (int k = 0; k < HP; ++k) h[k] = fast_tanh(group_allreduce<LPC>(h[k]) + b1[k]);
-        const cfloat* Wh = b1 + HP;
+                for (int k = 0; k < HP; ++k) bb[k] = b1[k];
+#pragma unroll
+            for (int k = 0; k < HP; ++k) h[k] = fast_tanh(group_allreduce<LPC>(h[k]) + bb[k]);
+        }
+        midp Wh = b1 + HP;
         for (int hl = 1; hl < n_hl; ++hl) {
             float t[HP];
-            const cfloat* bh = Wh + HP * HP;
+            midp bh = Wh + HP * HP;
+            if constexpr (MID_LDS) load_row16<HP>(t, bh);
+            else
 #pragma unroll
-            for (int k = 0; k < HP; ++k) t[k] = bh[k];
+                for (int k = 0; k < HP; ++k) t[k] = bh[k];
 #pragma unroll
-            for (int i = 0; i < HP; ++i)
+            for (int i = 0; i < HP; ++i) {
+                float wr[HP];
+                if constexpr (MID_LDS) load_row16<HP>(wr, Wh + i * HP);
+                else
 #pragma unroll
-                for (int k = 0; k < HP; ++k) t[k] = fmaf(Wh[i * HP + k], h[i], t[k]);
+                    for (int k = 0; k < HP; ++k) wr[k] = Wh[i * HP + k];
+#pragma unroll
+                for (int k = 0; k < HP; ++k) t[k] = fmaf(wr[k], h[i], t[k]);
+            }
 #pragma unroll
             for (int k = 0; k < HP; ++k) h[k] = fast_tanh(t[k]);
             Wh = bh + HP;
