@@ -102,8 +102,12 @@ typedef struct {
     int32_t n_coupling;       /* number of (ReversePermutation, AffineCoupling) pairs */
     int32_t n_hidden;         /* H */
     int32_t n_hidden_layers;  /* conditioner hidden layers (>= 1) */
-    float min_scale;          /* m in alpha = exp(u/2 + log(1-m)) + m */
-    int32_t reserved;
+    float min_scale;          /* m in alpha = exp(u/2 + log(1-m)) + m  (1 = additive coupling, 'nice') */
+    int32_t n_bins;           /* 0: affine coupling.  8: rational-quadratic spline coupling ('c-rqnsf') with 8 bins on
+                                 [-spline_bound, spline_bound], identity outside; the last conditioner layer then has
+                                 (3*n_bins - 1) * d_b outputs, target-major: [t*(3K-1) + (K widths | K heights | K-1
+                                 derivatives)] (spec: DESIGN.md section 4).  Spline flows run on the one-chain-per-lane
+                                 kernels with n_hidden <= 32; the NeuTra entry points return NFMC_EUNSUPPORTED. */
     const float* ea0_log_scale; /* (d,) first ElementwiseAffine */
     const float* ea0_shift;
     const float* ea1_log_scale; /* (d,) last ElementwiseAffine */
@@ -114,12 +118,16 @@ typedef struct {
                                  weights (in, out), W3 keeps (out, in); rows [0, d_b) of W3 give u_alpha, rows
                                  [d_b, 2 d_b) give u_beta; d_a = d/2, d_b = d - d_a */
     int64_t layer_stride;     /* floats between consecutive coupling layers */
+    float spline_bound;       /* B (n_bins > 0) */
+    int32_t reserved;
 } NfmcRealNVP;
 
 /* HP: n_hidden padded to the kernels' width (4, 8, 16, 32 on the VALU path; 64 or 128 on the matrix-core path,
  * whose blob also carries every matrix in both orientations: csrc/mfma_device.hpp); 0 = unsupported. */
 int32_t nfmc_realnvp_padded_hidden(int32_t n_hidden);
 int64_t nfmc_realnvp_layer_floats(int32_t d, int32_t n_hidden, int32_t n_hidden_layers);
+/* the same for any coupling kind (n_bins as in NfmcRealNVP; 0 = affine) */
+int64_t nfmc_coupling_layer_floats(int32_t d, int32_t n_hidden, int32_t n_hidden_layers, int32_t n_bins);
 
 /* Optional tail of a sampler call: after the n_steps inner transitions, ONE flow-proposal Metropolis jump
  * (jump.py:205-243: flow.sample, flow.log_prob, 2 target calls, log u < log alpha, masked update) on the

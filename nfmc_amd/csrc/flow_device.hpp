@@ -33,6 +33,9 @@ struct FlowGeom {
     int d, d_a, d_b, n_hl, n_coupling;
     int64_t layer_stride;
     float log1m, m;
+    int n_bins;      // 0 = affine coupling, 8 = rational-quadratic spline coupling
+    int out_rows;    // rows of the last conditioner layer: 2 d_b (affine) or (3 n_bins - 1) d_b (spline)
+    float bound;     // spline bound B
 };
 
 __device__ __forceinline__ FlowGeom make_geom(const NfmcRealNVP& f) {
@@ -45,6 +48,9 @@ __device__ __forceinline__ FlowGeom make_geom(const NfmcRealNVP& f) {
     g.layer_stride = f.layer_stride;
     g.m = f.min_scale;
     g.log1m = __logf(1.f - f.min_scale);
+    g.n_bins = f.n_bins;
+    g.out_rows = f.n_bins > 0 ? (3 * f.n_bins - 1) * g.d_b : 2 * g.d_b;
+    g.bound = f.spline_bound;
     return g;
 }
 
@@ -132,6 +138,102 @@ __device__ __forceinline__ const float* w3_of_wide(const float* __restrict__ W, 
 
 // One coupling layer applied in place to this lane's row.  Returns the layer's log|det| contribution
 // (forward: +sum log alpha; inverse: -sum log alpha).
+// ---- rational-quadratic spline with K = 8 bins on [-B, B] (oracle/flow.py: rqs_params / rqs_apply; Durkan et al.
+// 2019), one coordinate.  `raw` = this coordinate's 3K - 1 conditioner outputs (widths | heights | derivatives).
+// The bin is found by a scan that carries the bin's corner values (no indexed register arrays).
+constexpr int kRqsBins = 8;
+constexpr float kRqsMinBin = 1e-3f, kRqsMinDeriv = 1e-3f;
+
+template <bool INVERSE>
+__device__ __forceinline__ float rqs_coordinate(float v, const float (&raw)[3 * kRqsBins - 1], float B, float& ld) {
+    constexpr int K = kRqsBins;
+    float w[K], h[K];
+    float mw = raw[0], mh = raw[K];
+#pragma unroll
+    for (int k = 1; k < K; ++k) {
+        mw = fmaxf(mw, raw[k]);
+        mh = fmaxf(mh, raw[K + k]);
+    }
+    float sw = 0.f, sh = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        w[k] = fast_exp(raw[k] - mw);
+        h[k] = fast_exp(raw[K + k] - mh);
+        sw += w[k];
+        sh += h[k];
+    }
+    const float nw = (1.f - K * kRqsMinBin) * __builtin_amdgcn_rcpf(sw), nh = (1.f - K * kRqsMinBin) * __builtin_amdgcn_rcpf(sh);
+    const bool inside = v >= -B && v <= B;
+    const float vc = fminf(fmaxf(v, -B), B);
+    // scan: knots cw_k / ch_k, derivatives d_k (d_0 = d_K = 1); keep the corners of the bin that holds vc
+    float cw = -B, ch = -B, dk = 1.f;
+    float x0 = -B, x1 = B, y0 = -B, y1 = B, d0 = 1.f, d1 = 1.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const float cwn = k == K - 1 ? B : fmaf(2.f * B, fmaf(nw, w[k], kRqsMinBin), cw);
+        const float chn = k == K - 1 ? B : fmaf(2.f * B, fmaf(nh, h[k], kRqsMinBin), ch);
+        float dn = 1.f;
+        if (k < K - 1) {
+            const float u = raw[2 * K + k];   // softplus(u) = max(u, 0) + log(1 + exp(-|u|))
+            dn = kRqsMinDeriv + fmaxf(u, 0.f) + fast_ln(1.f + fast_exp(-fabsf(u)));
+        }
+        const bool here = k == 0 || (INVERSE ? vc >= ch : vc >= cw);   // bins are visited in order: the last hit wins
+        x0 = here ? cw : x0;
+        x1 = here ? cwn : x1;
+        y0 = here ? ch : y0;
+        y1 = here ? chn : y1;
+        d0 = here ? dk : d0;
+        d1 = here ? dn : d1;
+        cw = cwn;
+        ch = chn;
+        dk = dn;
+    }
+    const float bw = x1 - x0, bh = y1 - y0;
+    const float s = bh * __builtin_amdgcn_rcpf(bw);
+    const float dd = d0 + d1 - 2.f * s;
+    float th, out;
+    if (INVERSE) {
+        const float dy = vc - y0;
+        const float a = fmaf(dy, dd, bh * (s - d0));
+        const float b = fmaf(-dy, dd, bh * d0);
+        const float c = -s * dy;
+        th = 2.f * c * __builtin_amdgcn_rcpf(-b - __builtin_amdgcn_sqrtf(fmaf(b, b, -4.f * a * c)));
+        out = fmaf(th, bw, x0);
+    } else {
+        th = (vc - x0) * __builtin_amdgcn_rcpf(bw);
+        const float t1 = th * (1.f - th);
+        out = fmaf(bh * fmaf(s * th, th, d0 * t1), __builtin_amdgcn_rcpf(fmaf(dd, t1, s)), y0);
+    }
+    const float t1 = th * (1.f - th), om = 1.f - th;
+    const float den = fmaf(dd, t1, s);
+    const float l = fast_ln(s * s * fmaf(d1 * th, th, fmaf(2.f * s, t1, d0 * om * om))) - 2.f * fast_ln(den);
+    ld += inside ? l : 0.f;
+    return inside ? out : v;
+}
+
+// spline variant of the target loop of coupling_apply: W3 rows are target-major, (3K-1) per target
+template <int HP, bool INVERSE>
+__device__ __forceinline__ float coupling_targets_rqs(float* __restrict__ row, const float* __restrict__ W3,
+                                                      const float* __restrict__ b3, const float (&h)[HP],
+                                                      const FlowGeom& g, bool rev) {
+    constexpr int P = 3 * kRqsBins - 1;
+    float ld = 0.f;
+    for (int t = 0; t < g.d_b; ++t) {
+        float raw[P];
+        const float* wr = W3 + (int64_t)t * P * HP;
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+            float u = b3[t * P + q];
+#pragma unroll
+            for (int k = 0; k < HP; ++k) u = fmaf(wr[q * HP + k], h[k], u);
+            raw[q] = u;
+        }
+        const int p = phys(g.d_a + t, g.d, rev);
+        row[p] = rqs_coordinate<INVERSE>(row[p], raw, g.bound, ld);
+    }
+    return INVERSE ? -ld : ld;
+}
+
 template <int HP, bool INVERSE>
 __device__ __forceinline__ float coupling_apply(float* __restrict__ row, const float* __restrict__ W,
                                                 const FlowGeom& g, bool rev, float* __restrict__ hbuf = nullptr) {
@@ -145,7 +247,8 @@ __device__ __forceinline__ float coupling_apply(float* __restrict__ row, const f
     } else {
         conditioner_hidden<HP>(row, W, g, rev, h);
         W3 = w3_of(W, g, HP);
-        b3 = W3 + (int64_t)2 * g.d_b * HP;
+        b3 = W3 + (int64_t)g.out_rows * HP;
+        if (g.n_bins > 0) return coupling_targets_rqs<HP, INVERSE>(row, W3, b3, h, g, rev);
     }
     float ld = 0.f;
     for (int t = 0; t < g.d_b; ++t) {

@@ -241,7 +241,12 @@ static int check_flow(const NfmcRealNVP* f) {
     if (f->d > 512) return NFMC_ESHAPE;
     if (f->n_hidden > 128) return NFMC_EUNSUPPORTED;
     if (!(f->min_scale >= 0.f && f->min_scale <= 1.f)) return NFMC_EINVAL;   // 1 = additive coupling (exp(-inf) + 1)
-    if (f->n_coupling > 0 && f->layer_stride < nfmc_realnvp_layer_floats(f->d, f->n_hidden, f->n_hidden_layers))
+    if (f->n_bins != 0) {   // spline couplings: 8 bins, VALU conditioners
+        if (f->n_bins != kRqsBins || !(f->spline_bound > 0.f)) return NFMC_EINVAL;
+        if (f->n_hidden > 32) return NFMC_EUNSUPPORTED;
+    }
+    if (f->n_coupling > 0 &&
+        f->layer_stride < nfmc_coupling_layer_floats(f->d, f->n_hidden, f->n_hidden_layers, f->n_bins))
         return NFMC_EINVAL;
     return NFMC_OK;
 }
@@ -274,6 +279,14 @@ extern "C" int64_t nfmc_realnvp_layer_floats(int32_t d, int32_t n_hidden, int32_
     if (hp > 32) return mfma_layer_floats(d, (int)hp, n_hidden_layers);
     const int64_t d_a = d / 2, d_b = d - d_a;
     return d_a * hp + hp + (int64_t)(n_hidden_layers - 1) * (hp * hp + hp) + 2 * d_b * hp + 2 * d_b;
+}
+
+extern "C" int64_t nfmc_coupling_layer_floats(int32_t d, int32_t n_hidden, int32_t n_hidden_layers, int32_t n_bins) {
+    if (n_bins == 0) return nfmc_realnvp_layer_floats(d, n_hidden, n_hidden_layers);
+    if (d <= 0 || n_hidden <= 0 || n_hidden > 32 || n_hidden_layers <= 0 || n_bins != kRqsBins) return 0;
+    const int64_t hp = nfmc_realnvp_padded_hidden(n_hidden);
+    const int64_t d_a = d / 2, d_b = d - d_a, rows = (3 * (int64_t)n_bins - 1) * d_b;
+    return d_a * hp + hp + (int64_t)(n_hidden_layers - 1) * (hp * hp + hp) + rows * hp + rows;
 }
 
 #define NFMC_HP_DISPATCH(HPV, CALL)             \
@@ -342,7 +355,7 @@ extern "C" int nfmc_flow_mh_steps_f32(const NfmcFlowMhArgs* args, nfmc_stream_t 
     int dp = padded_d(d);
     hipStream_t st = (hipStream_t)stream;
     int grid = 0;
-    rc = getenv("NFMC_FLOW_TILE_PATH") ? NFMC_EUNSUPPORTED : flow_mh_b_launch(a, st, &grid, &dp);
+    rc = (getenv("NFMC_FLOW_TILE_PATH") || a.flow.n_bins != 0) ? NFMC_EUNSUPPORTED : flow_mh_b_launch(a, st, &grid, &dp);
     if (rc == NFMC_EUNSUPPORTED) {  // wider conditioners: one chain per lane, wave tiles in LDS
         dp = padded_d(d);
         const int64_t tiles = (a.n + 63) / 64;

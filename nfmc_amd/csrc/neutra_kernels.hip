@@ -372,7 +372,7 @@ static int check_flow_neutra(const NfmcRealNVP* f) {
     if (f->d < 2 && f->n_coupling > 0) return NFMC_ESHAPE;
     if (f->d > 512) return NFMC_ESHAPE;
     if (f->n_hidden_layers > kMaxHiddenLayers) return NFMC_ESHAPE;
-    if (f->n_hidden > 32) return NFMC_EUNSUPPORTED;
+    if (f->n_hidden > 32 || f->n_bins != 0) return NFMC_EUNSUPPORTED;   // spline couplings: no reverse-sweep kernel
     if (f->n_coupling > 0 && f->layer_stride < nfmc_realnvp_layer_floats(f->d, f->n_hidden, f->n_hidden_layers))
         return NFMC_EINVAL;
     return NFMC_OK;
@@ -409,6 +409,7 @@ extern "C" int64_t nfmc_neutra_scratch_bytes(int64_t n, int32_t d, int32_t n_hid
 
 extern "C" int nfmc_neutra_potential_grad_f32(const NfmcRealNVP* flow, const NfmcPotential* pot, const float* z,
                                               int64_t n, float* u_out, float* grad_out, nfmc_stream_t stream) {
+    if (flow && flow->n_bins != 0) return NFMC_EUNSUPPORTED;
     if (flow && flow->n_hidden > 32) return nfmc_neutra_potential_grad_mfma_f32(flow, pot, z, n, u_out, grad_out, stream);
     int rc = check_flow_neutra(flow);
     if (rc) return rc;
@@ -431,6 +432,7 @@ extern "C" int nfmc_neutra_hmc_steps_f32(const NfmcNeutraHmcArgs* args, nfmc_str
     if (!args) return NFMC_EINVAL;
     NfmcNeutraHmcArgs a = *args;
     if (a.stats.sum_x && a.stats.defer) return NFMC_EUNSUPPORTED;   // NeuTra folds its statistics per call
+    if (a.flow.n_bins != 0) return NFMC_EUNSUPPORTED;
     if (a.flow.n_hidden > 32) {
         if (!a.z || a.n <= 0 || a.n_steps <= 0 || a.n_leapfrog <= 0 || !(a.step_size > 0.f)) return NFMC_EINVAL;
         if (a.n_steps > NFMC_MAX_STEPS_PER_CALL) return NFMC_ESHAPE;

@@ -50,7 +50,7 @@ static int check_common(const Args* a) {
         if (!j.flow.ea0_log_scale || !j.flow.ea0_shift || !j.flow.ea1_log_scale || !j.flow.ea1_shift) return NFMC_EINVAL;
         if (j.flow.n_coupling > 0 && !j.flow.weights) return NFMC_EINVAL;
         if (j.flow.n_hidden <= 0 || j.flow.n_hidden_layers <= 0) return NFMC_EINVAL;
-        if (j.flow.n_hidden > 8 || a->d > 512) return NFMC_EUNSUPPORTED;
+        if (j.flow.n_hidden > 8 || a->d > 512 || j.flow.n_bins != 0) return NFMC_EUNSUPPORTED;
         if (!a->stats.sum_x) return NFMC_EINVAL;  // the jump counters travel through the statistics slab
         if (j.adjusted && (j.replay_latent != nullptr) != (j.replay_uniform != nullptr)) return NFMC_EINVAL;
     }

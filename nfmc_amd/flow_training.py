@@ -15,7 +15,9 @@ from copy import deepcopy
 
 import torch
 
-from .flows import MIN_SCALE, AffineCoupling, ElementwiseAffine, ReversePermutation
+from .flows import MIN_SCALE, AffineCoupling, ElementwiseAffine, ReversePermutation, RQSCoupling
+
+RQS_MIN_BIN, RQS_MIN_DERIV = 1e-3, 1e-3
 
 
 def _coupling_params(layer: AffineCoupling, x_a, min_scale=MIN_SCALE):
@@ -30,6 +32,42 @@ def _coupling_params(layer: AffineCoupling, x_a, min_scale=MIN_SCALE):
     return alpha, h[:, layer.d_b:] / 2
 
 
+def _rqs(layer: RQSCoupling, x_a, v, bound, inverse):
+    """Differentiable rational-quadratic spline coupling of the target half v ('c-rqnsf'):
+    returns (transformed v, summed logdet of THIS direction)."""
+    K, B = layer.n_bins, float(bound)
+    h = x_a
+    for lin in layer.conditioner[:-1]:
+        h = torch.tanh(lin(h))
+    raw = layer.conditioner[-1](h).reshape(v.shape[0], layer.d_b, 3 * K - 1)
+    w = RQS_MIN_BIN + (1 - K * RQS_MIN_BIN) * torch.softmax(raw[..., :K], dim=-1)
+    hh = RQS_MIN_BIN + (1 - K * RQS_MIN_BIN) * torch.softmax(raw[..., K:2 * K], dim=-1)
+    zero, one = torch.zeros_like(w[..., :1]), torch.ones_like(w[..., :1])
+    edge = torch.full_like(zero, B)
+    cw = torch.cat([(torch.cat([zero, torch.cumsum(w, -1)], -1) * (2 * B) - B)[..., :-1], edge], -1)
+    ch = torch.cat([(torch.cat([zero, torch.cumsum(hh, -1)], -1) * (2 * B) - B)[..., :-1], edge], -1)
+    dv = torch.cat([one, RQS_MIN_DERIV + torch.nn.functional.softplus(raw[..., 2 * K:]), one], -1)
+    inside = (v >= -B) & (v <= B)
+    vc = v.clamp(-B, B)
+    k = (vc[..., None] >= (ch if inverse else cw)[..., 1:-1]).sum(-1, keepdim=True)
+    take = lambda a, off=0: torch.gather(a, -1, k + off)[..., 0]
+    x0, x1, y0, y1, d0, d1 = take(cw), take(cw, 1), take(ch), take(ch, 1), take(dv), take(dv, 1)
+    bw, bh = x1 - x0, y1 - y0
+    s = bh / bw
+    dd = d0 + d1 - 2 * s
+    if inverse:
+        dy = vc - y0
+        a, b, c = dy * dd + bh * (s - d0), bh * d0 - dy * dd, -s * dy
+        th = 2 * c / (-b - torch.sqrt(b * b - 4 * a * c))
+        out = th * bw + x0
+    else:
+        th = (vc - x0) / bw
+        out = y0 + bh * (s * th * th + d0 * th * (1 - th)) / (s + dd * th * (1 - th))
+    ld = torch.log(s * s * (d1 * th * th + 2 * s * th * (1 - th) + d0 * (1 - th) ** 2)) - 2 * torch.log(s + dd * th * (1 - th))
+    ld = torch.where(inside, -ld if inverse else ld, torch.zeros_like(ld))
+    return torch.where(inside, out, v), ld.sum(-1)
+
+
 def forward_torch(bijection, x):
     """Differentiable x -> (z, logdet) of the RealNVP spec."""
     n = x.shape[0]
@@ -41,6 +79,10 @@ def forward_torch(bijection, x):
             ld = ld + layer.log_scale.sum()
         elif isinstance(layer, ReversePermutation):
             h = h.flip(-1)
+        elif isinstance(layer, RQSCoupling):
+            out, l = _rqs(layer, h[:, :layer.d_a], h[:, layer.d_a:], bijection.spline_bound, False)
+            h = torch.cat([h[:, :layer.d_a], out], dim=1)
+            ld = ld + l
         else:
             alpha, beta = _coupling_params(layer, h[:, :layer.d_a], bijection.min_scale)
             h = torch.cat([h[:, :layer.d_a], alpha * h[:, layer.d_a:] + beta], dim=1)
@@ -58,6 +100,10 @@ def inverse_torch(bijection, z):
             ld = ld - layer.log_scale.sum()
         elif isinstance(layer, ReversePermutation):
             h = h.flip(-1)
+        elif isinstance(layer, RQSCoupling):
+            out, l = _rqs(layer, h[:, :layer.d_a], h[:, layer.d_a:], bijection.spline_bound, True)
+            h = torch.cat([h[:, :layer.d_a], out], dim=1)
+            ld = ld + l
         else:
             alpha, beta = _coupling_params(layer, h[:, :layer.d_a], bijection.min_scale)
             h = torch.cat([h[:, :layer.d_a], (h[:, layer.d_a:] - beta) / alpha], dim=1)

@@ -60,10 +60,27 @@ class AffineCoupling(nn.Module):
         self.conditioner = nn.ModuleList([nn.Linear(dims[i], dims[i + 1]) for i in range(len(dims) - 1)])
 
 
+RQS_BINS, RQS_BOUND = 8, 5.0
+
+
+class RQSCoupling(AffineCoupling):
+    """Half-split rational-quadratic spline coupling ('c-rqnsf'): the conditioner emits, per target coordinate,
+    3K - 1 numbers (K widths | K heights | K - 1 interior derivatives), target-major (oracle/flow.py: rqs_apply)."""
+
+    def __init__(self, d, n_hidden=None, n_layers=2, n_bins=RQS_BINS):
+        super().__init__(d, n_hidden, n_layers)
+        self.n_bins = int(n_bins)
+        dims = [self.d_a] + [self.n_hidden] * self.n_layers + [(3 * self.n_bins - 1) * self.d_b]
+        self.conditioner = nn.ModuleList([nn.Linear(dims[i], dims[i + 1]) for i in range(len(dims) - 1)])
+
+
 class RealNVP(nn.Module):
     """[ElementwiseAffine] + n_layers x [ReversePermutation, AffineCoupling] + [ElementwiseAffine]."""
 
     min_scale = MIN_SCALE   # scale = exp(u/2 + log(1 - min_scale)) + min_scale
+    n_bins = 0              # 0: affine couplings; K: spline couplings with K bins (CRQNSF)
+    spline_bound = RQS_BOUND
+    coupling_class = AffineCoupling
 
     def __init__(self, event_shape, n_layers: int = 2, conditioner_kwargs: Optional[dict] = None, **kwargs):
         super().__init__()
@@ -77,10 +94,13 @@ class RealNVP(nn.Module):
         self.n_coupling = int(n_layers)
         layers = [ElementwiseAffine(self.d)]
         for _ in range(self.n_coupling):
-            layers += [ReversePermutation(), AffineCoupling(self.d, ck.get('n_hidden'), ck.get('n_layers', 2))]
+            layers += [ReversePermutation(), self._make_coupling(ck)]
         layers.append(ElementwiseAffine(self.d))
         self.layers = nn.ModuleList(layers)
         self._pack_cache = None
+
+    def _make_coupling(self, ck):
+        return AffineCoupling(self.d, ck.get('n_hidden'), ck.get('n_layers', 2))
 
     # ------------------------------------------------------------------ packing for the kernels
     @property
@@ -114,10 +134,13 @@ class RealNVP(nn.Module):
         lib = hip.lib()
         d, H, nhl = self.d, max(self.n_hidden, int(min_hidden)), self.n_hidden_layers
         hp = int(lib.nfmc_realnvp_padded_hidden(H))
-        stride = int(lib.nfmc_realnvp_layer_floats(d, H, nhl))
+        stride = int(lib.nfmc_coupling_layer_floats(d, H, nhl, self.n_bins))
+        out_rows = (3 * self.n_bins - 1) * (d - d // 2) if self.n_bins else 2 * (d - d // 2)
         d_a, d_b = d // 2, d - d // 2
         if hp == 0:
             raise ValueError('RealNVP conditioner width %d is beyond the kernels (max 128)' % H)
+        if stride == 0:
+            raise ValueError('spline couplings run with conditioners of width <= 32 and %d bins' % RQS_BINS)
         with torch.no_grad():
             # one preallocated host buffer filled by slice copies (torch.cat of ~1e5 floats spins up the CPU
             # thread pool: 30-40 ms per call, most of the host time of a sample() with a wide conditioner)
@@ -159,15 +182,16 @@ class RealNVP(nn.Module):
                     for l in lin[1:-1]:
                         put(l.weight, hp, hp, transpose=True)
                         put(l.bias, hp)
-                    put(lin[-1].weight, 2 * d_b, hp)
+                    put(lin[-1].weight, out_rows, hp)
                     put(lin[-1].bias)
                 assert cur[0] == (li + 1) * stride, (cur[0], li, stride)
             weights = torch.from_numpy(flat).to(device)
             ea0, ea1 = self.layers[0], self.layers[-1]
             keep = [weights] + [t.detach().float().contiguous().to(device)
                                 for t in (ea0.log_scale, ea0.shift, ea1.log_scale, ea1.shift)]
-        st = hip.NfmcRealNVP(d, self.n_coupling, H, nhl, float(self.min_scale), 0, hip.ptr(keep[1]), hip.ptr(keep[2]),
-                             hip.ptr(keep[3]), hip.ptr(keep[4]), hip.ptr(keep[0]), stride)
+        st = hip.NfmcRealNVP(d, self.n_coupling, H, nhl, float(self.min_scale), int(self.n_bins), hip.ptr(keep[1]),
+                             hip.ptr(keep[2]), hip.ptr(keep[3]), hip.ptr(keep[4]), hip.ptr(keep[0]), stride,
+                             float(self.spline_bound), 0)
         cache[int(min_hidden)] = (key, (st, keep))
         self._pack_cache = cache
         return st, keep
@@ -205,6 +229,17 @@ class NICE(RealNVP):
     scale half of the conditioner output is carried but inert (zero gradient)."""
 
     min_scale = 1.0
+
+
+class CRQNSF(RealNVP):
+    """Coupling rational-quadratic neural spline flow ('c-rqnsf', nfmc/util.py:17): the RealNVP stack with
+    RQSCoupling layers (8 bins on [-5, 5], identity outside).  Same kernels for forward / inverse / sampling / the
+    flow-proposal Metropolis step (one chain per lane); NeuTra needs the reverse sweep and is not covered."""
+
+    n_bins = RQS_BINS
+
+    def _make_coupling(self, ck):
+        return RQSCoupling(self.d, ck.get('n_hidden'), ck.get('n_layers', 2), self.n_bins)
 
 
 class Flow(nn.Module):

@@ -39,9 +39,9 @@ class NfmcStats(C.Structure):
 
 class NfmcRealNVP(C.Structure):
     _fields_ = [('d', C.c_int32), ('n_coupling', C.c_int32), ('n_hidden', C.c_int32), ('n_hidden_layers', C.c_int32),
-                ('min_scale', C.c_float), ('reserved', C.c_int32),
+                ('min_scale', C.c_float), ('n_bins', C.c_int32),
                 ('ea0_log_scale', c_fp), ('ea0_shift', c_fp), ('ea1_log_scale', c_fp), ('ea1_shift', c_fp),
-                ('weights', c_fp), ('layer_stride', C.c_int64)]
+                ('weights', c_fp), ('layer_stride', C.c_int64), ('spline_bound', C.c_float), ('reserved', C.c_int32)]
 
 
 class NfmcJumpTail(C.Structure):
@@ -97,6 +97,7 @@ SYMBOLS = [
     ('nfmc_hmc_steps_f32', C.c_int, [C.POINTER(NfmcHmcArgs), c_fp]),
     ('nfmc_realnvp_padded_hidden', C.c_int32, [C.c_int32]),
     ('nfmc_realnvp_layer_floats', C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    ('nfmc_coupling_layer_floats', C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     ('nfmc_realnvp_forward_f32', C.c_int, [C.POINTER(NfmcRealNVP), c_fp, C.c_int64, c_fp, c_fp, c_fp, c_fp]),
     ('nfmc_realnvp_inverse_f32', C.c_int, [C.POINTER(NfmcRealNVP), c_fp, C.c_int64, c_fp, c_fp, c_fp,
                                            C.POINTER(NfmcRng), c_fp]),

@@ -80,13 +80,14 @@ def flow_is_native(flow) -> bool:
     if not isinstance(bij, RealNVP):
         return False
     lim = hip.limits()
-    return bij.d <= lim.max_d_flow and bij.n_hidden <= lim.max_hidden
+    return bij.d <= lim.max_d_flow and bij.n_hidden <= (32 if bij.n_bins else lim.max_hidden)
 
 
 def flow_fits_jump_tail(flow) -> bool:
     """The jump can ride at the end of the inner sampler's launch (NfmcJumpTail): narrow conditioner, d <= 512."""
     bij = getattr(flow, 'bijection', None)
-    return isinstance(bij, RealNVP) and bij.n_hidden <= 8 and bij.d <= 512 and bij.n_hidden_layers <= 4
+    return (isinstance(bij, RealNVP) and bij.n_hidden <= 8 and bij.d <= 512 and bij.n_hidden_layers <= 4
+            and bij.n_bins == 0)
 
 
 def make_jump_tail(run: Run, flow, adjusted):

@@ -1,6 +1,6 @@
 """Flow-spec strings and the Metropolis log-ratio (nfmc/util.py:189-215, 218-281, 382-392).
 
-The half-split coupling flows `realnvp` and `nice` are on this build's path; the reference's other ~58
+The half-split coupling flows `realnvp`, `nice` and `c-rqnsf` are on this build's path; the reference's other ~57
 architecture names live in torchflows and raise a clear error here instead of silently mapping to something else.
 """
 import json
@@ -9,6 +9,7 @@ from typing import Dict, List
 FLOW_NAMES: Dict[str, List[str]] = {
     'realnvp': ['realnvp', 'real_nvp', 'rnvp'],  # nfmc/util.py:6
     'nice': ['nice'],                            # nfmc/util.py:13
+    'c-rqnsf': ['c-rqnsf', 'c-rqsnsf'],          # nfmc/util.py:17
 }
 
 
@@ -35,7 +36,7 @@ def parse_flow_string(flow_string: str):
 
 def create_flow_object(flow_string: str, event_shape, **kwargs):
     """nfmc/util.py:218-281,379 for the realnvp branch."""
-    from .flows import NICE, Flow, RealNVP
+    from .flows import CRQNSF, NICE, Flow, RealNVP
     data = parse_flow_string(flow_string)
     name = data['name']
     kwargs.update(data['kwargs'])
@@ -43,7 +44,7 @@ def create_flow_object(flow_string: str, event_shape, **kwargs):
         raise ValueError
     if not is_flow_supported(name):
         raise ValueError(f"flow '{name}' is outside this build's path (supported: {get_supported_normalizing_flows()})")
-    cls = NICE if name in FLOW_NAMES['nice'] else RealNVP
+    cls = NICE if name in FLOW_NAMES['nice'] else (CRQNSF if name in FLOW_NAMES['c-rqnsf'] else RealNVP)
     return Flow(cls(event_shape, **kwargs))
 
 

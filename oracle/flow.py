@@ -129,6 +129,102 @@ class RealNVP(nn.Module):
         return h.reshape(z.shape), logdet
 
 
+# ---- rational-quadratic spline coupling ('c-rqnsf', nfmc/util.py:17; Durkan et al. 2019).  Build-defined like the
+# affine coupling above (torchflows absent): K bins on [-B, B], identity outside, linear tails (boundary
+# derivatives 1).  Per target coordinate t the conditioner emits P = 3K - 1 numbers at indices t*P + (0..P):
+#   K unnormalised widths | K unnormalised heights | K - 1 unnormalised interior derivatives
+#   widths  w = MIN_BIN + (1 - K MIN_BIN) softmax(.), knots cw_0 = -B, cw_{k+1} = cw_k + 2B w_k (cw_K = B)
+#   heights likewise (ch);  derivatives d_0 = d_K = 1, d_k = MIN_DERIV + softplus(.)
+# forward  x in bin k: th = (x - cw_k) / (2B w_k), s = h_k / w_k (h, w = bin height / width),
+#   y = ch_k + h (s th^2 + d_k th (1 - th)) / (s + (d_k + d_{k+1} - 2 s) th (1 - th))
+#   logdet = log(s^2 (d_{k+1} th^2 + 2 s th (1 - th) + d_k (1 - th)^2)) - 2 log(s + (d_k + d_{k+1} - 2 s) th (1 - th))
+RQS_BINS, RQS_BOUND, RQS_MIN_BIN, RQS_MIN_DERIV = 8, 5.0, 1e-3, 1e-3
+
+
+def rqs_params(raw, K=RQS_BINS, B=RQS_BOUND):
+    """raw (..., 3K-1) -> knot positions cw, ch (..., K+1) and derivatives d (..., K+1)."""
+    uw, uh, ud = raw[..., :K], raw[..., K:2 * K], raw[..., 2 * K:]
+    w = RQS_MIN_BIN + (1 - K * RQS_MIN_BIN) * torch.softmax(uw, dim=-1)
+    h = RQS_MIN_BIN + (1 - K * RQS_MIN_BIN) * torch.softmax(uh, dim=-1)
+    zero = torch.zeros_like(w[..., :1])
+    cw = torch.cat([zero, torch.cumsum(w, dim=-1)], dim=-1) * (2 * B) - B
+    ch = torch.cat([zero, torch.cumsum(h, dim=-1)], dim=-1) * (2 * B) - B
+    cw = torch.cat([cw[..., :-1], torch.full_like(zero, B)], dim=-1)
+    ch = torch.cat([ch[..., :-1], torch.full_like(zero, B)], dim=-1)
+    one = torch.ones_like(zero)
+    d = torch.cat([one, RQS_MIN_DERIV + torch.nn.functional.softplus(ud), one], dim=-1)
+    return cw, ch, d
+
+
+def rqs_apply(v, raw, inverse, K=RQS_BINS, B=RQS_BOUND):
+    """elementwise spline of v (...,) with parameters raw (..., 3K-1); returns (out, logdet of THIS direction)."""
+    cw, ch, d = rqs_params(raw, K, B)
+    inside = (v >= -B) & (v <= B)
+    vc = v.clamp(-B, B)
+    knots = ch if inverse else cw
+    k = (vc[..., None] >= knots[..., 1:-1]).sum(-1, keepdim=True)          # bin index 0..K-1
+    take = lambda a, off=0: torch.gather(a, -1, k + off)[..., 0]
+    x0, x1, y0, y1 = take(cw), take(cw, 1), take(ch), take(ch, 1)
+    d0, d1 = take(d), take(d, 1)
+    bw, bh = x1 - x0, y1 - y0
+    s = bh / bw
+    if inverse:
+        dy = vc - y0
+        a = dy * (d0 + d1 - 2 * s) + bh * (s - d0)
+        b = bh * d0 - dy * (d0 + d1 - 2 * s)
+        c = -s * dy
+        th = 2 * c / (-b - torch.sqrt(b * b - 4 * a * c))
+        out = th * bw + x0
+    else:
+        th = (vc - x0) / bw
+        out = y0 + bh * (s * th * th + d0 * th * (1 - th)) / (s + (d0 + d1 - 2 * s) * th * (1 - th))
+    den = s + (d0 + d1 - 2 * s) * th * (1 - th)
+    ld = torch.log(s * s * (d1 * th * th + 2 * s * th * (1 - th) + d0 * (1 - th) ** 2)) - 2 * torch.log(den)
+    if inverse:
+        ld = -ld
+    return torch.where(inside, out, v), torch.where(inside, ld, torch.zeros_like(ld))
+
+
+class RQSCoupling(nn.Module):
+    def __init__(self, d, n_hidden=None, n_layers=2, n_bins=RQS_BINS):
+        super().__init__()
+        self.d_a = d // 2
+        self.d_b = d - self.d_a
+        self.n_bins = int(n_bins)
+        h = default_hidden(self.d_a) if n_hidden is None else int(n_hidden)
+        dims = [self.d_a] + [h] * int(n_layers) + [(3 * self.n_bins - 1) * self.d_b]
+        self.conditioner = nn.ModuleList([nn.Linear(dims[i], dims[i + 1]) for i in range(len(dims) - 1)])
+
+    def _raw(self, x_a):
+        h = x_a
+        for lin in self.conditioner[:-1]:
+            h = torch.tanh(lin(h))
+        return self.conditioner[-1](h).reshape(x_a.shape[0], self.d_b, 3 * self.n_bins - 1)
+
+    def forward(self, x):
+        out, ld = rqs_apply(x[:, self.d_a:], self._raw(x[:, :self.d_a]), False, self.n_bins)
+        return torch.cat([x[:, :self.d_a], out], dim=1), ld.sum(-1)
+
+    def inverse(self, z):
+        out, ld = rqs_apply(z[:, self.d_a:], self._raw(z[:, :self.d_a]), True, self.n_bins)
+        return torch.cat([z[:, :self.d_a], out], dim=1), ld.sum(-1)
+
+
+class CRQNSF(RealNVP):
+    """[ElementwiseAffine] + n_layers x [ReversePermutation, RQSCoupling] + [ElementwiseAffine]."""
+
+    def __init__(self, event_shape, n_layers: int = 2, conditioner_kwargs: dict = None, n_bins: int = RQS_BINS, **kwargs):
+        super().__init__(event_shape, n_layers=n_layers, conditioner_kwargs=conditioner_kwargs, **kwargs)
+        d = int(math.prod(self.event_shape))
+        ck = dict(conditioner_kwargs or {})
+        ck.update({k: v for k, v in kwargs.items() if k in ('n_hidden',)})
+        layers = list(self.layers)
+        for i, m in enumerate(layers):
+            if isinstance(m, AffineCoupling):
+                layers[i] = RQSCoupling(d, ck.get('n_hidden'), ck.get('n_layers', 2), n_bins)
+        self.layers = nn.ModuleList(layers)
+
+
 class NICE(RealNVP):
     """Additive couplings (nfmc/util.py:13 'nice'): the same stack, every coupling scale = 1, logdet of the
     couplings = 0.  Build-defined like RealNVP above (torchflows absent)."""

@@ -952,3 +952,64 @@ def test_edge_c_abi_argument_errors(dev):
     a.n_steps, a.stats = 4, raw
     with pytest.raises(ValueError, match='scratch'):
         hip.check(hip.lib().nfmc_mala_steps_f32(C.byref(a), hip.stream()), 'nfmc_mala_steps_f32')
+
+
+@pytest.mark.parametrize('d,nl,nh,cl', [(6, 2, None, 2), (7, 3, 5, 1), (64, 2, 16, 2), (33, 2, 32, 2)])
+def test_rqs_flow_matches_oracle_and_known_answers(dev, d, nl, nh, cl):
+    """'c-rqnsf' through the kernels (nfmc_realnvp_forward/inverse_f32 with n_bins = 8): forward, inverse, log_prob
+    and sampling against the oracle's spline; tolerances: fp32 kernels with hardware exp/log/rcp/sqrt."""
+    from nfmc_amd.util import create_flow_object
+    from nfmc_amd.flows import CRQNSF
+    from oracle import flow as oflow
+    ck = {'n_layers': cl}
+    if nh is not None:
+        ck['n_hidden'] = nh
+    torch.manual_seed(d * 7 + nl)
+    # wide inputs with O(1) weights saturate the softmaxes (bins at the minimum width, slopes ~1e3) and make the
+    # fp32 round trip meaningless; keep the splines moderately bent at large d
+    of = oflow.perturb_(oflow.Flow(oflow.CRQNSF((d,), n_layers=nl, conditioner_kwargs=ck)), 9, 1.0 if d <= 8 else 0.25, 0.8)
+    f = create_flow_object('c-rqnsf', (d,), n_layers=nl, conditioner_kwargs=ck)
+    assert isinstance(f.bijection, CRQNSF)
+    f.load_state_dict(of.state_dict())
+    x = torch.randn(400, d) * 1.5
+    x[:5] *= 6.0    # beyond the spline bound in some coordinates: identity there
+    with torch.no_grad():
+        z0, ld0 = of.bijection.forward(x)
+        lp0 = of.log_prob(x)
+        xi0, ldi0 = of.bijection.inverse(x)
+    z, ld = f.bijection.forward(x)
+    np.testing.assert_allclose(z.cpu().numpy(), z0.numpy(), atol=2e-4, rtol=1e-4)
+    np.testing.assert_allclose(ld.cpu().numpy(), ld0.numpy(), atol=1e-3, rtol=1e-4)
+    np.testing.assert_allclose(f.log_prob(x).cpu().numpy(), lp0.numpy(), atol=5e-3, rtol=2e-4)
+    xi, ldi = f.bijection.inverse(x)
+    np.testing.assert_allclose(xi.cpu().numpy(), xi0.numpy(), atol=5e-4, rtol=1e-4)
+    np.testing.assert_allclose(ldi.cpu().numpy(), ldi0.numpy(), atol=1e-3, rtol=1e-4)
+    xb, ldb = f.bijection.inverse(z)
+    np.testing.assert_allclose(xb.cpu().numpy(), x.numpy(), atol=5e-3, rtol=1e-4)
+    np.testing.assert_allclose(ldb.cpu().numpy(), -ld.cpu().numpy(), atol=2e-2, rtol=2e-3)   # fp32 round trip
+    xs, lq = f.sample(500, return_log_prob=True)
+    err = (lq - f.log_prob(xs)).abs().cpu()        # inverse pass vs forward pass of the same point: an fp32 round trip
+    assert float(err.max()) < 5e-2 and float((err < 3e-3).float().mean()) > 0.98
+
+
+def test_rqs_flow_in_jump_and_imh_strategies(dev):
+    """Spline flows drive the flow-proposal Metropolis kernels (one chain per lane): jump_mala and imh run, moments
+    of the N(0, I/2) target come out, a fit lifts the jump acceptance; NeuTra is refused with a clear error."""
+    from nfmc_amd import sample
+    from nfmc_amd.potentials import SumOfSquares
+    from nfmc_amd.util import create_flow_object
+    d = 8
+    torch.manual_seed(0)
+    flow = create_flow_object('c-rqnsf', (d,))
+    data = torch.randn(4096, d) * 0.7071
+    flow.fit(data[:3000], x_val=data[3000:], n_epochs=150, lr=0.02)
+    out = sample(SumOfSquares((d,)), strategy='jump_mala', flow=flow, n_chains=2048, n_iterations=10, show_progress=False,
+                 inner_param_kwargs={'n_iterations': 20}, param_kwargs={'store_samples': False}, seed=3)
+    st = out.statistics
+    assert st.n_attempted_jumps == 2048 * 10 and st.jump_acceptance_rate > 0.3
+    assert abs(float(out.variance.mean()) - 0.5) < 0.03 and float(out.mean.abs().max()) < 0.05
+    out = sample(SumOfSquares((d,)), strategy='imh', flow=flow, n_chains=2048, n_iterations=50, show_progress=False, seed=4)
+    assert out.samples.shape == (50, 2048, d) and out.statistics.acceptance_rate > 0.3
+    assert abs(float(out.variance.mean()) - 0.5) < 0.05
+    with pytest.raises(ValueError):
+        sample(SumOfSquares((d,)), strategy='neutra_hmc', flow=flow, n_chains=64, n_iterations=2, show_progress=False)

@@ -381,3 +381,35 @@ def test_integration_stub_structs_match_the_header():
     for name in ('NfmcPotential', 'NfmcRng', 'NfmcStats', 'NfmcMalaArgs'):
         assert C.sizeof(ns[name]) == C.sizeof(getattr(hip, name)), name
         assert [f[0] for f in ns[name]._fields_] == [f[0] for f in getattr(hip, name)._fields_], name
+
+
+def test_rqs_flow_string_and_training_restatement():
+    """'c-rqnsf' (nfmc/util.py:17): flow string, layer count, differentiable restatement equals the oracle's spline."""
+    from nfmc_amd.flows import CRQNSF, RQSCoupling
+    from nfmc_amd.util import create_flow_object, is_flow_supported
+    from nfmc_amd import flow_training as ft
+    from oracle import flow as oflow
+    assert is_flow_supported('c-rqnsf') and is_flow_supported('c-rqsnsf')
+    f = create_flow_object('c-rqnsf%{"n_layers": 3, "conditioner_kwargs": {"n_hidden": 6}}', (7,))
+    assert isinstance(f.bijection, CRQNSF) and len(f.bijection.layers) == 8
+    assert sum(isinstance(m, RQSCoupling) for m in f.bijection.layers) == 3
+    assert f.bijection.layers[2].conditioner[-1].out_features == 23 * 4
+    torch.manual_seed(0)
+    of = oflow.perturb_(oflow.Flow(oflow.CRQNSF((7,), n_layers=3, conditioner_kwargs={'n_hidden': 6})), 3, 1.0)
+    f.load_state_dict(of.state_dict())
+    x = torch.randn(50, 7) * 2.5
+    with torch.no_grad():
+        z, ld = ft.forward_torch(f.bijection, x)
+        zo, ldo = of.bijection.forward(x)
+        xi, ldi = ft.inverse_torch(f.bijection, z)
+        xio, ldio = of.bijection.inverse(z)
+    np.testing.assert_allclose(z.numpy(), zo.numpy(), atol=1e-6)
+    np.testing.assert_allclose(ld.numpy(), ldo.numpy(), atol=1e-5)
+    np.testing.assert_allclose(xi.numpy(), xio.numpy(), atol=1e-6)
+    np.testing.assert_allclose(ldi.numpy(), ldio.numpy(), atol=1e-5)
+    np.testing.assert_allclose(xi.numpy(), x.numpy(), atol=5e-3)      # fp32 round trip through three spline layers
+    # the restatement is differentiable in the weights (what Flow.fit needs)
+    zz, ll = ft.forward_torch(f.bijection, x)
+    loss = (0.5 * (zz * zz).sum(-1) - ll).mean()
+    loss.backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in f.parameters())

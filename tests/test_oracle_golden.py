@@ -151,3 +151,31 @@ def test_metropolis_log_ratio_convention():
     fx = load_golden('util')
     a, b, c, d = (np.array(v, np.float32) for v in ([1.0, -2.0], [0.5, 3.0], [0.25, 0.0], [-1.0, 4.0]))
     np.testing.assert_allclose(b - a + c - d, fx['log_ratio'])
+
+
+def test_rqs_flow_known_answers():
+    """'c-rqnsf' (build-defined spline couplings, parity unpinned): the known answers of SURVEY 8c on the CPU spec:
+    round trip, logdet antisymmetry, logdet = slogdet of the autograd Jacobian, identity outside [-B, B]."""
+    from oracle import flow as oflow
+    torch.manual_seed(3)
+    d = 6
+    f = oflow.perturb_(oflow.Flow(oflow.CRQNSF((d,), n_layers=3, conditioner_kwargs={'n_hidden': 5})), 4, 1.5).double()
+    x = torch.randn(200, d, dtype=torch.float64) * 2.0
+    with torch.no_grad():
+        z, ld = f.bijection.forward(x)
+        xb, ldi = f.bijection.inverse(z)
+    np.testing.assert_allclose(xb.numpy(), x.numpy(), atol=1e-10)
+    np.testing.assert_allclose(ldi.numpy(), -ld.numpy(), atol=1e-10)
+    for i in range(5):
+        J = torch.autograd.functional.jacobian(lambda v: f.bijection.forward(v[None])[0][0], x[i])
+        np.testing.assert_allclose(float(torch.linalg.slogdet(J)[1]), float(ld[i]), atol=1e-9)
+    # the spline really bends the map (not an affine flow in disguise) and is the identity beyond the bound
+    c = f.bijection.layers[2]
+    far = torch.full((3, d), 7.5, dtype=torch.float64)
+    out, l0 = c.forward(far)
+    assert torch.equal(out, far) and float(l0.abs().max()) == 0.0
+    mid = torch.linspace(-4, 4, 50, dtype=torch.float64)[:, None].repeat(1, d)
+    out, _ = c.forward(mid)
+    second = out[2:, -1] - 2 * out[1:-1, -1] + out[:-2, -1]
+    assert float(second.abs().max()) > 1e-4
+    assert len(f.bijection.layers) == 2 + 2 * 3
