@@ -121,8 +121,8 @@ struct JumpDev {
 // One flow-proposal Metropolis jump on the registers of the chain (jump.py:205-243).  Returns accept.
 // (The fused kernels cap their VGPR budget at 128 so the jump tail, executed once per launch, cannot cost the
 // inner loop its occupancy: __launch_bounds__ below.)
-template <int CPL, int LPC, int HP, class PotT>
-__device__ __forceinline__ bool jump_once(float (&x)[CPL], const FlowB<CPL, LPC, HP, true>& fl, const PotT& pot,
+template <int CPL, int LPC, int HP, class FlowT, class PotT>
+__device__ __forceinline__ bool jump_once(float (&x)[CPL], const FlowT& fl, const PotT& pot,
                                           const JumpDev& j, uint64_t seed, uint32_t step, uint32_t gchain, int64_t row,
                                           int64_t n, int d, int g, bool active, float& lr_out, bool& bad) {
     const bool revl = (j.flow.n_coupling & 1) != 0;
@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(kBlock, NFMC_WPE) mala_kernel(NfmcMalaArgs a, 
     Pot<CPL, LPC, FAST> pot;
     pot.init(a.pot, g, d);
     if constexpr (Pot<CPL, LPC, FAST>::kQuadratic) mc.init_quadratic(pot, rw);
-    FlowB<CPL, LPC, JHP == 0 ? 4 : JHP, true> fl;
+    FlowB<CPL, LPC, JHP == 0 ? 4 : JHP, true, (FAST && CPL >= 8 && JHP > 0)> fl;
     if constexpr (JHP > 0) {
         FlowImage<CPL, LPC, JHP>::stage(flow_lds, jd.flow, kBlock);
         __syncthreads();
@@ -329,7 +329,7 @@ __global__ void __launch_bounds__(kBlock, NFMC_WPE) hmc_kernel(NfmcHmcArgs a, in
     mc.init(h, 0.f, a.inv_mass_diag, g, d);
     Pot<CPL, LPC, FAST> pot;
     pot.init(a.pot, g, d);
-    FlowB<CPL, LPC, JHP == 0 ? 4 : JHP, true> fl;
+    FlowB<CPL, LPC, JHP == 0 ? 4 : JHP, true, (FAST && CPL >= 8 && JHP > 0)> fl;
     if constexpr (JHP > 0) {
         FlowImage<CPL, LPC, JHP>::stage(flow_lds, jd.flow, kBlock);
         __syncthreads();

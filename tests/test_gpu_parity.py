@@ -1013,3 +1013,26 @@ def test_rqs_flow_in_jump_and_imh_strategies(dev):
     assert abs(float(out.variance.mean()) - 0.5) < 0.05
     with pytest.raises(ValueError):
         sample(SumOfSquares((d,)), strategy='neutra_hmc', flow=flow, n_chains=64, n_iterations=2, show_progress=False)
+
+
+@pytest.mark.parametrize('strategy', ['jump_mala', 'jump_hmc'])
+def test_fused_jump_tail_exact_fit_equals_separate_jump_launch(dev, strategy):
+    """d = 64 (exact-fit layout): the jump riding at the end of the inner launch (NfmcJumpTail) and the separate
+    flow-MH launch simulate the same chains from the same Philox streams."""
+    from nfmc_amd.sample import create_sampler
+    from nfmc_amd.potentials import SumOfSquares
+    outs = []
+    for fuse in (False, True):
+        torch.manual_seed(5)
+        s = create_sampler(SumOfSquares((64,)), strategy=strategy, flow='realnvp', param_kwargs={'n_iterations': 4},
+                           inner_param_kwargs={'n_iterations': 6})
+        s.fuse_jump_tail = fuse
+        s.seed = 21
+        torch.manual_seed(6)
+        outs.append(s.sample(torch.randn(700, 64) * 0.7, show_progress=False))
+    a, b = outs
+    assert a.samples.shape == b.samples.shape == (4 * 7, 700, 64)
+    close = ((a.samples - b.samples).abs().amax(dim=(0, 2)) < 1e-4).float().mean()
+    assert float(close) > 0.99
+    assert abs(a.statistics.n_accepted_jumps - b.statistics.n_accepted_jumps) <= 2
+    assert a.statistics.n_attempted_jumps == b.statistics.n_attempted_jumps == 4 * 700
