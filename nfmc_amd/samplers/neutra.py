@@ -64,6 +64,13 @@ class NeuTra(Sampler):
         n = _z.shape[0]
         dev = hip.require_gpu()
         grad_needed = torch.is_grad_enabled() and _z.requires_grad
+        if grad_needed and getattr(self.kernel.flow.bijection, 'n_bins', 0):
+            # spline couplings have no reverse-sweep kernel: differentiate the torch restatement of the flow
+            from ..flow_training import inverse_torch
+            x, log_det_inverse = inverse_torch(self.kernel.flow.bijection, _z.to(dev, torch.float32))
+            x = x.reshape(n, *self.event_shape)
+            adjusted_potential = self.target(x).reshape(-1) - log_det_inverse.reshape(-1)
+            return (adjusted_potential, x) if return_data else adjusted_potential
         if grad_needed:
             return _AdjustedPotential.apply(_z, self)
         x, log_det_inverse = self.kernel.flow.bijection.inverse(_z)
@@ -119,7 +126,7 @@ class NeuTra(Sampler):
         run = Run(self, x0)
         n, d, event_shape = run.n, run.d, run.event_shape
         pot = resolve_target(self.target, event_shape)
-        if not isinstance(inner, HMC) or pot is None:
+        if not isinstance(inner, HMC) or pot is None or getattr(self.kernel.flow.bijection, 'n_bins', 0):
             # NeuTraMH / arbitrary targets: the inner sampler's split path on the adjusted target (neutra.py:116-127)
             inner.seed, inner.shard, inner.replay = self.seed, self.shard, self.replay
             out = inner.sample(x0, show_progress=show_progress, time_limit_seconds=time_limit_seconds)
