@@ -3,10 +3,11 @@
 // n_hidden = 128).  Layout and GEMM scheme: mfma_device.hpp.  Replaces neutra.py:58-68 + hmc.py:40-77,96-126.
 //
 // 16 chains per wave (v_mfma_f32_16x16x4_f32), 8 waves = 128 chains per workgroup, two waves per SIMD.
-// One trajectory = n_leapfrog launches of `neutra_leapfrog_mfma_kernel`; the first also draws the
-// momentum and records H0, the last also does the Hamiltonian test, the masked update and the statistics.
-// Between launches zq / p / grad live in caller-supplied scratch (HBM): 3 tiles read + 3 written per
-// leapfrog = 6*4*d bytes per chain against ~0.5 MFLOP of conditioner GEMMs -- compute bound by >10x.
+// One launch of `neutra_leapfrog_mfma_kernel` = one whole trajectory of every chain: momentum draw and H0, the
+// n_leapfrog steps with position and gradient tiles resident in registers from one step to the next, then the
+// Hamiltonian test, the masked update and the statistics.  Only the momentum tile goes through caller-supplied
+// HBM scratch (stored before each gradient, reloaded after it: it must not be live through the GEMMs):
+// 2*4*d bytes per chain per leapfrog against ~0.5 MFLOP of conditioner GEMMs.
 #include "mfma_device.hpp"
 
 namespace nfmc {
@@ -275,9 +276,8 @@ __global__ void __launch_bounds__(kMfmaBlock, 2) neutra_grad_mfma_kernel(NfmcRea
 
 struct LeapArgs {
     NfmcNeutraHmcArgs a;
-    float *zq, *p, *g, *gz, *uz, *h0;  // scratch: trajectory position / momentum / grad, grad and U~ at the state, H0
-    int step;                           // transition index within this call
-    int first, last;
+    float *p, *gz, *uz, *h0;  // scratch: momentum; gradient and U~ at the current state; H0
+    int step;                  // transition index within this call
 };
 
 // mass / momentum helpers in C layout: tile position pos <-> logical latent coordinate (rev ? d-1-pos : pos)
@@ -309,20 +309,25 @@ __global__ void __launch_bounds__(kMfmaBlock, 2) neutra_leapfrog_mfma_kernel(Lea
     double* red = reinterpret_cast<double*>(lds + 2 * kImgFloats + 2 * kVecFloats);  // [8 waves][2*d + 2]
     WeightPipe wp{lds, 0};
     uint32_t n_acc = 0, n_bad = 0;
-    if (A.last) {
-        for (int i = threadIdx.x; i < kMfmaWaves * (2 * d + 2); i += kMfmaBlock) red[i] = 0.0;
-        __syncthreads();
-    }
+    for (int i = threadIdx.x; i < kMfmaWaves * (2 * d + 2); i += kMfmaBlock) red[i] = 0.0;
+    __syncthreads();
+    const int L = a.n_leapfrog;
 
     for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        const int64_t row_in = tile * kMfmaChains + wave * 16 + col;
-        const bool active = row_in < n;
-        const int64_t rrow_in = active ? row_in : n - 1;
+        const int64_t row_t = tile * kMfmaChains + wave * 16 + col;
+        const bool active = row_t < n;
+        const int64_t rrow_t = active ? row_t : n - 1;
         f32x4 x[TD], g[TD];
+        float u = 0.f;
+        for (int l = 0; l < L; ++l) {
         {
+            // per-step opaque copies of the row index: the HBM addresses below are loop invariant and would
+            // otherwise be hoisted out of the leapfrog loop and held through every gradient
+            int64_t row_in = row_t, rrow_in = rrow_t;
+            asm volatile("" : "+v"(row_in), "+v"(rrow_in));
             f32x4 p[TD], mass[TD];
             mass_tiles<TD>(mass, a.inv_mass_diag, half, rev);
-            if (A.first) {
+            if (l == 0) {
                 load_ctiles<TD>(x, a.z, rrow_in, d, half, rev);
                 load_ctiles<TD>(g, A.gz, rrow_in, d, half, rev);
                 float kin = 0.f;
@@ -353,9 +358,7 @@ __global__ void __launch_bounds__(kMfmaBlock, 2) neutra_leapfrog_mfma_kernel(Lea
                 }
                 kin = chain_sum(kin);
                 if (active && half == 0) A.h0[row_in] = A.uz[row_in] + 0.5f * kin;  // hmc.py:103-106
-            } else {
-                load_ctiles<TD>(x, A.zq, rrow_in, d, half, rev);
-                load_ctiles<TD>(g, A.g, rrow_in, d, half, rev);
+            } else {   // position and gradient tiles are still in registers from the previous step
                 load_ctiles<TD>(p, A.p, rrow_in, d, half, rev);
             }
 #pragma unroll
@@ -367,10 +370,10 @@ __global__ void __launch_bounds__(kMfmaBlock, 2) neutra_leapfrog_mfma_kernel(Lea
                 }
             if (active) store_ctiles<TD>(p, A.p, row_in, d, half, rev);  // momentum is not live across the GEMMs
         }
-        const float u = adjusted_grad_c<TD, TH, NHL>(x, g, a.flow, a.pot, wp, col, half, lane);
+        u = adjusted_grad_c<TD, TH, NHL>(x, g, a.flow, a.pot, wp, col, half, lane);
         // everything below addresses HBM by the row index: an opaque copy keeps that address arithmetic from
         // being computed before the gradient and held in registers through it (cf. stage_matrix)
-        int64_t row = row_in, rrow = rrow_in;
+        int64_t row = row_t, rrow = rrow_t;
         asm volatile("" : "+v"(row), "+v"(rrow));
         f32x4 p[TD];
         load_ctiles<TD>(p, A.p, rrow, d, half, rev);
@@ -378,12 +381,8 @@ __global__ void __launch_bounds__(kMfmaBlock, 2) neutra_leapfrog_mfma_kernel(Lea
         for (int m = 0; m < TD; ++m)
 #pragma unroll
             for (int t = 0; t < 4; ++t) p[m][t] = fmaf(-hh, g[m][t], p[m][t]);  // hmc.py:71
-        if (!A.last) {
-            if (active) {
-                store_ctiles<TD>(x, A.zq, row, d, half, rev);
-                store_ctiles<TD>(p, A.p, row, d, half, rev);
-                store_ctiles<TD>(g, A.g, row, d, half, rev);
-            }
+        if (l + 1 < L) {
+            if (active) store_ctiles<TD>(p, A.p, row, d, half, rev);
             continue;
         }
         // ---- end of the trajectory: Hamiltonian test, masked update, statistics
@@ -451,8 +450,9 @@ __global__ void __launch_bounds__(kMfmaBlock, 2) neutra_leapfrog_mfma_kernel(Lea
                     }
                 }
         }
+        }  // leapfrog steps
     }
-    if (A.last && a.stats.sum_x) {
+    if (a.stats.sum_x) {
         for (int m = 1; m < 16; m <<= 1) {   // counted on lane group 0 only
             n_acc += __shfl_xor(n_acc, m, kWave);
             n_bad += __shfl_xor(n_bad, m, kWave);
@@ -496,10 +496,8 @@ static int run_hmc(const NfmcNeutraHmcArgs& a, float* scratch, hipStream_t st) {
     const int64_t n = a.n;
     LeapArgs A;
     A.a = a;
-    A.zq = scratch;
-    A.p = A.zq + n * d;
-    A.g = A.p + n * d;
-    A.gz = A.g + n * d;
+    A.p = scratch;
+    A.gz = A.p + n * d;
     A.uz = A.gz + n * d;
     A.h0 = A.uz + n;
     int rc = launch_grad<TD, TH, NHL>(a.flow, a.pot, a.z, n, A.uz, A.gz, st);
@@ -511,12 +509,8 @@ static int run_hmc(const NfmcNeutraHmcArgs& a, float* scratch, hipStream_t st) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMfmaLdsBytes);
     if (e != hipSuccess) return (int)e;
     for (int s = 0; s < a.n_steps; ++s) {
-        for (int l = 0; l < a.n_leapfrog; ++l) {
-            A.step = s;
-            A.first = (l == 0);
-            A.last = (l == a.n_leapfrog - 1);
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(kMfmaBlock), kMfmaLdsBytes, st, A, tiles, dp);
-        }
+        A.step = s;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kMfmaBlock), kMfmaLdsBytes, st, A, tiles, dp);
         if (a.stats.sum_x) {
             hipLaunchKernelGGL(stats_finish_kernel<false>, dim3(stats_finish_grid(dp)), dim3(kFinishBlock), 0, st,
                                a.stats.scratch, grid, dp, d, a.stats, (unsigned long long)n);
