@@ -119,8 +119,8 @@ struct JumpDev {
 };
 
 // One flow-proposal Metropolis jump on the registers of the chain (jump.py:205-243).  Returns accept.
-// (The fused kernels cap their VGPR budget at 128 so the jump tail, executed once per launch, cannot cost the
-// inner loop its occupancy: __launch_bounds__ below.)
+// The flow code lifts a fused kernel to ~208 VGPRs (occupancy 5 -> 2 for the whole launch), which costs the inner
+// transitions more than the separate flow-MH launch: the tail is exercised by the tests but off by default.
 template <int CPL, int LPC, int HP, class FlowT, class PotT>
 __device__ __forceinline__ bool jump_once(float (&x)[CPL], const FlowT& fl, const PotT& pot,
                                           const JumpDev& j, uint64_t seed, uint32_t step, uint32_t gchain, int64_t row,
