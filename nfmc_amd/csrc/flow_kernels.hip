@@ -251,6 +251,14 @@ static int check_flow(const NfmcRealNVP* f) {
     return NFMC_OK;
 }
 
+// shapes served by the matrix-core flow kernels (flow_mfma.hip); NFMC_FLOW_NO_MFMA=1 keeps the VALU kernels (A/B, tests)
+static bool use_mfma_flow(const NfmcRealNVP* f) {
+    return f->n_bins == 0 && f->n_coupling > 0 && nfmc_mfma_supported(f->d, f->n_hidden, f->n_hidden_layers) &&
+           !getenv("NFMC_FLOW_NO_MFMA");
+}
+
+static bool al16(const void* p) { return ((uintptr_t)p & 15u) == 0; }   // NULL counts as aligned
+
 static int hp_bucket(int h) { return h <= 4 ? 4 : (h <= 8 ? 8 : (h <= 16 ? 16 : 32)); }
 
 template <class K>
@@ -307,6 +315,7 @@ extern "C" int nfmc_realnvp_forward_f32(const NfmcRealNVP* flow, const float* x,
     int rc = check_flow(flow);
     if (rc) return rc;
     if (!x || n <= 0) return NFMC_EINVAL;
+    if (use_mfma_flow(flow) && al16(x) && al16(z)) return nfmc_realnvp_forward_mfma_f32(flow, x, n, z, logdet, log_prob, stream);
     const int64_t tiles = (n + 63) / 64;
     const int grid = (int)(tiles < 4 * kMaxGrid ? tiles : 4 * kMaxGrid);
     const size_t lds = (size_t)64 * tile_stride(flow->d) * sizeof(float) + hbuf_bytes(flow->n_hidden);
@@ -328,6 +337,7 @@ extern "C" int nfmc_realnvp_inverse_f32(const NfmcRealNVP* flow, const float* z,
     NfmcRng r = {};
     if (rng) r = *rng;
     r.replay_normals = nullptr;  // explicit latents come through `z`
+    if (use_mfma_flow(flow) && al16(x) && al16(z)) return nfmc_realnvp_inverse_mfma_f32(flow, z, n, x, logdet, log_q, &r, stream);
     const int64_t tiles = (n + 63) / 64;
     const int grid = (int)(tiles < 4 * kMaxGrid ? tiles : 4 * kMaxGrid);
     const size_t lds = (size_t)64 * tile_stride(flow->d) * sizeof(float) + hbuf_bytes(flow->n_hidden);
@@ -356,7 +366,11 @@ extern "C" int nfmc_flow_mh_steps_f32(const NfmcFlowMhArgs* args, nfmc_stream_t 
     hipStream_t st = (hipStream_t)stream;
     int grid = 0;
     rc = (getenv("NFMC_FLOW_TILE_PATH") || a.flow.n_bins != 0) ? NFMC_EUNSUPPORTED : flow_mh_b_launch(a, st, &grid, &dp);
-    if (rc == NFMC_EUNSUPPORTED) {  // wider conditioners: one chain per lane, wave tiles in LDS
+    if (rc == NFMC_EUNSUPPORTED && use_mfma_flow(&a.flow) && al16(a.x) && al16(a.samples)) {
+        // wide conditioners at d = 64 / 128 (16-byte aligned rows): matrix cores
+        rc = nfmc_flow_mh_steps_mfma_f32(a, stream, &grid, &dp);
+        if (rc) return rc;
+    } else if (rc == NFMC_EUNSUPPORTED) {  // wider conditioners: one chain per lane, wave tiles in LDS
         dp = padded_d(d);
         const int64_t tiles = (a.n + 63) / 64;
         grid = (int)(tiles < kMaxGrid ? tiles : kMaxGrid);

@@ -193,6 +193,12 @@ int nfmc_neutra_potential_grad_mfma_f32(const NfmcRealNVP* flow, const NfmcPoten
                                         float* u_out, float* grad_out, nfmc_stream_t stream);
 int nfmc_neutra_hmc_steps_mfma_f32(const NfmcNeutraHmcArgs* args, float* scratch, int64_t scratch_bytes,
                                    nfmc_stream_t stream);
+// entry points of flow_mfma.hip used by the C ABI in flow_kernels.hip (shapes: nfmc_mfma_supported)
+int nfmc_realnvp_forward_mfma_f32(const NfmcRealNVP* f, const float* x, int64_t n, float* z, float* logdet,
+                                  float* log_prob, nfmc_stream_t stream);
+int nfmc_realnvp_inverse_mfma_f32(const NfmcRealNVP* f, const float* z, int64_t n, float* x, float* logdet,
+                                  float* log_q, const NfmcRng* rng, nfmc_stream_t stream);
+int nfmc_flow_mh_steps_mfma_f32(const NfmcFlowMhArgs& a, nfmc_stream_t stream, int* grid_out, int* dp_out);
 
 // ---- the weight pipeline: two LDS images (+ their vector areas) used STRICTLY ALTERNATELY, one per GEMM.
 // A wave stages the operand of GEMM k right after it finished GEMM k-1, into the image GEMM k-2 read; every

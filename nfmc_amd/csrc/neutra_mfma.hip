@@ -8,7 +8,7 @@
 // Hamiltonian test, the masked update and the statistics.  Only the momentum tile goes through caller-supplied
 // HBM scratch (stored before each gradient, reloaded after it: it must not be live through the GEMMs):
 // 2*4*d bytes per chain per leapfrog against ~0.5 MFLOP of conditioner GEMMs.
-#include "mfma_device.hpp"
+#include "mfma_flow.hpp"
 
 namespace nfmc {
 
@@ -54,38 +54,6 @@ __device__ __forceinline__ float potential_value_grad_c(const f32x4 (&x)[TD], f3
         }
     }
     return chain_sum(u);
-}
-
-// ---- inverse coupling layer, forward sweep (v -> y): returns this lane's share of the layer's logdet_inverse
-template <int TD, int TH, int NHL, bool REV>
-__device__ __forceinline__ float coupling_inverse_c(f32x4 (&x)[TD], const MLayer& L, float mscale, float log1m,
-                                                    WeightPipe& wp, int col, int half) {
-    constexpr int TS = TD / 2, SRC0 = REV ? TS : 0, TGT0 = REV ? 0 : TS, D2 = 8 * TD, hp = 16 * TH;
-    f32x4 hl[TH];   // activations of the last hidden layer
-    {
-        f32x4 src[TS], h1[TH];
-#pragma unroll
-        for (int ms = 0; ms < TS; ++ms) src[ms] = x[SRC0 + ms];
-        if constexpr (NHL > 1) hidden_stack<TS, TH, NHL>(src, h1, hl, L, REV, wp, col, half);
-        else hidden_stack<TS, TH, NHL>(src, hl, h1, L, REV, wp, col, half);
-    }
-    wp.template stage<hp, D2, 1, D2>(L.W3, 2 * D2, REV, false, L.b3, 2 * D2, REV);
-    const float* img = wp.img();
-    const float* vec = wp.vec();
-    float ld = 0.f;
-#pragma unroll
-    for (int mt = 0; mt < TS; ++mt) {
-        f32x4 ua = vec_tile(vec, mt, half), ub = vec_tile(vec, TS + mt, half);
-        gemm_tile<TH>(ua, img + (16 * mt + col) * (hp + 4) + 4 * half, hl);
-        gemm_tile<TH>(ub, img + (16 * (TS + mt) + col) * (hp + 4) + 4 * half, hl);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const float alpha = fast_exp(fmaf(0.5f, ua[t], log1m)) + mscale;
-            x[TGT0 + mt][t] = (x[TGT0 + mt][t] - 0.5f * ub[t]) * __builtin_amdgcn_rcpf(alpha);
-            ld -= fast_ln(alpha);
-        }
-    }
-    return ld;
 }
 
 // ---- reverse sweep through one inverse coupling layer: (y, dL/dy) -> (v, dL/dv); L = U(x) + sum log alpha.
@@ -194,31 +162,7 @@ __device__ __forceinline__ float adjusted_grad_c(f32x4 (&x)[TD], f32x4 (&g)[TD],
     constexpr int d = 16 * TD, hp = 16 * TH;
     const bool rev_last = (f.n_coupling & 1) != 0;
     const float log1m = __logf(1.f - f.min_scale);
-    float ldp = 0.f;
-#pragma unroll
-    for (int m = 0; m < TD; ++m) {  // EA1^-1
-        const f32x4 ls = rev_last ? vec_tile_rev(f.ea1_log_scale, m, half, d) : vec_tile(f.ea1_log_scale, m, half);
-        const f32x4 sh = rev_last ? vec_tile_rev(f.ea1_shift, m, half, d) : vec_tile(f.ea1_shift, m, half);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            x[m][t] = (x[m][t] - sh[t]) * fast_exp(-ls[t]);
-            ldp -= ls[t];
-        }
-    }
-    for (int l = f.n_coupling - 1; l >= 0; --l) {
-        const MLayer L = mfma_layer(f.weights + l * f.layer_stride, d, hp, NHL);
-        if ((l & 1) == 0) ldp += coupling_inverse_c<TD, TH, NHL, true>(x, L, f.min_scale, log1m, wp, col, half);
-        else ldp += coupling_inverse_c<TD, TH, NHL, false>(x, L, f.min_scale, log1m, wp, col, half);
-    }
-#pragma unroll
-    for (int m = 0; m < TD; ++m) {  // EA0^-1
-        const f32x4 ls = vec_tile(f.ea0_log_scale, m, half), sh = vec_tile(f.ea0_shift, m, half);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            x[m][t] = (x[m][t] - sh[t]) * fast_exp(-ls[t]);
-            ldp -= ls[t];
-        }
-    }
+    float ldp = flow_inverse_sweep_c<TD, TH, NHL>(x, f, wp, col, half);
     const float u = potential_value_grad_c<TD>(x, g, pot, half, lane);
     // reverse sweep
 #pragma unroll

@@ -17,6 +17,7 @@ The parameters are ordinary `nn.Parameter`s; `packed(device)` lays them out for 
 """
 import ctypes as C
 import math
+import os
 from typing import Optional, Tuple
 
 import numpy as np
@@ -120,12 +121,22 @@ class RealNVP(nn.Module):
     def _version_key(self, device):
         return (str(device),) + tuple((p.data_ptr(), p._version) for p in self.parameters())
 
-    def packed(self, device, min_hidden: int = 0):
+    def default_min_hidden(self) -> int:
+        """Width to present to the flow kernels by default: at d = 64 / 128 a conditioner of width 9..32 is faster
+        zero-padded to 64 on the matrix cores (flow_mfma.hip) than on the one-chain-per-lane kernels (C3 shape, jump
+        per outer step: H = 32 0.57 -> 0.47 ms).  Narrower ones stay on the register-layout kernel."""
+        ok = (self.d in (64, 128) and 8 < self.n_hidden <= 32 and self.n_hidden_layers in (1, 2) and self.n_bins == 0
+              and os.environ.get('NFMC_FLOW_NO_MFMA') is None)
+        return 64 if ok else 0
+
+    def packed(self, device, min_hidden: int = None):
         """(NfmcRealNVP struct, keep-alive tensors) on `device`; rebuilt only when a parameter changed.
 
         `min_hidden`: present the conditioner as at least that wide (extra hidden units have zero weights, so
         tanh(0) = 0 contributes nothing: same function).  NeuTra uses 64 to reach the matrix-core kernels with
         narrow conditioners (d = 128, H = 8: 6.6 -> ~3 ms per transition)."""
+        if min_hidden is None:
+            min_hidden = self.default_min_hidden()
         key = self._version_key(device) + (int(min_hidden),)
         cache = self._pack_cache if isinstance(self._pack_cache, dict) else {}
         hit = cache.get(int(min_hidden))

@@ -1041,3 +1041,36 @@ def test_fused_jump_tail_exact_fit_equals_separate_jump_launch(dev, strategy):
     assert float(close) > 0.99
     assert abs(a.statistics.n_accepted_jumps - b.statistics.n_accepted_jumps) <= 2
     assert a.statistics.n_attempted_jumps == b.statistics.n_attempted_jumps == 4 * 700
+
+
+@pytest.mark.parametrize('d,nh,cl,strategy', [(64, 64, 1, 'imh'), (128, 128, 2, 'jump_mala'), (64, 40, 2, 'jump_hmc')])
+def test_wide_flow_metropolis_on_matrix_cores_equals_valu_kernels(dev, d, nh, cl, strategy, monkeypatch):
+    """Wide conditioners at d = 64 / 128: forward / inverse / flow-MH run on the matrix cores (flow_mfma.hip); the
+    one-chain-per-lane kernels (NFMC_FLOW_NO_MFMA=1) simulate the same chains from the same Philox streams."""
+    from nfmc_amd.sample import create_sampler
+    from nfmc_amd.flows import Flow, RealNVP
+    from nfmc_amd.potentials import SumOfSquares
+    from oracle import flow as oflow
+    ck = {'n_hidden': nh, 'n_layers': cl}
+    torch.manual_seed(d + nh)
+    of = oflow.perturb_(oflow.Flow(oflow.RealNVP((d,), n_layers=2, conditioner_kwargs=ck)), 4, 0.05, 0.75)
+    outs = []
+    for no_mfma in (False, True):
+        if no_mfma:
+            monkeypatch.setenv('NFMC_FLOW_NO_MFMA', '1')
+        f = Flow(RealNVP((d,), n_layers=2, conditioner_kwargs=ck))
+        f.load_state_dict(of.state_dict())
+        kw = {'inner_param_kwargs': {'n_iterations': 3}} if strategy != 'imh' else {}
+        s = create_sampler(SumOfSquares((d,)), strategy=strategy, flow=f, param_kwargs={'n_iterations': 5}, **kw)
+        s.seed = 17
+        torch.manual_seed(9)
+        outs.append(s.sample(torch.randn(300, d) * 0.7, show_progress=False))
+    a, b = outs
+    assert a.samples.shape == b.samples.shape
+    close = ((a.samples - b.samples).abs().amax(dim=(0, 2)) < 2e-3).float().mean()
+    assert float(close) > 0.97, float(close)
+    sa, sb = a.statistics, b.statistics
+    key = 'n_accepted_jumps' if strategy != 'imh' else 'n_accepted_trajectories'
+    assert abs(getattr(sa, key) - getattr(sb, key)) <= 3
+    assert getattr(sa, key) > 20          # the flow is close to the target: jumps do get accepted
+    np.testing.assert_allclose(a.mean.numpy(), b.mean.numpy(), atol=2e-3)
