@@ -18,7 +18,6 @@
 // no index arithmetic and no branches, also for ragged d.
 #pragma once
 
-#include <type_traits>
 
 #include "common.hpp"
 #include "flow_device.hpp"
@@ -125,11 +124,7 @@ struct FlowB {
     using Img = FlowImage<CPL, LPC, HP>;
     static constexpr int DP = CPL * LPC;
     static_assert(!EXACT || CPL >= 8, "EXACT needs whole register quads per half");
-    // wave-uniform weights are read through the scalar cache (s_load -> SGPR operands): constant address space
-    typedef const float __attribute__((address_space(4))) cfloat;
     const float* img;  // LDS
-    const cfloat* mid;  // global: b1 | [WhT | bh] x (n_hl - 1) of layer 0
-    int64_t gstride;
     int n_hl, n_coupling, lf, g;
     float m, log1m;
 
@@ -141,8 +136,6 @@ struct FlowB {
         m = f.min_scale;
         log1m = __logf(1.f - f.min_scale);
         g = g_;
-        mid = (const cfloat*)(uintptr_t)(f.weights + (f.d / 2) * HP);
-        gstride = f.layer_stride;
     }
 
     // Make the image pointer opaque to the optimiser.  The weights are loop-invariant across the chain tiles of
@@ -157,13 +150,10 @@ struct FlowB {
         constexpr int S0 = EXACT ? (REV ? CPL / 2 : 0) : 0, S1 = EXACT ? S0 + CPL / 2 : CPL;       // source registers
         constexpr int T0 = EXACT ? (REV ? 0 : CPL / 2) : 0, T1 = EXACT ? T0 + CPL / 2 : CPL;       // target registers
         const float* W1 = img + l * lf + g * HP;
-        // hidden-stack weights are wave-uniform: through the scalar cache for HP = 4 (24 SGPRs per layer), from
-        // the LDS image (broadcast 128-bit reads) for HP = 8, where 80 SGPRs per layer would spill to VGPR lanes
-        constexpr bool MID_LDS = HP > 4;
-        using midp = typename std::conditional<MID_LDS, const float*, const cfloat*>::type;
-        midp b1;
-        if constexpr (MID_LDS) b1 = img + l * lf + DP * HP;
-        else b1 = mid + l * gstride;
+        // hidden-stack weights are wave-uniform: broadcast 128-bit reads from the LDS image.  (Through the scalar
+        // cache -- constant address space, s_load, SGPR operands -- they cost 24 (HP = 4) / 80 (HP = 8) SGPRs per
+        // layer, spilled to VGPR lanes at HP = 8, and measured 3-5 % slower at both widths.)
+        const float* b1 = img + l * lf + DP * HP;
         float h[HP];
 #pragma unroll
         for (int k = 0; k < HP; ++k) h[k] = 0.f;
@@ -177,28 +167,19 @@ struct FlowB {
         }
         {
             float bb[HP];
-            if constexpr (MID_LDS) load_row16<HP>(bb, b1);
-            else
-#pragma unroll
-                for (int k = 0; k < HP; ++k) bb[k] = b1[k];
+            load_row16<HP>(bb, b1);
 #pragma unroll
             for (int k = 0; k < HP; ++k) h[k] = fast_tanh(group_allreduce<LPC>(h[k]) + bb[k]);
         }
-        midp Wh = b1 + HP;
+        const float* Wh = b1 + HP;
         for (int hl = 1; hl < n_hl; ++hl) {
             float t[HP];
-            midp bh = Wh + HP * HP;
-            if constexpr (MID_LDS) load_row16<HP>(t, bh);
-            else
-#pragma unroll
-                for (int k = 0; k < HP; ++k) t[k] = bh[k];
+            const float* bh = Wh + HP * HP;
+            load_row16<HP>(t, bh);
 #pragma unroll
             for (int i = 0; i < HP; ++i) {
                 float wr[HP];
-                if constexpr (MID_LDS) load_row16<HP>(wr, Wh + i * HP);
-                else
-#pragma unroll
-                    for (int k = 0; k < HP; ++k) wr[k] = Wh[i * HP + k];
+                load_row16<HP>(wr, Wh + i * HP);
 #pragma unroll
                 for (int k = 0; k < HP; ++k) t[k] = fmaf(wr[k], h[i], t[k]);
             }
