@@ -413,3 +413,15 @@ def test_rqs_flow_string_and_training_restatement():
     loss = (0.5 * (zz * zz).sum(-1) - ll).mean()
     loss.backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in f.parameters())
+
+
+def test_default_kernel_width_policy():
+    """At d = 64 / 128 conditioners of width 9..32 are presented zero-padded to 64 (matrix-core flow kernels); narrow
+    ones, other shapes and spline flows are left alone (flows.py: default_min_hidden)."""
+    from nfmc_amd.flows import CRQNSF, RealNVP
+    mk = lambda d, h, cls=RealNVP, cl=2: cls((d,), conditioner_kwargs={'n_hidden': h, 'n_layers': cl})
+    assert mk(64, 16).default_min_hidden() == 64 and mk(128, 32).default_min_hidden() == 64
+    assert mk(64, 8).default_min_hidden() == 0 and mk(64, 4).default_min_hidden() == 0
+    assert mk(100, 16).default_min_hidden() == 0 and mk(64, 16, cl=3).default_min_hidden() == 0
+    assert mk(64, 64).default_min_hidden() == 0          # already wide: nothing to pad
+    assert mk(64, 16, CRQNSF).default_min_hidden() == 0
