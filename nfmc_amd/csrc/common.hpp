@@ -300,6 +300,9 @@ static __device__ __forceinline__ double take(double* p) {
     return v;
 }
 
+// ZERO: the slabs are zeroed as they are read, so the scratch is all-zero again after every fold.  Every launch site
+// uses it: a fold-per-call launch leaves nothing behind that a later DEFERRED launch (which adds to the slabs) could
+// pick up when the two modes are mixed within one run.
 template <bool ZERO = false>
 static __global__ void __launch_bounds__(kFinishBlock) stats_finish_kernel(double* __restrict__ scratch,
                                                                            int nblocks, int dp, int d, NfmcStats st,

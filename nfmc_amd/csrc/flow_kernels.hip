@@ -387,7 +387,7 @@ extern "C" int nfmc_flow_mh_steps_f32(const NfmcFlowMhArgs* args, nfmc_stream_t 
     }
     NFMC_HIP_CHECK_LAUNCH();
     if (a.stats.sum_x && !a.stats.defer) {
-        hipLaunchKernelGGL(stats_finish_kernel<false>, dim3(stats_finish_grid(dp)), dim3(kFinishBlock), 0, st, a.stats.scratch, grid, dp, d, a.stats,
+        hipLaunchKernelGGL(stats_finish_kernel<true>, dim3(stats_finish_grid(dp)), dim3(kFinishBlock), 0, st, a.stats.scratch, grid, dp, d, a.stats,
                            (unsigned long long)a.n * (unsigned long long)a.n_steps);
         NFMC_HIP_CHECK_LAUNCH();
     }

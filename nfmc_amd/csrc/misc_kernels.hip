@@ -206,7 +206,7 @@ extern "C" int nfmc_moments_update_f32(const float* x, int64_t rows, int32_t d, 
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(moments_kernel, dim3(grid), dim3(kBlock), 0, st, x, rows, (int)d, dp, stats->scratch);
     NFMC_HIP_CHECK_LAUNCH();
-    hipLaunchKernelGGL(stats_finish_kernel<false>, dim3(stats_finish_grid(dp)), dim3(kFinishBlock), 0, st, stats->scratch, grid, dp, (int)d, *stats, 0ull);
+    hipLaunchKernelGGL(stats_finish_kernel<true>, dim3(stats_finish_grid(dp)), dim3(kFinishBlock), 0, st, stats->scratch, grid, dp, (int)d, *stats, 0ull);
     NFMC_HIP_CHECK_LAUNCH();
     return NFMC_OK;
 }
@@ -266,7 +266,7 @@ extern "C" int nfmc_mh_accept_select_f32(const NfmcSelectArgs* args, nfmc_stream
     }
     NFMC_HIP_CHECK_LAUNCH();
     if (a.stats.sum_x && !a.stats.defer) {
-        hipLaunchKernelGGL(stats_finish_kernel<false>, dim3(stats_finish_grid(dp)), dim3(kFinishBlock), 0, st, a.stats.scratch, grid, dp, a.d, a.stats,
+        hipLaunchKernelGGL(stats_finish_kernel<true>, dim3(stats_finish_grid(dp)), dim3(kFinishBlock), 0, st, a.stats.scratch, grid, dp, a.d, a.stats,
                            (unsigned long long)a.n);
         NFMC_HIP_CHECK_LAUNCH();
     }

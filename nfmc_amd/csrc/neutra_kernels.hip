@@ -462,7 +462,7 @@ extern "C" int nfmc_neutra_hmc_steps_f32(const NfmcNeutraHmcArgs* args, nfmc_str
     })
     NFMC_HIP_CHECK_LAUNCH();
     if (a.stats.sum_x) {
-        hipLaunchKernelGGL(stats_finish_kernel<false>, dim3(stats_finish_grid(dp)), dim3(kFinishBlock), 0, st, a.stats.scratch,
+        hipLaunchKernelGGL(stats_finish_kernel<true>, dim3(stats_finish_grid(dp)), dim3(kFinishBlock), 0, st, a.stats.scratch,
                            grid, dp, d, a.stats, (unsigned long long)a.n * (unsigned long long)a.n_steps);
         NFMC_HIP_CHECK_LAUNCH();
     }

@@ -456,7 +456,7 @@ static int run_hmc(const NfmcNeutraHmcArgs& a, float* scratch, hipStream_t st) {
         A.step = s;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kMfmaBlock), kMfmaLdsBytes, st, A, tiles, dp);
         if (a.stats.sum_x) {
-            hipLaunchKernelGGL(stats_finish_kernel<false>, dim3(stats_finish_grid(dp)), dim3(kFinishBlock), 0, st,
+            hipLaunchKernelGGL(stats_finish_kernel<true>, dim3(stats_finish_grid(dp)), dim3(kFinishBlock), 0, st,
                                a.stats.scratch, grid, dp, d, a.stats, (unsigned long long)n);
         }
     }

@@ -113,7 +113,7 @@ extern "C" int nfmc_mala_steps_f32(const NfmcMalaArgs* args, nfmc_stream_t strea
     if (rc) return rc;
     NFMC_HIP_CHECK_LAUNCH();
     if (a.stats.sum_x && !a.stats.defer) {
-        hipLaunchKernelGGL(stats_finish_kernel<false>, dim3(stats_finish_grid(dp)), dim3(kFinishBlock), 0, st, a.stats.scratch,
+        hipLaunchKernelGGL(stats_finish_kernel<true>, dim3(stats_finish_grid(dp)), dim3(kFinishBlock), 0, st, a.stats.scratch,
                            grid, dp, a.d, a.stats, (unsigned long long)a.n * (unsigned long long)a.n_steps, jc,
                            (unsigned long long)a.n);
         NFMC_HIP_CHECK_LAUNCH();
@@ -146,7 +146,7 @@ extern "C" int nfmc_hmc_steps_f32(const NfmcHmcArgs* args, nfmc_stream_t stream)
     if (rc) return rc;
     NFMC_HIP_CHECK_LAUNCH();
     if (a.stats.sum_x && !a.stats.defer) {
-        hipLaunchKernelGGL(stats_finish_kernel<false>, dim3(stats_finish_grid(dp)), dim3(kFinishBlock), 0, st, a.stats.scratch,
+        hipLaunchKernelGGL(stats_finish_kernel<true>, dim3(stats_finish_grid(dp)), dim3(kFinishBlock), 0, st, a.stats.scratch,
                            grid, dp, a.d, a.stats, (unsigned long long)a.n * (unsigned long long)a.n_steps, jc,
                            (unsigned long long)a.n);
         NFMC_HIP_CHECK_LAUNCH();

@@ -1074,3 +1074,52 @@ def test_wide_flow_metropolis_on_matrix_cores_equals_valu_kernels(dev, d, nh, cl
     assert abs(getattr(sa, key) - getattr(sb, key)) <= 3
     assert getattr(sa, key) > 20          # the flow is close to the target: jumps do get accepted
     np.testing.assert_allclose(a.mean.numpy(), b.mean.numpy(), atol=2e-3)
+
+
+def test_mixed_deferred_and_immediate_statistics(dev):
+    """Closed-form potential (fused inner launches: deferred statistics) with a FOREIGN flow object (jump through the
+    split path: statistics folded per call): the two modes alternate on one scratch and must not contaminate each
+    other -- the run equals the all-fused run of the same chains."""
+    from nfmc_amd.sample import create_sampler
+    from nfmc_amd.flows import Flow, RealNVP
+    from nfmc_amd.potentials import SumOfSquares
+    d = 16
+
+    class Foreign(torch.nn.Module):   # duck-typed flow (sampling/base.py:18-26): delegates to a native one
+        def __init__(self, inner):
+            super().__init__()
+            self.inner = inner
+            self.bijection = _Bij(inner.bijection)
+        event_shape = (d,)
+        def sample(self, n, return_log_prob=False, no_grad=False, rng=None):
+            return self.inner.sample(n, return_log_prob=return_log_prob, rng=rng)
+        def log_prob(self, x):
+            return self.inner.log_prob(x)
+
+    class _Bij:
+        def __init__(self, b):
+            self._b = b
+            self.event_shape, self.layers = b.event_shape, b.layers
+        def forward(self, x):
+            return self._b.forward(x)
+        def inverse(self, z):
+            return self._b.inverse(z)
+
+    outs = []
+    for foreign in (False, True):
+        torch.manual_seed(3)
+        f = Flow(RealNVP((d,)))
+        f.seed = 99
+        s = create_sampler(SumOfSquares((d,)), strategy='jump_mala', flow=Foreign(f) if foreign else f,
+                           param_kwargs={'n_iterations': 6, 'store_samples': False}, inner_param_kwargs={'n_iterations': 7})
+        s.seed = 5
+        torch.manual_seed(4)
+        outs.append(s.sample(torch.randn(3000, d) * 0.7, show_progress=False))
+    a, b = outs
+    sa, sb = a.statistics, b.statistics
+    assert sa.n_attempted_trajectories == sb.n_attempted_trajectories == 3000 * 42
+    assert sa.n_attempted_jumps == sb.n_attempted_jumps == 3000 * 6
+    # the inner transitions see the same noise; the jumps draw their latents from different streams, so compare moments
+    assert abs(sa.acceptance_rate - sb.acceptance_rate) < 0.02
+    np.testing.assert_allclose(a.second_moment.numpy(), b.second_moment.numpy(), atol=0.03)
+    assert abs(float(b.variance.mean()) - 0.5) < 0.03 and abs(float(a.variance.mean()) - 0.5) < 0.03
