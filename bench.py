@@ -81,7 +81,8 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    distributed = world > 1
+    # NFMC_BENCH_FORCE_DIST=1: take the multi-rank code path (RCCL init, barriers, all-reduce) with one rank (rehearsal)
+    distributed = world > 1 or os.environ.get('NFMC_BENCH_FORCE_DIST') == '1'
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if distributed:

@@ -8,6 +8,7 @@ independent between flow refits (mcmc/base.py:74-77), so the only traffic is
 Native noise is keyed by the GLOBAL chain id (Shard.bounds -> chain_offset), so the chains a rank
 simulates are bit-for-bit the chains a single GPU would have simulated.
 """
+import os
 from typing import Tuple
 
 import torch
@@ -23,6 +24,11 @@ class Shard:
             world = tdist.get_world_size(group) if tdist.is_initialized() else 1
         self.rank, self.world = int(rank), int(world)
 
+    def _single(self) -> bool:
+        """One rank: the collectives are identities and skipped (NFMC_SHARD_NO_SHORTCUT=1 runs them anyway, to
+        rehearse the RCCL code path on a single GPU)."""
+        return self.world == 1 and not (os.environ.get('NFMC_SHARD_NO_SHORTCUT') == '1' and tdist.is_initialized())
+
     def bounds(self, n_global: int) -> Tuple[int, int]:
         """Contiguous block of chains owned by this rank (block sizes differ by at most one)."""
         base, rem = divmod(n_global, self.world)
@@ -35,7 +41,7 @@ class Shard:
         return t
 
     def broadcast_int(self, value: int) -> int:
-        if self.world == 1:
+        if self._single():
             return int(value)
         dev = 'cpu' if tdist.get_backend(self.group) == 'gloo' else torch.device('cuda', torch.cuda.current_device())
         t = torch.tensor([int(value)], dtype=torch.int64, device=dev)
@@ -44,7 +50,7 @@ class Shard:
 
     def all_gather_rows(self, rows: torch.Tensor) -> torch.Tensor:
         """C1: concatenate every rank's (k, ...) block in rank order (equal k on every rank)."""
-        if self.world == 1:
+        if self._single():
             return rows
         src = self._backend_device(rows.contiguous())
         out = torch.empty((self.world * src.shape[0],) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
@@ -52,7 +58,7 @@ class Shard:
         return out.to(rows.device)
 
     def all_reduce_sum_(self, t: torch.Tensor) -> torch.Tensor:
-        if self.world == 1:
+        if self._single():
             return t
         buf = self._backend_device(t)
         tdist.all_reduce(buf, op=tdist.ReduceOp.SUM, group=self.group)
@@ -62,7 +68,7 @@ class Shard:
 
     def merge_statistics(self, st):
         """C2: make `st` (MCMCStatistics / JumpNFMCStatistics) the statistics of ALL chains on every rank."""
-        if self.world == 1:
+        if self._single():
             return st
         e1, e2 = st.expectations['first_moment'], st.expectations['second_moment']
         d = e1.total.numel()
