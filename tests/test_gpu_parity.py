@@ -1123,3 +1123,32 @@ def test_mixed_deferred_and_immediate_statistics(dev):
     assert abs(sa.acceptance_rate - sb.acceptance_rate) < 0.02
     np.testing.assert_allclose(a.second_moment.numpy(), b.second_moment.numpy(), atol=0.03)
     assert abs(float(b.variance.mean()) - 0.5) < 0.03 and abs(float(a.variance.mean()) - 0.5) < 0.03
+
+
+@pytest.mark.parametrize('strategy', ['mala', 'hmc', 'mh', 'imh', 'adaptive_imh', 'jump_mala', 'jump_hmc', 'neutra_hmc'])
+def test_sampling_time_limit(dev, strategy):
+    """Mirror of the reference's test/test_time_limit.py (skipped there: "may not terminate"): a million iterations
+    under a one-second sampling limit return promptly with whatever was done."""
+    import time
+    from nfmc_amd import sample
+    torch.manual_seed(0)
+    t0 = time.time()
+    out = sample(lambda x: torch.sum(x ** 2, dim=1), event_shape=(10,), strategy=strategy, n_chains=64,
+                 n_iterations=1_000_000, sampling_time_limit_seconds=1.0, warmup=False, show_progress=False,
+                 param_kwargs={'store_samples': False} if strategy != 'adaptive_imh' else {'n_iterations': 200})
+    assert time.time() - t0 < 15.0
+    assert out.statistics.n_attempted_trajectories > 0 and torch.isfinite(out.mean).all()
+
+
+@pytest.mark.parametrize('strategy', ['mala', 'jump_mala', 'imh'])
+def test_warmup_time_limit(dev, strategy):
+    """Second half of the reference's test/test_time_limit.py: warmup under a time limit, then sampling under one."""
+    import time
+    from nfmc_amd import sample
+    torch.manual_seed(0)
+    t0 = time.time()
+    out = sample(lambda x: torch.sum(x ** 2, dim=1), event_shape=(10,), strategy=strategy, n_chains=64,
+                 n_iterations=1_000_000, n_warmup_iterations=1_000_000, sampling_time_limit_seconds=1.0,
+                 warmup_time_limit_seconds=1.0, warmup=True, show_progress=False, param_kwargs={'store_samples': False})
+    assert time.time() - t0 < 25.0
+    assert out.statistics.n_attempted_trajectories > 0 and torch.isfinite(out.mean).all()

@@ -425,3 +425,14 @@ def test_default_kernel_width_policy():
     assert mk(100, 16).default_min_hidden() == 0 and mk(64, 16, cl=3).default_min_hidden() == 0
     assert mk(64, 64).default_min_hidden() == 0          # already wide: nothing to pad
     assert mk(64, 16, CRQNSF).default_min_hidden() == 0
+
+
+def test_metropolis_log_ratio_ordering():
+    """Mirror of the reference's test/test_metropolization.py."""
+    from nfmc_amd.util import metropolis_acceptance_log_ratio
+    target = lambda x: 0.5 * torch.sum(x ** 2, dim=1)
+    proposal = lambda x: 0.5 * torch.sum((x / 3.0) ** 2, dim=1) + x.shape[1] * float(np.log(3.0))
+    x0, x1 = torch.tensor([[-100.0, -100.0]]), torch.tensor([[0.0, 0.0]])
+    forward = metropolis_acceptance_log_ratio(-target(x0), -target(x1), -proposal(x0), -proposal(x1))
+    inverse = metropolis_acceptance_log_ratio(-proposal(x0), -proposal(x1), -target(x0), -target(x1))
+    assert forward > inverse
