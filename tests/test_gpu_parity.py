@@ -1152,3 +1152,38 @@ def test_warmup_time_limit(dev, strategy):
                  warmup_time_limit_seconds=1.0, warmup=True, show_progress=False, param_kwargs={'store_samples': False})
     assert time.time() - t0 < 25.0
     assert out.statistics.n_attempted_trajectories > 0 and torch.isfinite(out.mean).all()
+
+
+def test_moment_estimation_full(dev):
+    """Mirror of the reference's test/test_moment_estimation.py::test_full over every supported strategy (the
+    `negative_log_likelihood=` keyword of the likelihood-based samplers is accepted and unused here)."""
+    from nfmc_amd import sample
+    from nfmc_amd.util import get_supported_samplers
+    for strategy in get_supported_samplers():
+        torch.manual_seed(0)
+        out = sample(target=lambda x: torch.sum(x ** 2, dim=1), negative_log_likelihood=lambda x: torch.sum(x ** 2, dim=1),
+                     event_shape=(10,), strategy=strategy, n_iterations=3, n_warmup_iterations=3, show_progress=False)
+        for v in (out.mean, out.second_moment, out.variance):
+            assert v.shape == (10,) and torch.isfinite(v).all(), strategy
+
+
+def test_moment_estimation_basic_direct_construction(dev):
+    """Mirror of test_moment_estimation.py::test_basic: `Sampler(event_shape, target)` with every default."""
+    from nfmc_amd.potentials import DiagonalGaussian
+    from nfmc_amd.samplers.imh import AdaptiveIMH
+    from nfmc_amd.samplers.jump import JumpHMC
+    from nfmc_amd.samplers.mcmc import HMC
+    from nfmc_amd.samplers.neutra import NeuTraHMC
+    torch.manual_seed(0)
+    target = DiagonalGaussian((12,), mu=torch.zeros(12), sigma=torch.linspace(0.5, 2.0, 12))
+    for cls in (HMC, NeuTraHMC, JumpHMC, AdaptiveIMH):
+        torch.manual_seed(0)
+        s = cls(target.event_shape, target)
+        s.params.n_iterations = 3
+        if isinstance(s, JumpHMC):
+            s.inner_sampler.params.n_iterations = 3
+        out = s.sample(torch.randn(100, *target.event_shape), show_progress=False)
+        st = out.statistics
+        assert st.running_first_moment.shape == tuple(target.event_shape), cls
+        assert st.running_second_moment.shape == tuple(target.event_shape)
+        assert torch.isfinite(st.running_first_moment).all() and torch.isfinite(st.running_second_moment).all()
