@@ -1187,3 +1187,43 @@ def test_moment_estimation_basic_direct_construction(dev):
         assert st.running_first_moment.shape == tuple(target.event_shape), cls
         assert st.running_second_moment.shape == tuple(target.event_shape)
         assert torch.isfinite(st.running_first_moment).all() and torch.isfinite(st.running_second_moment).all()
+
+
+def _std_gauss(x):
+    return 0.5 * torch.sum(x ** 2, dim=-1)
+
+
+def test_warmup_outputs_like_reference(dev):
+    """Mirror of the reference's test/test_warmup.py: default-constructed samplers, shape of what `.warmup()` returns."""
+    from nfmc_amd.samplers.imh import AdaptiveIMH, FixedIMH
+    from nfmc_amd.samplers.jump import JumpHMC, JumpMALA, JumpMH, JumpUHMC, JumpULA
+    from nfmc_amd.samplers.mcmc import HMC, MALA, MH, UHMC, ULA, RandomWalk
+    from nfmc_amd.samplers.neutra import NeuTraHMC
+    n_dim, n_chains = 5, 3
+    for cls in (MALA, MH, UHMC, HMC, ULA, RandomWalk):                       # test_warmup_mcmc
+        torch.manual_seed(0)
+        s = cls(event_shape=(n_dim,), target=_std_gauss)
+        s.params.n_warmup_iterations = 7
+        out = s.warmup(torch.randn(n_chains, n_dim), show_progress=False)
+        assert out.samples.shape == (7, n_chains, n_dim) and torch.isfinite(out.samples).all(), cls
+    for cls in (JumpMH, JumpULA, JumpHMC, JumpUHMC, JumpMALA):               # test_warmup_jump_nfmc
+        torch.manual_seed(0)
+        s = cls(event_shape=(n_dim,), target=_std_gauss)
+        s.params.flow_fit_kwargs = {**(s.params.flow_fit_kwargs or {}), 'n_epochs': 10}
+        s.inner_sampler.params.n_warmup_iterations = 5
+        out = s.warmup(torch.randn(n_chains, n_dim), show_progress=False)
+        assert out.samples.dim() == 3 and out.samples.shape[1:] == (n_chains, n_dim), cls
+        assert torch.isfinite(out.samples).all()
+    for cls in (AdaptiveIMH, FixedIMH):                                      # test_warmup_imh
+        torch.manual_seed(0)
+        s = cls(event_shape=(n_dim,), target=_std_gauss)
+        s.params.warmup_fit_kwargs.update(n_epochs=20, n_samples=64)
+        out = s.warmup(torch.randn(n_chains, n_dim), show_progress=False)
+        assert out.samples.shape == (1, n_chains, n_dim) and torch.isfinite(out.samples).all(), cls
+    torch.manual_seed(0)                                                      # test_warmup_neutra
+    s = NeuTraHMC(event_shape=(n_dim,), target=_std_gauss)
+    s.params.warmup_fit_kwargs.update(n_epochs=20, n_samples=64)
+    s.params.n_warmup_iterations = 6
+    out = s.warmup(torch.randn(n_chains, n_dim), show_progress=False)
+    assert out.samples.shape == (s.inner_sampler.params.n_warmup_iterations, n_chains, n_dim)
+    assert torch.isfinite(out.samples).all()
