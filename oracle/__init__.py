@@ -7,14 +7,14 @@ it, and only as the checker.  Nothing under `nfmc_amd/` imports it.
 
 Pinning status
 --------------
-* nfmc-owned half (MALA/ULA, HMC/UHMC, MCMC inner loop, jump loop, FixedIMH,
-  NeuTra adjusted target, streaming moments, train/val split): **pinned** by
+* nfmc-owned half (MALA/ULA, random-walk MH, HMC/UHMC, MCMC inner loop, jump loop, FixedIMH,
+  AdaptiveIMH, NeuTra adjusted target, streaming moments, train/val split, dual averaging): **pinned** by
   `tests/golden/*.npz`, generated with `tests/golden/make_golden.py` by running
   the reference's own modules (imported from /root/reference in the build
   container) and recording inputs/outputs.
-* flow half (RealNVP internals): the reference delegates to the third-party
+* flow half (RealNVP / NICE / spline-coupling internals, `Flow.fit`): the reference delegates to the third-party
   package `torchflows` (unpinned in pyproject.toml:23 / setup.py:55, source not
   present).  The spec in `oracle/flow.py` is this build's own; it is checked by
-  mathematical known-answer tests only => **parity unpinned** for RealNVP
+  mathematical known-answer tests only => **parity unpinned** for the flow
   internals.
 """
