@@ -223,6 +223,17 @@ typedef struct {
 
 int nfmc_flow_mh_steps_f32(const NfmcFlowMhArgs* args, nfmc_stream_t stream);
 
+/* The same run of n_steps independent-MH transitions (FixedIMH.sample, imh.py:200-255) as a data-parallel problem:
+ * the proposals of an independence sampler do not depend on the state, so all n * n_steps of them are evaluated at
+ * once, a per-chain scan applies the Metropolis tests, and the accepted proposals are replayed, weighted by their
+ * dwell times, for the moments / sample store / final state.  Same noise streams and results as
+ * nfmc_flow_mh_steps_f32 (states and masks bit for bit; moments up to summation order); worth it when
+ * n alone does not fill the GPU.  Requires adjusted = 1, n_hidden <= 8, n_steps <= NFMC_IMH_PARALLEL_MAX_STEPS;
+ * `work` >= nfmc_imh_parallel_work_bytes(n, d, n_steps) bytes of device scratch. */
+#define NFMC_IMH_PARALLEL_MAX_STEPS 65536
+int64_t nfmc_imh_parallel_work_bytes(int64_t n, int32_t d, int32_t n_steps);
+int nfmc_imh_parallel_f32(const NfmcFlowMhArgs* args, void* work, int64_t work_bytes, nfmc_stream_t stream);
+
 /* ---- K5 + K2: HMC in latent space on U~(z) = U(f^-1(z)) - logdet_inv(z), gradient by a hand-written
  * VJP through the coupling stack.  Replaces `NeuTra.adjusted_target` under `HMC.propose`
  * (neutra.py:58-68,109-129; hmc.py:40-48,96-126). */

@@ -1,0 +1,319 @@
+// FixedIMH as a data-parallel problem (imh.py:200-255).  An independence sampler's proposals do not depend on the
+// chain's state, so a run of k transitions of n chains is
+//   A  k*n independent proposal evaluations  x' = f^-1(z),  f' = log q(x'),  u' = U(x')      (imh_eval_kernel)
+//   B  one cheap sequential scan per chain over (u', f') with the accept uniforms               (imh_scan_kernel)
+//   C  one replay of the ACCEPTED proposals, weighted by how long each stayed the state, for the moments, the
+//      sample store and the final state                                                            (imh_replay_kernel)
+// instead of k dependent transitions per chain.  Few chains (the reference's default is 100) no longer leave the GPU
+// idle: A and C fill it with k*n work items.  Noise streams, arithmetic and results are those of
+// nfmc_flow_mh_steps_f32 (same Philox counters per (chain, step); states and accept masks bit for bit, moments up to
+// the order of summation).  Register-layout flow kernels (flow_b.hpp): conditioners of width <= 8.
+#include "flow_b.hpp"
+
+namespace nfmc {
+
+struct ImhWork {
+    float* u;        // (k, n) U(x')
+    float* f;        // (k, n) log q(x')
+    float* logu;     // (k, n) log of the accept uniform of (step, chain)
+    int32_t* dwell;  // (k, n) number of steps proposal (s, i) was the state of chain i (0: rejected)
+    int32_t* dwell0; // (n)    the same for the initial state
+    int32_t* last;   // (n)    step whose proposal is the final state, -1: the initial state
+    float* x0;       // (n, d) copy of the initial states
+};
+
+// proposal (s, i): latent from the chain's stream, inverse pass, log q and potential.  All lanes of the row group.
+template <int CPL, int LPC, int HP, class FlowT, class PotT>
+__device__ __forceinline__ void imh_propose(float (&xp)[CPL], float& f_xp, float& u_xp, const NfmcFlowMhArgs& a,
+                                            const FlowT& fl, const PotT& pot, int64_t i, int s, int g, bool revl,
+                                            float base_c) {
+    const int d = a.flow.d;
+    const uint32_t gchain = (uint32_t)(a.rng.chain_offset + (uint64_t)i);
+    draw_latent<CPL, LPC>(xp, a.rng.replay_normals ? a.rng.replay_normals + (int64_t)s * a.n * d : nullptr, a.rng.seed,
+                          a.rng.step0 + (uint32_t)s, gchain, i, a.n, d, g, revl);          // flow.sample: imh.py:221
+    float part = 0.f;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) part = fmaf(-0.5f * xp[k], xp[k], part);
+    part -= fl.inverse(xp);
+    f_xp = group_allreduce<LPC>(part) + base_c;
+    float up = 0.f;
+    const auto ctx = pot.prepare(xp, g, d);
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) up += pot.term(ctx, k, xp[k]);
+    u_xp = group_allreduce<LPC>(up);                                                          // imh.py:225
+}
+
+template <int CPL, int LPC, int HP, template <int, int, bool> class Pot, bool FAST>
+__global__ void __launch_bounds__(kBlock) imh_eval_kernel(NfmcFlowMhArgs a, ImhWork w, int64_t tiles) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int CPW = kWave / LPC;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane % LPC, cw = lane / LPC;
+    const int d = a.flow.d;
+    const int64_t n = a.n, total = n * (int64_t)a.n_steps;
+    FlowImage<CPL, LPC, HP>::stage(lds, a.flow, kBlock);
+    __syncthreads();
+    FlowB<CPL, LPC, HP, false, (FAST && CPL >= 8)> fl;
+    fl.init(lds, a.flow, g);
+    Pot<CPL, LPC, FAST> pot;
+    pot.init(a.pot, g, d);
+    const bool revl = (a.flow.n_coupling & 1) != 0;
+    const float base_c = -0.5f * (float)d * kLog2Pi;
+    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int64_t r = (tile * kWavesPerBlock + wave) * CPW + cw;
+        const bool active = r < total;
+        const int64_t rr = active ? r : total - 1;
+        const int s = (int)(rr / n);
+        const int64_t i = rr - (int64_t)s * n;
+        float xp[CPL], f_xp, u_xp;
+        imh_propose<CPL, LPC, HP>(xp, f_xp, u_xp, a, fl, pot, i, s, g, revl, base_c);
+        if (active && g == 0) {
+            float uu;   // the accept uniform of (chain i, step s): imh.py:229
+            if (a.rng.replay_uniforms) {
+                uu = a.rng.replay_uniforms[r];
+            } else {
+                const uint4 rnd = philox4x32_10((uint32_t)(a.rng.chain_offset + (uint64_t)i), a.rng.step0 + (uint32_t)s, 0u,
+                                                kTagJump, (uint32_t)a.rng.seed, (uint32_t)(a.rng.seed >> 32));
+                uu = u32_to_uniform(rnd.x);
+            }
+            w.u[r] = u_xp;
+            w.f[r] = f_xp;
+            w.logu[r] = fast_ln(uu);
+            w.dwell[r] = 0;
+        }
+    }
+}
+
+// One WAVE per chain: the Metropolis scan over the k proposals (imh.py:223-233).  Everything expensive (proposal,
+// uniform, logarithm) was done in parallel by imh_eval_kernel.  The scan is sequential only through acceptances: the
+// 64 lanes test the next 64 steps against the current state at once, the first accepting lane (ballot + ffs) becomes
+// the state and the scan resumes right after it -- k / 64 rounds when nothing is accepted, one round per acceptance
+// otherwise, each a few hundred cycles.
+__global__ void __launch_bounds__(256) imh_scan_kernel(NfmcFlowMhArgs a, ImhWork w) {
+    const int64_t n = a.n;
+    const int d = a.flow.d;
+    const int k = a.n_steps;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    unsigned long long acc_total = 0, bad_total = 0;   // wave-uniform
+    for (int64_t i = wave0; i < n; i += nwaves) {
+        float u_x = potential_row(w.x0 + i * d, a.pot, d);   // imh.py:224 (every lane: uniform addresses)
+        float f_x = a.logq[i];                                // imh.py:214 (filled by the caller when not cached)
+        int cur = -1, pos = 0;
+        while (pos < k) {
+            const int s = pos + lane;
+            const bool valid = s < k;
+            const int64_t r = (int64_t)(valid ? s : k - 1) * n + i;
+            const float pu = w.u[r], pf = w.f[r], pl = w.logu[r];
+            const float lr = (-pu) - (-u_x) + f_x - pf;      // util.py:392
+            const bool acc = valid && pl < lr;                // imh.py:229-230; NaN -> reject
+            const bool bad = valid && !(fabsf(lr) <= 3.0e38f);
+            const unsigned long long am = __ballot(acc), bm = __ballot(bad);
+            const int j = am ? __ffsll((long long)am) - 1 : 63;          // lanes 0..j are decided by this round
+            const unsigned long long decided = j == 63 ? ~0ull : ((2ull << j) - 1ull);
+            bad_total += (unsigned long long)__popcll(bm & decided);
+            if (valid && lane <= j) {
+                if (a.masks_out) a.masks_out[r] = (acc && lane == j) ? 1 : 0;
+                if (a.log_ratio_out) a.log_ratio_out[r] = lr;
+            }
+            if (am) {
+                const int s_acc = pos + j;
+                if (lane == 0) {
+                    if (cur < 0) w.dwell0[i] = s_acc;                    // steps before the first acceptance
+                    else w.dwell[(int64_t)cur * n + i] = s_acc - cur;    // steps this proposal stayed the state
+                }
+                u_x = __shfl(pu, j, kWave);
+                f_x = __shfl(pf, j, kWave);
+                cur = s_acc;
+                acc_total++;
+                pos = s_acc + 1;
+            } else {
+                pos += 64;
+            }
+        }
+        if (lane == 0) {
+            if (cur < 0) w.dwell0[i] = k;
+            else w.dwell[(int64_t)cur * n + i] = k - cur;
+            w.last[i] = cur;
+            a.logq[i] = f_x;                                              // imh.py:233
+        }
+    }
+    // integer counters: atomic adds are exact, the totals do not depend on the order
+    if (lane == 0 && a.stats.counters) {
+        if (acc_total) atomicAdd(a.stats.counters + NFMC_CNT_ACCEPTED, acc_total);
+        if (bad_total) atomicAdd(a.stats.counters + NFMC_CNT_NONFINITE, bad_total);
+    }
+}
+
+// Replay of the proposals that were accepted (and of the initial states), weighted by their dwell times.
+template <int CPL, int LPC, int HP, template <int, int, bool> class Pot, bool FAST>
+__global__ void __launch_bounds__(kBlock) imh_replay_kernel(NfmcFlowMhArgs a, ImhWork w, int64_t tiles) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int CPW = kWave / LPC;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane % LPC, cw = lane / LPC;
+    const int d = a.flow.d;
+    const int64_t n = a.n, total = n * (int64_t)a.n_steps + n;   // proposals, then the n initial states
+    FlowImage<CPL, LPC, HP>::stage(lds, a.flow, kBlock);
+    __syncthreads();
+    FlowB<CPL, LPC, HP, false, (FAST && CPL >= 8)> fl;
+    fl.init(lds, a.flow, g);
+    Pot<CPL, LPC, FAST> pot;
+    pot.init(a.pot, g, d);
+    const bool revl = (a.flow.n_coupling & 1) != 0;
+    const float base_c = -0.5f * (float)d * kLog2Pi;
+    float sx[CPL], sxx[CPL];
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) sx[q] = sxx[q] = 0.f;
+    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int64_t r = (tile * kWavesPerBlock + wave) * CPW + cw;
+        const bool active = r < total;
+        const bool initial = active && r >= total - n;
+        int c = 0, s = -1;
+        int64_t i = 0;
+        if (active) {
+            if (initial) {
+                i = r - (total - n);
+                c = w.dwell0[i];
+            } else {
+                s = (int)(r / n);
+                i = r - (int64_t)s * n;
+                c = w.dwell[r];
+            }
+        }
+        if (__ballot(c > 0) == 0ull) continue;   // nothing accepted in this wave's rows: skip the flow pass
+        float xs[CPL];
+        if (__ballot(!initial && c > 0) != 0ull) {
+            float f_xp, u_xp;
+            imh_propose<CPL, LPC, HP>(xs, f_xp, u_xp, a, fl, pot, i, s < 0 ? 0 : s, g, revl, base_c);
+        }
+        if (initial) load_row<CPL, LPC, FAST>(w.x0, i, d, g, true, xs);
+        if (c > 0) {
+            const float cf = (float)c;
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) {
+                sx[q] = fmaf(cf, xs[q], sx[q]);
+                sxx[q] = fmaf(cf * xs[q], xs[q], sxx[q]);
+            }
+            if (!initial) {
+                if (a.samples)
+                    for (int t = s; t < s + c; ++t) store_row<CPL, LPC, FAST>(a.samples + (int64_t)t * n * d, i, d, g, true, xs);
+                if (w.last[i] == s) store_row<CPL, LPC, FAST>(a.x, i, d, g, true, xs);
+            } else if (a.samples) {
+                for (int t = 0; t < c; ++t) store_row<CPL, LPC, FAST>(a.samples + (int64_t)t * n * d, i, d, g, true, xs);
+            }
+        }
+    }
+    if (a.stats.sum_x) block_stats_flush<CPL, LPC>(sx, sxx, 0u, 0u, a.stats);
+}
+
+struct PCfg {
+    int cpl, lpc;
+};
+static const PCfg kPCfgs[] = {{4, 1}, {4, 2}, {4, 4}, {4, 8}, {8, 8}, {8, 16}, {8, 32}, {8, 64}};
+#define NFMC_FOR_PCFG(M) M(4, 1) M(4, 2) M(4, 4) M(4, 8) M(8, 8) M(8, 16) M(8, 32) M(8, 64)
+
+template <int CPL, int LPC, int HP>
+static int launch_imh(const NfmcFlowMhArgs& a, const ImhWork& w, hipStream_t st, int* grid_c, int* dp_out) {
+    const size_t lds = (size_t)FlowImage<CPL, LPC, HP>::total_floats(a.flow.n_hidden_layers, a.flow.n_coupling) * sizeof(float);
+    if (lds > 120 * 1024) return NFMC_EUNSUPPORTED;
+    constexpr int cpw = kWave / LPC, rows_per_block = kWavesPerBlock * cpw;
+    const int64_t total_a = a.n * (int64_t)a.n_steps, total_c = total_a + a.n;
+    const int64_t tiles_a = (total_a + rows_per_block - 1) / rows_per_block;
+    const int64_t tiles_c = (total_c + rows_per_block - 1) / rows_per_block;
+    const int grid_a = (int)(tiles_a < kMaxGrid ? tiles_a : kMaxGrid);
+    const int gc = (int)(tiles_c < kMaxGrid ? tiles_c : kMaxGrid);
+    const int dp = CPL * LPC;
+    if (a.stats.sum_x && a.stats.scratch_bytes < (int64_t)gc * (2 * dp + kStatTail) * (int64_t)sizeof(double)) return NFMC_ESCRATCH;
+    if (check_defer(a.stats, dp, a.flow.d)) return NFMC_EINVAL;
+#define NFMC_LI(POT, F)                                                                                           \
+    {                                                                                                             \
+        auto ka = imh_eval_kernel<CPL, LPC, HP, POT, F>;                                                          \
+        auto kc = imh_replay_kernel<CPL, LPC, HP, POT, F>;                                                        \
+        if (lds > 48 * 1024) {                                                                                    \
+            hipError_t e = hipFuncSetAttribute((const void*)ka, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e != hipSuccess) return (int)e;                                                                   \
+            e = hipFuncSetAttribute((const void*)kc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
+            if (e != hipSuccess) return (int)e;                                                                   \
+        }                                                                                                         \
+        hipLaunchKernelGGL(ka, dim3(grid_a), dim3(kBlock), lds, st, a, w, tiles_a);                               \
+        const int gs = (int)((a.n + 3) / 4 < 4096 ? (a.n + 3) / 4 : 4096);   /* one wave per chain */              \
+        hipLaunchKernelGGL(imh_scan_kernel, dim3(gs), dim3(256), 0, st, a, w);                                    \
+        hipLaunchKernelGGL(kc, dim3(gc), dim3(kBlock), lds, st, a, w, tiles_c);                                   \
+    }
+    const int d = a.flow.d;
+    const bool fast = d == dp && (d % 4) == 0 && a.pot.a == nullptr && a.pot.b == nullptr && (((uintptr_t)a.x) & 15u) == 0 &&
+                      (((uintptr_t)w.x0) & 15u) == 0 && (!a.samples || (((uintptr_t)a.samples) & 15u) == 0);
+    if (a.pot.kind == NFMC_POT_FUNNEL) NFMC_LI(FunnelPot, false)
+    else if (fast) NFMC_LI(QuadraticPot, true)
+    else NFMC_LI(QuadraticPot, false)
+#undef NFMC_LI
+    *grid_c = gc;
+    *dp_out = dp;
+    return 0;
+}
+
+}  // namespace nfmc
+
+using namespace nfmc;
+
+static int64_t imh_work_floats(int64_t n, int32_t d, int32_t k) { return 4 * n * (int64_t)k + 2 * n + n * (int64_t)d + 8; }
+
+extern "C" int64_t nfmc_imh_parallel_work_bytes(int64_t n, int32_t d, int32_t n_steps) {
+    if (n <= 0 || d <= 0 || n_steps <= 0) return 0;
+    return imh_work_floats(n, d, n_steps) * 4 + 64;
+}
+
+extern "C" int nfmc_imh_parallel_f32(const NfmcFlowMhArgs* args, void* work, int64_t work_bytes, nfmc_stream_t stream) {
+    if (!args || !work) return NFMC_EINVAL;
+    NfmcFlowMhArgs a = *args;
+    const NfmcRealNVP& f = a.flow;
+    if (!a.x || !a.logq || a.n <= 0 || a.n_steps <= 0 || !a.adjusted) return NFMC_EINVAL;
+    if (!f.ea0_log_scale || !f.ea0_shift || !f.ea1_log_scale || !f.ea1_shift || (f.n_coupling > 0 && !f.weights)) return NFMC_EINVAL;
+    if (f.d < 2 || f.d > 512 || a.n_steps > NFMC_IMH_PARALLEL_MAX_STEPS) return NFMC_ESHAPE;
+    if (f.n_hidden <= 0 || f.n_hidden > 8 || f.n_hidden_layers <= 0 || f.n_bins != 0) return NFMC_EUNSUPPORTED;
+    if (a.pot.kind != NFMC_POT_QUADRATIC && a.pot.kind != NFMC_POT_FUNNEL) return NFMC_EUNSUPPORTED;
+    if (a.stats.sum_x && (!a.stats.sum_x2 || !a.stats.counters || !a.stats.scratch)) return NFMC_EINVAL;
+    if (a.stats.sum_x && a.stats.defer && a.stats.tail_slot != 0) return NFMC_EINVAL;
+    if ((a.rng.replay_normals != nullptr) != (a.rng.replay_uniforms != nullptr)) return NFMC_EINVAL;
+    if (work_bytes < nfmc_imh_parallel_work_bytes(a.n, f.d, a.n_steps)) return NFMC_ESCRATCH;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t kn = a.n * (int64_t)a.n_steps;
+    ImhWork w;
+    w.u = (float*)work;
+    w.f = w.u + kn;
+    w.logu = w.f + kn;
+    w.dwell = (int32_t*)(w.logu + kn);
+    w.dwell0 = w.dwell + kn;
+    w.last = w.dwell0 + a.n;
+    w.x0 = (float*)(w.last + a.n);
+    w.x0 += (4 - ((4 * kn + 2 * a.n) & 3)) & 3;   // keep the copy of the states 16-byte aligned (vector IO)
+    if (!a.logq_cached) {   // flow.log_prob(x0): imh.py:214
+        const int rc = nfmc_realnvp_forward_f32(&f, a.x, a.n, nullptr, nullptr, a.logq, stream);
+        if (rc) return rc;
+    }
+    hipError_t e = hipMemcpyAsync(w.x0, a.x, (size_t)a.n * f.d * sizeof(float), hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) return (int)e;
+    const int d = f.d, hp = f.n_hidden <= 4 ? 4 : 8;
+    PCfg c = {0, 0};
+    for (const PCfg& k : kPCfgs) {   // smallest capacity; CPL = 4 first (more lanes per row for small batches)
+        if (k.cpl * k.lpc < d) continue;
+        if (c.cpl == 0 || k.cpl * k.lpc < c.cpl * c.lpc) c = k;
+    }
+    if (!c.cpl) return NFMC_EUNSUPPORTED;
+    int rc = NFMC_EUNSUPPORTED, grid = 0, dp = 0;
+#define M(CPL, LPC)                   \
+    if (c.cpl == CPL && c.lpc == LPC) \
+        rc = hp == 4 ? launch_imh<CPL, LPC, 4>(a, w, st, &grid, &dp) : launch_imh<CPL, LPC, 8>(a, w, st, &grid, &dp);
+    NFMC_FOR_PCFG(M)
+#undef M
+    if (rc) return rc;
+    NFMC_HIP_CHECK_LAUNCH();
+    if (a.stats.sum_x && !a.stats.defer) {
+        hipLaunchKernelGGL(stats_finish_kernel<true>, dim3(stats_finish_grid(dp)), dim3(kFinishBlock), 0, st, a.stats.scratch, grid, dp, d,
+                           a.stats, (unsigned long long)a.n * (unsigned long long)a.n_steps);
+        NFMC_HIP_CHECK_LAUNCH();
+    }
+    return NFMC_OK;
+}

@@ -18,6 +18,7 @@ POT_QUADRATIC, POT_FUNNEL = 0, 1
 TAG_NOISE, TAG_ACCEPT, TAG_LATENT, TAG_JUMP = 0, 1, 2, 3
 CNT_ACCEPTED, CNT_ATTEMPTED, CNT_NONFINITE, CNT_WORDS = 0, 1, 2, 4
 MAX_STEPS_PER_CALL = 512
+IMH_PARALLEL_MAX_STEPS = 65536
 
 c_fp = C.c_void_p  # all device pointers travel as void*
 
@@ -102,6 +103,8 @@ SYMBOLS = [
     ('nfmc_realnvp_inverse_f32', C.c_int, [C.POINTER(NfmcRealNVP), c_fp, C.c_int64, c_fp, c_fp, c_fp,
                                            C.POINTER(NfmcRng), c_fp]),
     ('nfmc_flow_mh_steps_f32', C.c_int, [C.POINTER(NfmcFlowMhArgs), c_fp]),
+    ('nfmc_imh_parallel_work_bytes', C.c_int64, [C.c_int64, C.c_int32, C.c_int32]),
+    ('nfmc_imh_parallel_f32', C.c_int, [C.POINTER(NfmcFlowMhArgs), c_fp, C.c_int64, c_fp]),
     ('nfmc_neutra_scratch_bytes', C.c_int64, [C.c_int64, C.c_int32, C.c_int32]),
     ('nfmc_neutra_hmc_steps_f32', C.c_int, [C.POINTER(NfmcNeutraHmcArgs), c_fp]),
     ('nfmc_neutra_potential_grad_f32', C.c_int, [C.POINTER(NfmcRealNVP), C.POINTER(NfmcPotential), c_fp, C.c_int64,

@@ -13,7 +13,7 @@ from tqdm import tqdm
 from .. import hip
 from ..containers import MCMCOutput, NFMCKernel, NFMCParameters, Sampler
 from .common import Run, chunks, resolve_target
-from .jump import flow_is_native, launch_flow_mh, split_flow_mh
+from .jump import flow_is_native, imh_parallel_ok, launch_flow_mh, launch_imh_parallel, split_flow_mh
 
 
 @dataclass
@@ -83,7 +83,9 @@ class FixedIMH(AbstractIMH):
         logq = torch.empty(n, dtype=torch.float32, device=run.dev)
         t0 = time.time()
         done = 0
-        limit = hip.MAX_STEPS_PER_CALL if (time_limit_seconds is None and not show_progress) else 16
+        unlimited = time_limit_seconds is None and not show_progress
+        limit = hip.MAX_STEPS_PER_CALL if unlimited else 16
+        parallel = fused and imh_parallel_ok(run, flow)
         bar = tqdm(total=T, desc=self.name, disable=not show_progress)
         if not fused:
             logq.copy_(flow.log_prob(run.x.reshape(n, *event_shape)).detach().to(run.dev, torch.float32))  # imh.py:214
@@ -93,8 +95,13 @@ class FixedIMH(AbstractIMH):
                 if time.time() - t0 >= time_limit_seconds:
                     break
             k = min(limit, T - done) if fused else 1
+            if fused and parallel:   # all proposals of the chunk at once: as many steps as ~8M work items allow
+                k = min(T - done, max(limit, min(hip.IMH_PARALLEL_MAX_STEPS, (1 << 23) // max(n, 1)))) if unlimited else k
             view = buf[done:done + k] if buf is not None else None
-            if fused:
+            if fused and parallel:
+                launch_imh_parallel(run, flow, pot, logq, k, done, done > 0,
+                                    run.stats.struct(defer=True, attempted=n * k), view)
+            elif fused:
                 launch_flow_mh(run, flow, pot, logq, k, done, done > 0, True,
                                run.stats.struct(defer=True, attempted=n * k), view)
             else:

@@ -4,6 +4,7 @@ the fused inner kernel (K transitions, state in registers) and `nfmc_flow_mh_ste
 (flow.sample + flow.log_prob + 2 target calls + MH test + masked update + moments in one kernel).
 """
 import ctypes as C
+import os
 import time
 from copy import deepcopy
 from dataclasses import dataclass
@@ -117,6 +118,41 @@ def launch_flow_mh(run: Run, flow, pot, logq, k, step0, cached, adjusted, stats_
     a.log_ratio_out = hip.ptr(log_ratio_out) if log_ratio_out is not None else None
     with run.timed('flow_mh_steps'):
         hip.check(hip.lib().nfmc_flow_mh_steps_f32(C.byref(a), hip.stream()), 'nfmc_flow_mh_steps_f32')
+
+
+def imh_parallel_ok(run: Run, flow) -> bool:
+    """FixedIMH as a data-parallel problem (csrc/imh_parallel.hip) pays when the chains alone do not fill the GPU
+    (sequential transitions are latency-bound there); register-layout flows only.  NFMC_IMH_PARALLEL=0/1 overrides."""
+    bij = getattr(flow, 'bijection', None)
+    if not flow_is_native(flow) or bij.n_hidden > 8 or bij.n_bins != 0 or bij.d > 512:
+        return False
+    env = os.environ.get('NFMC_IMH_PARALLEL')
+    if env is not None:
+        return env == '1'
+    return run.n <= 8192   # d = 64, 1000 steps: 2.6 vs 3.0 ms at n = 8192, 4.2 vs 3.9 ms at n = 16384
+
+
+def launch_imh_parallel(run: Run, flow, pot, logq, k, step0, cached, stats_struct, samples=None, masks_out=None,
+                        log_ratio_out=None):
+    """k IMH transitions of every chain through nfmc_imh_parallel_f32 (same contract as launch_flow_mh)."""
+    a = hip.NfmcFlowMhArgs()
+    st, _keep = flow.bijection.packed(run.dev)
+    a.x, a.logq, a.n, a.n_steps = hip.ptr(run.x), hip.ptr(logq), run.n, k
+    a.logq_cached = 1 if cached else 0
+    a.adjusted = 1
+    a.flow = st
+    a.pot = pot.descriptor(run.dev)
+    a.rng = run.rng(step0, k, adjusted=True)
+    a.stats = stats_struct
+    a.samples = hip.ptr(samples) if samples is not None else None
+    a.masks_out = hip.ptr(masks_out, torch.uint8) if masks_out is not None else None
+    a.log_ratio_out = hip.ptr(log_ratio_out) if log_ratio_out is not None else None
+    nbytes = int(hip.lib().nfmc_imh_parallel_work_bytes(run.n, run.d, k))
+    work = torch.empty(nbytes, dtype=torch.uint8, device=run.dev)
+    with run.timed('imh_parallel'):
+        hip.check(hip.lib().nfmc_imh_parallel_f32(C.byref(a), hip.ptr(work, torch.uint8), nbytes, hip.stream()),
+                  'nfmc_imh_parallel_f32')
+    return work   # kept alive by the caller until the stream has consumed it (torch's allocator is stream-ordered)
 
 
 def split_flow_mh(run: Run, flow, target, event_shape, step, adjusted, stats_struct, logq=None):

@@ -1227,3 +1227,34 @@ def test_warmup_outputs_like_reference(dev):
     out = s.warmup(torch.randn(n_chains, n_dim), show_progress=False)
     assert out.samples.shape == (s.inner_sampler.params.n_warmup_iterations, n_chains, n_dim)
     assert torch.isfinite(out.samples).all()
+
+
+@pytest.mark.parametrize('d,n,T,store', [(64, 300, 40, True), (25, 1000, 700, False), (7, 5, 33, True)])
+def test_imh_data_parallel_equals_sequential_transitions(dev, d, n, T, store, monkeypatch):
+    """FixedIMH as a data-parallel problem (imh_parallel.hip: all proposals at once, per-chain scan, weighted replay)
+    against the sequential flow-MH kernel: same Philox streams -> states, samples and counters bit for bit; the
+    moments are sums in another order (tolerance 1e-5)."""
+    from nfmc_amd.samplers import imh
+    from nfmc_amd.flows import Flow, RealNVP
+    from nfmc_amd.potentials import SumOfSquares
+    from oracle import flow as oflow
+    torch.manual_seed(d)
+    of = oflow.perturb_(oflow.Flow(oflow.RealNVP((d,))), 6, 0.2, 0.75)   # close to the target: accepts happen
+    outs = []
+    for par in ('1', '0'):
+        monkeypatch.setenv('NFMC_IMH_PARALLEL', par)
+        f = Flow(RealNVP((d,)))
+        f.load_state_dict(of.state_dict())
+        s = imh.FixedIMH((d,), SumOfSquares((d,)), imh.IMHKernel((d,), flow=f),
+                         imh.IMHParameters(n_iterations=T, store_samples=store))
+        s.seed = 77
+        torch.manual_seed(1)
+        outs.append(s.sample(torch.randn(n, d) * 0.7, show_progress=False))
+    a, b = outs
+    assert a.statistics.n_accepted_trajectories == b.statistics.n_accepted_trajectories > 0
+    assert a.statistics.n_attempted_trajectories == b.statistics.n_attempted_trajectories == n * T
+    assert torch.equal(a.running_samples.last_sample, b.running_samples.last_sample)
+    if store:
+        assert torch.equal(a.samples, b.samples)
+    np.testing.assert_allclose(a.mean.numpy(), b.mean.numpy(), atol=1e-5)
+    np.testing.assert_allclose(a.second_moment.numpy(), b.second_moment.numpy(), atol=1e-5)
