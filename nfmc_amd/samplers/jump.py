@@ -126,6 +126,14 @@ def imh_parallel_ok(run: Run, flow) -> bool:
     bij = getattr(flow, 'bijection', None)
     if not flow_is_native(flow) or bij.n_hidden > 8 or bij.n_bins != 0 or bij.d > 512:
         return False
+    # the register-layout kernels keep every layer's weight image in LDS (flow_b.hpp: FlowImage): deep flows do not fit
+    hp = 4 if bij.n_hidden <= 4 else 8
+    dp = 4
+    while dp < bij.d:
+        dp *= 2
+    image_floats = bij.n_coupling * (dp * hp + hp + (bij.n_hidden_layers - 1) * (hp * hp + hp) + dp * (2 * hp + 4)) + 4 * dp
+    if image_floats * 4 > 120 * 1024:
+        return False
     env = os.environ.get('NFMC_IMH_PARALLEL')
     if env is not None:
         return env == '1'
