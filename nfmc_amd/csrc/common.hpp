@@ -108,6 +108,71 @@ __device__ __forceinline__ float group_allreduce(float v) {
     return v;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Reduce-scatter / all-gather of NU (4 or 8) per-lane values over the LPC >= NU lanes of a chain: the register
+// flow kernels give each conditioner hidden unit to ONE lane class (unit = lane % NU) instead of evaluating the
+// whole hidden stack redundantly on every lane.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+// value of lane ^ 4: row_shl:4 into the even 4-lane banks, row_shr:4 into the odd ones
+__device__ __forceinline__ float dpp_xor4(float v) {
+    int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x104, 0xf, 0x5, false);
+    t = __builtin_amdgcn_update_dpp(t, __float_as_int(v), 0x114, 0xf, 0xa, false);
+    return __int_as_float(t);
+}
+
+// position r of an all-gathered register row holds unit (lane % NU) ^ unit_xor<NU>(r)
+template <int NU>
+__host__ __device__ constexpr int unit_xor(int r) {
+    return NU == 8 ? (((r & 1) << 2) | (r & 2) | ((r >> 2) & 1)) : (((r & 1) << 1) | ((r >> 1) & 1));
+}
+
+// h[k] = this lane's partial of unit k.  Returns the sum over the chain's LPC lanes of unit (lane % NU), with the
+// association of group_allreduce (pairs at lane distance 1, then 2, 4, ...), so both give bitwise the same sums.
+template <int NU, int LPC>
+__device__ __forceinline__ float group_reduce_scatter(const float (&h)[NU]) {
+    static_assert((NU == 4 || NU == 8) && LPC >= NU, "one lane class per unit");
+    constexpr uint64_t M0 = 0xAAAAAAAAAAAAAAAAull, M1 = 0xCCCCCCCCCCCCCCCCull, M2 = 0xF0F0F0F0F0F0F0F0ull;
+    float a[NU / 2];
+#pragma unroll
+    for (int r = 0; r < NU / 2; ++r)
+        a[r] = select_f32(M0, h[2 * r + 1], h[2 * r]) + dpp_mov<0xB1>(select_f32(M0, h[2 * r], h[2 * r + 1]));
+    float c;
+    if constexpr (NU == 8) {
+        float b[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+            b[r] = select_f32(M1, a[2 * r + 1], a[2 * r]) + dpp_mov<0x4E>(select_f32(M1, a[2 * r], a[2 * r + 1]));
+        c = select_f32(M2, b[1], b[0]) + dpp_xor4(select_f32(M2, b[0], b[1]));
+    } else {
+        c = select_f32(M1, a[1], a[0]) + dpp_mov<0x4E>(select_f32(M1, a[0], a[1]));
+        if constexpr (LPC >= 8) c += dpp_xor4(c);
+    }
+    if constexpr (LPC >= 16) c += dpp_mov<0x128>(c);  // row_ror:8 : lane ^ 8
+    if constexpr (LPC >= 32) c += __shfl_xor(c, 16, kWave);
+    if constexpr (LPC >= 64) c += __shfl_xor(c, 32, kWave);
+    return c;
+}
+
+// v = value of unit (lane % NU); h[r] = value of unit (lane % NU) ^ unit_xor<NU>(r)
+template <int NU>
+__device__ __forceinline__ void group_all_gather(float v, float (&h)[NU]) {
+    h[0] = v;
+    if constexpr (NU == 8) {
+        h[1] = dpp_xor4(h[0]);
+        h[2] = dpp_mov<0x4E>(h[0]);
+        h[3] = dpp_mov<0x4E>(h[1]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[4 + r] = dpp_mov<0xB1>(h[r]);
+    } else {
+        h[1] = dpp_mov<0x4E>(h[0]);
+        h[2] = dpp_mov<0xB1>(h[0]);
+        h[3] = dpp_mov<0xB1>(h[1]);
+    }
+}
+
 template <int LPC>
 __device__ __forceinline__ float group_broadcast0(float v) {
     // value held by the group's first lane

@@ -11,9 +11,13 @@
 // compile-time per quad (no lane idles in either phase).
 //
 // Conditioner: each lane accumulates the first-layer pre-activations over its own source coordinates
-// (weights from an LDS image, one ds_read_b128 per coordinate for HP = 4), a DPP butterfly sums them over
-// the group, every lane evaluates the tiny hidden stack redundantly, then computes the affine parameters of
-// its own target coordinates.  Coordinates that are not source (target) in a layer index an all-zero row,
+// (weights from an LDS image, one ds_read_b128 per coordinate for HP = 4).  With LPC >= HP lanes per chain the
+// hidden stack is DISTRIBUTED: a DPP reduce-scatter leaves lane g with the complete sum of hidden unit g % HP,
+// the lane applies bias + tanh to that one unit, and a DPP all-gather hands every lane all HP activations (in a
+// lane-dependent register order that the image's weight rows are pre-permuted for); further hidden layers are
+// one HP-term dot product + one tanh per lane.  (Evaluating the stack redundantly on every lane, as the
+// LPC < HP layouts still do, was half of a coupling layer's instructions at d = 64.)  Then every lane computes
+// the affine parameters of its own target coordinates.  Coordinates that are not source (target) in a layer index an all-zero row,
 // and carry an is-target flag of 0, which yields exactly alpha = 1, beta = 0, log alpha = 0 for them:
 // no index arithmetic and no branches, also for ragged d.
 #pragma once
@@ -28,15 +32,21 @@ namespace nfmc {
 // coordinate held by register i of lane g), so a lane's rows are `g` rows past a compile-time base and
 // consecutive lanes read consecutive rows (bank-conflict free ds_read_b128):
 //   W1 (DP x HP): row s = W1T[logical j] if the slot's coordinate is a SOURCE of this layer, else 0
-//   b1 HP | [WhT HP x HP | bh HP] x (n_hl - 1)
-//   W3 (DP x RS): row s = [alpha weights HP | beta weights HP | b3_alpha | b3_beta | is_target | 0] (zeros if not target)
+//   b1 HP | [WhT HP x HP | bh HP] x (n_hl - 1)                                   (LPC < HP)
+//   b1 HP | [HP rows of HP + 4: row u = weights INTO unit u, position r = from unit u ^ unit_xor(r) | bh[u] | 0 0 0] x (n_hl - 1)
+//   W3 (DP x RS): row s = [alpha weights HP | beta weights HP | b3_alpha | b3_beta | is_target | 0] (zeros if not target);
+//       distributed: weight position r belongs to hidden unit (g % HP) ^ unit_xor(r)
 // followed, after all layers, by the ElementwiseAffine parameters per slot:
 //   ea0_ls | ea0_sh | ea1_ls | ea1_sh   (DP each; ea1 already mapped through the final reversal)
 template <int CPL, int LPC, int HP>
 struct FlowImage {
     static constexpr int RS = 2 * HP + 4;
     static constexpr int DP = CPL * LPC;
-    __host__ __device__ static int layer_floats(int n_hl) { return DP * HP + HP + (n_hl - 1) * (HP * HP + HP) + DP * RS; }
+    static constexpr bool DIST = LPC >= HP;                  // one lane class per hidden unit
+    static constexpr int HROW = HP + 4;                      // distributed hidden-layer row: HP weights | bias | pad
+    static constexpr int HL = DIST ? HP * HROW : HP * HP + HP;  // floats per hidden layer after the first
+    __host__ __device__ static int mid_floats(int n_hl) { return HP + (n_hl - 1) * HL; }
+    __host__ __device__ static int layer_floats(int n_hl) { return DP * HP + mid_floats(n_hl) + DP * RS; }
     __host__ __device__ static int total_floats(int n_hl, int n_coupling) { return n_coupling * layer_floats(n_hl) + 4 * DP; }
 
     // all `nthreads` threads of the workgroup; blob layout: flow_device.hpp (W1T | b1 | [WhT | bh] | W3 | b3).
@@ -45,11 +55,12 @@ struct FlowImage {
     __device__ static void stage(float* __restrict__ img, const NfmcRealNVP& f, int nthreads) {
         const int d = f.d, d_a = d / 2, d_b = d - d_a, n_hl = f.n_hidden_layers;
         const int lf = layer_floats(n_hl);
-        const int nmid = HP + (n_hl - 1) * (HP * HP + HP);
+        const int nmid = mid_floats(n_hl);                        // image
+        const int bmid = HP + (n_hl - 1) * (HP * HP + HP);        // blob
         for (int l = 0; l < f.n_coupling; ++l) {
             const bool rev = (l & 1) == 0;
             const float* W = f.weights + l * f.layer_stride;
-            const float* W3 = W + d_a * HP + nmid;
+            const float* W3 = W + d_a * HP + bmid;
             const float* b3 = W3 + 2 * d_b * HP;
             float* o = img + l * lf;
             float* o3 = o + DP * HP + nmid;
@@ -61,12 +72,14 @@ struct FlowImage {
                 const int tt = tgt ? j - d_a : 0;
                 const float* wa = W3 + tt * HP;
                 const float* wb = W3 + (d_b + tt) * HP;
+                const int ub = (s % LPC) % HP;                       // the slot's lane class
                 float r1[HP], r3[RS];
 #pragma unroll
                 for (int k = 0; k < HP; ++k) {
+                    const int kk = DIST ? (ub ^ unit_xor<HP>(k)) : k;
                     r1[k] = src ? w1[k] : 0.f;
-                    r3[k] = tgt ? wa[k] : 0.f;
-                    r3[HP + k] = tgt ? wb[k] : 0.f;
+                    r3[k] = tgt ? wa[kk] : 0.f;
+                    r3[HP + k] = tgt ? wb[kk] : 0.f;
                 }
                 r3[2 * HP] = tgt ? b3[tt] : 0.f;
                 r3[2 * HP + 1] = tgt ? b3[d_b + tt] : 0.f;
@@ -79,7 +92,19 @@ struct FlowImage {
                 for (int k = 0; k < RS; k += 4)
                     *reinterpret_cast<float4*>(o3 + s * RS + k) = make_float4(r3[k], r3[k + 1], r3[k + 2], r3[k + 3]);
             }
-            for (int t = threadIdx.x; t < nmid; t += nthreads) o[DP * HP + t] = W[d_a * HP + t];
+            if constexpr (DIST) {
+                for (int t = threadIdx.x; t < HP; t += nthreads) o[DP * HP + t] = W[d_a * HP + t];
+                for (int hl = 1; hl < n_hl; ++hl) {
+                    const float* sw = W + d_a * HP + HP + (hl - 1) * (HP * HP + HP);   // WhT[in][out] | bh
+                    float* dw = o + DP * HP + HP + (hl - 1) * HL;
+                    for (int t = threadIdx.x; t < HL; t += nthreads) {
+                        const int u = t / HROW, r = t % HROW;
+                        dw[t] = r < HP ? sw[(u ^ unit_xor<HP>(r)) * HP + u] : (r == HP ? sw[HP * HP + u] : 0.f);
+                    }
+                }
+            } else {
+                for (int t = threadIdx.x; t < nmid; t += nthreads) o[DP * HP + t] = W[d_a * HP + t];
+            }
         }
         float* ea = img + f.n_coupling * lf;
         const bool revl = (f.n_coupling & 1) != 0;
@@ -123,6 +148,7 @@ template <int CPL, int LPC, int HP, bool LEAN = false, bool EXACT = false>
 struct FlowB {
     using Img = FlowImage<CPL, LPC, HP>;
     static constexpr int DP = CPL * LPC;
+    static constexpr bool kExact = EXACT;
     static_assert(!EXACT || CPL >= 8, "EXACT needs whole register quads per half");
     const float* img;  // LDS
     int n_hl, n_coupling, lf, g;
@@ -150,9 +176,9 @@ struct FlowB {
         constexpr int S0 = EXACT ? (REV ? CPL / 2 : 0) : 0, S1 = EXACT ? S0 + CPL / 2 : CPL;       // source registers
         constexpr int T0 = EXACT ? (REV ? 0 : CPL / 2) : 0, T1 = EXACT ? T0 + CPL / 2 : CPL;       // target registers
         const float* W1 = img + l * lf + g * HP;
-        // hidden-stack weights are wave-uniform: broadcast 128-bit reads from the LDS image.  (Through the scalar
-        // cache -- constant address space, s_load, SGPR operands -- they cost 24 (HP = 4) / 80 (HP = 8) SGPRs per
-        // layer, spilled to VGPR lanes at HP = 8, and measured 3-5 % slower at both widths.)
+        // hidden-stack weights come from the LDS image (one row per lane class when distributed, else wave-uniform
+        // broadcast reads).  Through the scalar cache -- constant address space, s_load, SGPR operands -- the
+        // redundant form cost 24 (HP = 4) / 80 (HP = 8) SGPRs per layer and measured 3-5 % slower at both widths.
         const float* b1 = img + l * lf + DP * HP;
         float h[HP];
 #pragma unroll
@@ -165,29 +191,46 @@ struct FlowB {
             for (int k = 0; k < HP; ++k) h[k] = fmaf(w[k], x[i], h[k]);
             if constexpr (LEAN) __builtin_amdgcn_sched_barrier(0);
         }
-        {
-            float bb[HP];
-            load_row16<HP>(bb, b1);
+        if constexpr (Img::DIST) {
+            const int ub = g & (HP - 1);
+            float v = fast_tanh(group_reduce_scatter<HP, LPC>(h) + b1[ub]);
+            group_all_gather<HP>(v, h);
+            const float* Wh = b1 + HP + ub * Img::HROW;
+            for (int hl = 1; hl < n_hl; ++hl) {
+                float wr[Img::HROW];
+                load_row16<Img::HROW>(wr, Wh);
+                float t = wr[HP];
 #pragma unroll
-            for (int k = 0; k < HP; ++k) h[k] = fast_tanh(group_allreduce<LPC>(h[k]) + bb[k]);
-        }
-        const float* Wh = b1 + HP;
-        for (int hl = 1; hl < n_hl; ++hl) {
-            float t[HP];
-            const float* bh = Wh + HP * HP;
-            load_row16<HP>(t, bh);
-#pragma unroll
-            for (int i = 0; i < HP; ++i) {
-                float wr[HP];
-                load_row16<HP>(wr, Wh + i * HP);
-#pragma unroll
-                for (int k = 0; k < HP; ++k) t[k] = fmaf(wr[k], h[i], t[k]);
+                for (int k = 0; k < HP; ++k) t = fmaf(wr[k], h[k], t);
+                v = fast_tanh(t);
+                group_all_gather<HP>(v, h);
+                Wh += Img::HL;
             }
+        } else {
+            {
+                float bb[HP];
+                load_row16<HP>(bb, b1);
 #pragma unroll
-            for (int k = 0; k < HP; ++k) h[k] = fast_tanh(t[k]);
-            Wh = bh + HP;
+                for (int k = 0; k < HP; ++k) h[k] = fast_tanh(group_allreduce<LPC>(h[k]) + bb[k]);
+            }
+            const float* Wh = b1 + HP;
+            for (int hl = 1; hl < n_hl; ++hl) {
+                float t[HP];
+                const float* bh = Wh + HP * HP;
+                load_row16<HP>(t, bh);
+#pragma unroll
+                for (int i = 0; i < HP; ++i) {
+                    float wr[HP];
+                    load_row16<HP>(wr, Wh + i * HP);
+#pragma unroll
+                    for (int k = 0; k < HP; ++k) t[k] = fmaf(wr[k], h[i], t[k]);
+                }
+#pragma unroll
+                for (int k = 0; k < HP; ++k) h[k] = fast_tanh(t[k]);
+                Wh = bh + HP;
+            }
         }
-        const float* W3 = img + l * lf + DP * HP + (HP + (n_hl - 1) * (HP * HP + HP)) + g * Img::RS;
+        const float* W3 = img + l * lf + DP * HP + Img::mid_floats(n_hl) + g * Img::RS;
         float ld = 0.f;
 #pragma unroll
         for (int i = T0; i < T1; ++i) {
@@ -261,7 +304,8 @@ struct FlowB {
 
 // latent z ~ N(0, I) for this lane's positions: position p holds logical latent coordinate (revl ? d-1-p : p).
 // `replay`: NULL -> native stream 2, else the (n, d) latents of this transition.
-template <int CPL, int LPC>
+// ALIGNED4: d % 4 == 0 is known at compile time (exact-fit layouts), so the per-coordinate branch is not emitted.
+template <int CPL, int LPC, bool ALIGNED4 = false>
 __device__ __forceinline__ void draw_latent(float (&z)[CPL], const float* __restrict__ replay, uint64_t seed,
                                             uint32_t step, uint32_t gchain, int64_t row, int64_t n, int d, int g,
                                             bool revl) {
@@ -275,7 +319,7 @@ __device__ __forceinline__ void draw_latent(float (&z)[CPL], const float* __rest
         return;
     }
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-    if (!revl || (d & 3) == 0) {
+    if (ALIGNED4 || !revl || (d & 3) == 0) {
         // a register quad is one Philox block (reversed flows with d % 4 == 0: block d/4-1-b, elements reversed)
 #pragma unroll
         for (int q = 0; q < CPL / 4; ++q) {

@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(kBlock, NFMC_FLOWB_WPE) flow_mh_b_kernel(NfmcF
         }
         for (int s = 0; s < a.n_steps; ++s) {
             float xp[CPL];
-            draw_latent<CPL, LPC>(xp, a.rng.replay_normals ? a.rng.replay_normals + (int64_t)s * n * d : nullptr, a.rng.seed,
+            draw_latent<CPL, LPC, FAST>(xp, a.rng.replay_normals ? a.rng.replay_normals + (int64_t)s * n * d : nullptr, a.rng.seed,
                                   a.rng.step0 + (uint32_t)s, gchain, row, n, d, g, revl);  // flow.sample: jump.py:205 / imh.py:221
             float part = 0.f;
 #pragma unroll

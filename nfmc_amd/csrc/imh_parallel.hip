@@ -29,7 +29,7 @@ __device__ __forceinline__ void imh_propose(float (&xp)[CPL], float& f_xp, float
                                             float base_c) {
     const int d = a.flow.d;
     const uint32_t gchain = (uint32_t)(a.rng.chain_offset + (uint64_t)i);
-    draw_latent<CPL, LPC>(xp, a.rng.replay_normals ? a.rng.replay_normals + (int64_t)s * a.n * d : nullptr, a.rng.seed,
+    draw_latent<CPL, LPC, FlowT::kExact>(xp, a.rng.replay_normals ? a.rng.replay_normals + (int64_t)s * a.n * d : nullptr, a.rng.seed,
                           a.rng.step0 + (uint32_t)s, gchain, i, a.n, d, g, revl);          // flow.sample: imh.py:221
     float part = 0.f;
 #pragma unroll

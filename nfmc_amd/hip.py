@@ -195,10 +195,13 @@ class DeviceStats:
     def __init__(self, d, device):
         self.d = d
         self.device = device
-        self._sum_x = torch.zeros(d, dtype=torch.float64, device=device)
-        self._sum_x2 = torch.zeros(d, dtype=torch.float64, device=device)
-        self._counters = torch.zeros(CNT_WORDS, dtype=torch.int64, device=device)
-        self._jump_counters = torch.zeros(CNT_WORDS, dtype=torch.int64, device=device)
+        # one backing allocation (8-byte words), so the totals come back in ONE device-to-host copy (host_totals):
+        # each separate .cpu() is ~30 us of latency at the end of every sample() call
+        self._buf = torch.zeros(2 * d + 2 * CNT_WORDS, dtype=torch.float64, device=device)
+        self._sum_x = self._buf[:d]
+        self._sum_x2 = self._buf[d:2 * d]
+        self._counters = self._buf[2 * d:2 * d + CNT_WORDS].view(torch.int64)
+        self._jump_counters = self._buf[2 * d + CNT_WORDS:].view(torch.int64)
         nbytes = int(lib().nfmc_stats_scratch_bytes(d))
         self.scratch = torch.zeros(nbytes // 8, dtype=torch.float64, device=device)
         self._pending = False
@@ -255,12 +258,17 @@ class DeviceStats:
         self.fold()
         return self._jump_counters
 
+    def host_totals(self):
+        """(sum_x, sum_x2, counters, jump_counters) as CPU tensors from one copy (synchronises the stream)."""
+        self.fold()
+        h = self._buf.cpu()
+        d = self.d
+        return (h[:d], h[d:2 * d], h[2 * d:2 * d + CNT_WORDS].view(torch.int64),
+                h[2 * d + CNT_WORDS:].view(torch.int64))
+
     def zero_(self):
         self.fold()
-        self._sum_x.zero_()
-        self._sum_x2.zero_()
-        self._counters.zero_()
-        self._jump_counters.zero_()
+        self._buf.zero_()
 
 
 def null_stats():

@@ -112,12 +112,12 @@ class FixedIMH(AbstractIMH):
             bar.update(k)
         bar.close()
         run.sync()
-        cnt = run.stats.counters.cpu()
+        sum_x, sum_x2, cnt, _jc = run.stats.host_totals()
         st = out.statistics
         st.update_counters(n_target_calls=2 * n * done, n_accepted_trajectories=int(cnt[hip.CNT_ACCEPTED]),
                            n_attempted_trajectories=int(cnt[hip.CNT_ATTEMPTED]))
         st.n_nonfinite_log_ratios = int(cnt[hip.CNT_NONFINITE])
-        st.absorb_device_sums(run.stats.sum_x.reshape(event_shape), run.stats.sum_x2.reshape(event_shape), n * done)
+        st.absorb_device_sums(sum_x.reshape(event_shape), sum_x2.reshape(event_shape), n * done)
         if buf is not None and done > 0:
             out.running_samples.add(buf[:done].reshape(done, n, *event_shape))
         out.running_samples.last_sample = run.x.reshape(n, *event_shape).clone()
@@ -235,13 +235,13 @@ class AdaptiveIMH(AbstractIMH):
             bar.update(1)
         bar.close()
         run.sync()
-        cnt = run.stats.counters.cpu()
+        sum_x, sum_x2, cnt, _jc = run.stats.host_totals()
         st = out.statistics
         # imh.py:140-144 books the 2n target evaluations as gradient calls; kept
         st.update_counters(n_target_gradient_calls=2 * n * done, n_accepted_trajectories=int(cnt[hip.CNT_ACCEPTED]),
                            n_attempted_trajectories=int(cnt[hip.CNT_ATTEMPTED]))
         st.n_nonfinite_log_ratios = int(cnt[hip.CNT_NONFINITE])
-        st.absorb_device_sums(run.stats.sum_x.reshape(event_shape), run.stats.sum_x2.reshape(event_shape), n * done)
+        st.absorb_device_sums(sum_x.reshape(event_shape), sum_x2.reshape(event_shape), n * done)
         if done > 0:
             out.running_samples.add(buf[:done].reshape(done, n, *event_shape))
         out.running_samples.last_sample = run.x.reshape(n, *event_shape).clone()

@@ -131,7 +131,8 @@ def imh_parallel_ok(run: Run, flow) -> bool:
     dp = 4
     while dp < bij.d:
         dp *= 2
-    image_floats = bij.n_coupling * (dp * hp + hp + (bij.n_hidden_layers - 1) * (hp * hp + hp) + dp * (2 * hp + 4)) + 4 * dp
+    hl = hp * (hp + 4)   # flow_b.hpp FlowImage::HL, distributed form (an upper bound of the other)
+    image_floats = bij.n_coupling * (dp * hp + hp + (bij.n_hidden_layers - 1) * hl + dp * (2 * hp + 4)) + 4 * dp
     if image_floats * 4 > 120 * 1024:
         return False
     env = os.environ.get('NFMC_IMH_PARALLEL')
@@ -334,8 +335,7 @@ class JumpNFMC(Sampler):
                                     f'{int(run.stats.counters[hip.CNT_ATTEMPTED])}')
         run.sync()
         inner._cur_run = None
-        cnt = run.stats.counters.cpu()
-        jc = run.stats.jump_counters.cpu()
+        sum_x, sum_x2, cnt, jc = run.stats.host_totals()
         calls, grads = inner._counts(n, K * done)
         st = out.statistics
         st.update_counters(n_accepted_trajectories=int(cnt[hip.CNT_ACCEPTED]),
@@ -344,8 +344,7 @@ class JumpNFMC(Sampler):
                            n_target_gradient_calls=grads,
                            n_accepted_jumps=int(jc[hip.CNT_ACCEPTED]), n_attempted_jumps=n * done)
         st.n_nonfinite_log_ratios = int(cnt[hip.CNT_NONFINITE]) + int(jc[hip.CNT_NONFINITE])
-        st.absorb_device_sums(run.stats.sum_x.reshape(event_shape), run.stats.sum_x2.reshape(event_shape),
-                              n * done * (K + 1))
+        st.absorb_device_sums(sum_x.reshape(event_shape), sum_x2.reshape(event_shape), n * done * (K + 1))
         if buf is not None and done > 0:
             out.running_samples.add(buf[:done * (K + 1)].reshape(done * (K + 1), n, *event_shape))
         out.running_samples.last_sample = run.x.reshape(n, *event_shape).clone()

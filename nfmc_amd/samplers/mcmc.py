@@ -172,13 +172,13 @@ class MCMCSampler(Sampler):
             bar.update(k)
         bar.close()
         run.sync()
-        cnt = run.stats.counters.cpu()
+        sum_x, sum_x2, cnt, _jc = run.stats.host_totals()
         calls, grads = self._counts(n, done)
         out.statistics.update_counters(n_target_calls=calls, n_target_gradient_calls=grads, n_divergences=0,
                                        n_accepted_trajectories=int(cnt[hip.CNT_ACCEPTED]),
                                        n_attempted_trajectories=int(cnt[hip.CNT_ATTEMPTED]))
         out.statistics.n_nonfinite_log_ratios = int(cnt[hip.CNT_NONFINITE])
-        out.statistics.absorb_device_sums(run.stats.sum_x.reshape(event_shape), run.stats.sum_x2.reshape(event_shape),
+        out.statistics.absorb_device_sums(sum_x.reshape(event_shape), sum_x2.reshape(event_shape),
                                           n * done)
         rs = out.running_samples
         if buf is not None and done > 0:
