@@ -13,14 +13,29 @@
 namespace nfmc {
 
 struct ImhWork {
-    float* u;        // (k, n) U(x')
-    float* f;        // (k, n) log q(x')
-    float* logu;     // (k, n) log of the accept uniform of (step, chain)
-    int32_t* dwell;  // (k, n) number of steps proposal (s, i) was the state of chain i (0: rejected)
+    // chain-major (n, k): a chain's k proposals are contiguous, so the scan's 64 lanes read 64 consecutive words
+    // (step-major made every lane of the scan touch its own cache line: 284 us of a 1.8 ms run at n = 8192, k = 1000)
+    float* u;        // (n, k) U(x')
+    float* f;        // (n, k) log q(x')
+    float* logu;     // (n, k) log of the accept uniform of (chain, step)
+    int32_t* dwell;  // (n, k) number of steps proposal (i, s) was the state of chain i (0: rejected)
     int32_t* dwell0; // (n)    the same for the initial state
     int32_t* last;   // (n)    step whose proposal is the final state, -1: the initial state
     float* x0;       // (n, d) copy of the initial states
 };
+
+// row r of the chain-major work arrays -> (chain i, step s).  A 64-bit division is ~180 VALU instructions on
+// gfx950 (a quarter of the proposal loop); every launch the host makes has n * k < 2^31 (`small`).
+__device__ __forceinline__ void split_row(int64_t r, int k, bool small, int64_t& i, int& s) {
+    if (small) {
+        const uint32_t q = (uint32_t)r / (uint32_t)k;
+        i = q;
+        s = (int)((uint32_t)r - q * (uint32_t)k);
+    } else {
+        i = r / k;
+        s = (int)(r - i * k);
+    }
+}
 
 // proposal (s, i): latent from the chain's stream, inverse pass, log q and potential.  All lanes of the row group.
 template <int CPL, int LPC, int HP, class FlowT, class PotT>
@@ -51,6 +66,7 @@ __global__ void __launch_bounds__(kBlock) imh_eval_kernel(NfmcFlowMhArgs a, ImhW
     const int g = lane % LPC, cw = lane / LPC;
     const int d = a.flow.d;
     const int64_t n = a.n, total = n * (int64_t)a.n_steps;
+    const bool small = total < (1ll << 31);
     FlowImage<CPL, LPC, HP>::stage(lds, a.flow, kBlock);
     __syncthreads();
     FlowB<CPL, LPC, HP, false, (FAST && CPL >= 8)> fl;
@@ -59,27 +75,42 @@ __global__ void __launch_bounds__(kBlock) imh_eval_kernel(NfmcFlowMhArgs a, ImhW
     pot.init(a.pot, g, d);
     const bool revl = (a.flow.n_coupling & 1) != 0;
     const float base_c = -0.5f * (float)d * kLog2Pi;
+    // a wave owns 64 consecutive rows per tile: first every lane draws the accept uniform of ONE row (one Philox call
+    // per row instead of one per lane and row: 8 % of the kernel at LPC = 8), then LPC passes evaluate CPW rows each
     for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        const int64_t r = (tile * kWavesPerBlock + wave) * CPW + cw;
-        const bool active = r < total;
-        const int64_t rr = active ? r : total - 1;
-        const int s = (int)(rr / n);
-        const int64_t i = rr - (int64_t)s * n;
-        float xp[CPL], f_xp, u_xp;
-        imh_propose<CPL, LPC, HP>(xp, f_xp, u_xp, a, fl, pot, i, s, g, revl, base_c);
-        if (active && g == 0) {
-            float uu;   // the accept uniform of (chain i, step s): imh.py:229
-            if (a.rng.replay_uniforms) {
-                uu = a.rng.replay_uniforms[r];
-            } else {
-                const uint4 rnd = philox4x32_10((uint32_t)(a.rng.chain_offset + (uint64_t)i), a.rng.step0 + (uint32_t)s, 0u,
-                                                kTagJump, (uint32_t)a.rng.seed, (uint32_t)(a.rng.seed >> 32));
-                uu = u32_to_uniform(rnd.x);
+        const int64_t r0 = (tile * kWavesPerBlock + wave) * kWave;
+        {
+            const int64_t r = r0 + lane;
+            if (r < total) {
+                int64_t i;
+                int s;
+                split_row(r, a.n_steps, small, i, s);
+                float uu;   // the accept uniform of (chain i, step s): imh.py:229
+                if (a.rng.replay_uniforms) {
+                    uu = a.rng.replay_uniforms[(int64_t)s * n + i];
+                } else {
+                    const uint4 rnd = philox4x32_10((uint32_t)(a.rng.chain_offset + (uint64_t)i), a.rng.step0 + (uint32_t)s, 0u,
+                                                    kTagJump, (uint32_t)a.rng.seed, (uint32_t)(a.rng.seed >> 32));
+                    uu = u32_to_uniform(rnd.x);
+                }
+                w.logu[r] = fast_ln(uu);
+                w.dwell[r] = 0;
             }
-            w.u[r] = u_xp;
-            w.f[r] = f_xp;
-            w.logu[r] = fast_ln(uu);
-            w.dwell[r] = 0;
+        }
+        for (int sub = 0; sub < LPC; ++sub) {
+            const int64_t rb = r0 + (int64_t)sub * CPW;
+            if (rb >= total) break;                                   // wave-uniform
+            const int64_t r = rb + cw;
+            const bool active = r < total;
+            int64_t i;
+            int s;
+            split_row(active ? r : total - 1, a.n_steps, small, i, s);
+            float xp[CPL], f_xp, u_xp;
+            imh_propose<CPL, LPC, HP>(xp, f_xp, u_xp, a, fl, pot, i, s, g, revl, base_c);
+            if (active && g == 0) {
+                w.u[r] = u_xp;
+                w.f[r] = f_xp;
+            }
         }
     }
 }
@@ -104,7 +135,8 @@ __global__ void __launch_bounds__(256) imh_scan_kernel(NfmcFlowMhArgs a, ImhWork
         while (pos < k) {
             const int s = pos + lane;
             const bool valid = s < k;
-            const int64_t r = (int64_t)(valid ? s : k - 1) * n + i;
+            const int sv = valid ? s : k - 1;
+            const int64_t r = i * k + sv, ro = (int64_t)sv * n + i;   // work arrays (n, k); outputs (k, n)
             const float pu = w.u[r], pf = w.f[r], pl = w.logu[r];
             const float lr = (-pu) - (-u_x) + f_x - pf;      // util.py:392
             const bool acc = valid && pl < lr;                // imh.py:229-230; NaN -> reject
@@ -114,14 +146,14 @@ __global__ void __launch_bounds__(256) imh_scan_kernel(NfmcFlowMhArgs a, ImhWork
             const unsigned long long decided = j == 63 ? ~0ull : ((2ull << j) - 1ull);
             bad_total += (unsigned long long)__popcll(bm & decided);
             if (valid && lane <= j) {
-                if (a.masks_out) a.masks_out[r] = (acc && lane == j) ? 1 : 0;
-                if (a.log_ratio_out) a.log_ratio_out[r] = lr;
+                if (a.masks_out) a.masks_out[ro] = (acc && lane == j) ? 1 : 0;
+                if (a.log_ratio_out) a.log_ratio_out[ro] = lr;
             }
             if (am) {
                 const int s_acc = pos + j;
                 if (lane == 0) {
                     if (cur < 0) w.dwell0[i] = s_acc;                    // steps before the first acceptance
-                    else w.dwell[(int64_t)cur * n + i] = s_acc - cur;    // steps this proposal stayed the state
+                    else w.dwell[i * k + cur] = s_acc - cur;             // steps this proposal stayed the state
                 }
                 u_x = __shfl(pu, j, kWave);
                 f_x = __shfl(pf, j, kWave);
@@ -134,7 +166,7 @@ __global__ void __launch_bounds__(256) imh_scan_kernel(NfmcFlowMhArgs a, ImhWork
         }
         if (lane == 0) {
             if (cur < 0) w.dwell0[i] = k;
-            else w.dwell[(int64_t)cur * n + i] = k - cur;
+            else w.dwell[i * k + cur] = k - cur;
             w.last[i] = cur;
             a.logq[i] = f_x;                                              // imh.py:233
         }
@@ -155,6 +187,7 @@ __global__ void __launch_bounds__(kBlock) imh_replay_kernel(NfmcFlowMhArgs a, Im
     const int g = lane % LPC, cw = lane / LPC;
     const int d = a.flow.d;
     const int64_t n = a.n, total = n * (int64_t)a.n_steps + n;   // proposals, then the n initial states
+    const bool small = total < (1ll << 31);
     FlowImage<CPL, LPC, HP>::stage(lds, a.flow, kBlock);
     __syncthreads();
     FlowB<CPL, LPC, HP, false, (FAST && CPL >= 8)> fl;
@@ -166,43 +199,52 @@ __global__ void __launch_bounds__(kBlock) imh_replay_kernel(NfmcFlowMhArgs a, Im
     float sx[CPL], sxx[CPL];
 #pragma unroll
     for (int q = 0; q < CPL; ++q) sx[q] = sxx[q] = 0.f;
+    // a wave looks at 64 consecutive rows at a time (one coalesced load of their dwell counts) and runs the flow pass
+    // only for the rows that were ever a chain's state, CPW of them per pass: at the usual acceptance rates almost
+    // every 64-row chunk is skipped after the load (8 rows per look cost 151 us at n = 8192, k = 1000)
     for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        const int64_t r = (tile * kWavesPerBlock + wave) * CPW + cw;
-        const bool active = r < total;
-        const bool initial = active && r >= total - n;
-        int c = 0, s = -1;
-        int64_t i = 0;
-        if (active) {
-            if (initial) {
-                i = r - (total - n);
-                c = w.dwell0[i];
-            } else {
-                s = (int)(r / n);
-                i = r - (int64_t)s * n;
-                c = w.dwell[r];
+        const int64_t r0 = (tile * kWavesPerBlock + wave) * kWave;
+        int c_lane = 0;
+        {
+            const int64_t r = r0 + lane;
+            if (r < total) c_lane = r >= total - n ? w.dwell0[r - (total - n)] : w.dwell[r];
+        }
+        unsigned long long todo = __ballot(c_lane > 0);
+        while (todo) {
+            unsigned long long m = todo;                      // this group's row: the cw-th set bit
+            for (int t = 0; t < cw; ++t) m &= m - 1ull;
+            const int bit = m ? __ffsll((long long)m) - 1 : -1;
+            const int c = __shfl(c_lane, bit < 0 ? 0 : bit, kWave) * (bit >= 0 ? 1 : 0);
+            const int64_t r = r0 + (bit < 0 ? 0 : bit);
+            const bool initial = bit >= 0 && r >= total - n;
+            int s = 0;
+            int64_t i = 0;
+            if (bit >= 0) {
+                if (initial) i = r - (total - n);
+                else split_row(r, a.n_steps, small, i, s);
             }
-        }
-        if (__ballot(c > 0) == 0ull) continue;   // nothing accepted in this wave's rows: skip the flow pass
-        float xs[CPL];
-        if (__ballot(!initial && c > 0) != 0ull) {
-            float f_xp, u_xp;
-            imh_propose<CPL, LPC, HP>(xs, f_xp, u_xp, a, fl, pot, i, s < 0 ? 0 : s, g, revl, base_c);
-        }
-        if (initial) load_row<CPL, LPC, FAST>(w.x0, i, d, g, true, xs);
-        if (c > 0) {
-            const float cf = (float)c;
+            float xs[CPL];
+            if (__ballot(!initial && c > 0) != 0ull) {
+                float f_xp, u_xp;
+                imh_propose<CPL, LPC, HP>(xs, f_xp, u_xp, a, fl, pot, i, s, g, revl, base_c);
+            }
+            if (initial) load_row<CPL, LPC, FAST>(w.x0, i, d, g, true, xs);
+            if (c > 0) {
+                const float cf = (float)c;
 #pragma unroll
-            for (int q = 0; q < CPL; ++q) {
-                sx[q] = fmaf(cf, xs[q], sx[q]);
-                sxx[q] = fmaf(cf * xs[q], xs[q], sxx[q]);
+                for (int q = 0; q < CPL; ++q) {
+                    sx[q] = fmaf(cf, xs[q], sx[q]);
+                    sxx[q] = fmaf(cf * xs[q], xs[q], sxx[q]);
+                }
+                if (!initial) {
+                    if (a.samples)
+                        for (int t = s; t < s + c; ++t) store_row<CPL, LPC, FAST>(a.samples + (int64_t)t * n * d, i, d, g, true, xs);
+                    if (w.last[i] == s) store_row<CPL, LPC, FAST>(a.x, i, d, g, true, xs);
+                } else if (a.samples) {
+                    for (int t = 0; t < c; ++t) store_row<CPL, LPC, FAST>(a.samples + (int64_t)t * n * d, i, d, g, true, xs);
+                }
             }
-            if (!initial) {
-                if (a.samples)
-                    for (int t = s; t < s + c; ++t) store_row<CPL, LPC, FAST>(a.samples + (int64_t)t * n * d, i, d, g, true, xs);
-                if (w.last[i] == s) store_row<CPL, LPC, FAST>(a.x, i, d, g, true, xs);
-            } else if (a.samples) {
-                for (int t = 0; t < c; ++t) store_row<CPL, LPC, FAST>(a.samples + (int64_t)t * n * d, i, d, g, true, xs);
-            }
+            for (int t = 0; t < CPW && todo; ++t) todo &= todo - 1ull;   // CPW rows done
         }
     }
     if (a.stats.sum_x) block_stats_flush<CPL, LPC>(sx, sxx, 0u, 0u, a.stats);
@@ -218,10 +260,9 @@ template <int CPL, int LPC, int HP>
 static int launch_imh(const NfmcFlowMhArgs& a, const ImhWork& w, hipStream_t st, int* grid_c, int* dp_out) {
     const size_t lds = (size_t)FlowImage<CPL, LPC, HP>::total_floats(a.flow.n_hidden_layers, a.flow.n_coupling) * sizeof(float);
     if (lds > 120 * 1024) return NFMC_EUNSUPPORTED;
-    constexpr int cpw = kWave / LPC, rows_per_block = kWavesPerBlock * cpw;
     const int64_t total_a = a.n * (int64_t)a.n_steps, total_c = total_a + a.n;
-    const int64_t tiles_a = (total_a + rows_per_block - 1) / rows_per_block;
-    const int64_t tiles_c = (total_c + rows_per_block - 1) / rows_per_block;
+    const int64_t tiles_a = (total_a + kWavesPerBlock * kWave - 1) / (kWavesPerBlock * kWave);   // 64 rows per wave and tile
+    const int64_t tiles_c = (total_c + kWavesPerBlock * kWave - 1) / (kWavesPerBlock * kWave);   // 64 rows per wave look
     const int grid_a = (int)(tiles_a < kMaxGrid ? tiles_a : kMaxGrid);
     const int gc = (int)(tiles_c < kMaxGrid ? tiles_c : kMaxGrid);
     const int dp = CPL * LPC;

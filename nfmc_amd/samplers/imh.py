@@ -95,8 +95,9 @@ class FixedIMH(AbstractIMH):
                 if time.time() - t0 >= time_limit_seconds:
                     break
             k = min(limit, T - done) if fused else 1
-            if fused and parallel:   # all proposals of the chunk at once: as many steps as ~8M work items allow
-                k = min(T - done, max(limit, min(hip.IMH_PARALLEL_MAX_STEPS, (1 << 23) // max(n, 1)))) if unlimited else k
+            if fused and parallel and unlimited:
+                # all proposals of the chunk at once: as many steps as 2^26 work items (1 GiB of work arrays) allow
+                k = min(T - done, hip.IMH_PARALLEL_MAX_STEPS, max(16, (1 << 26) // max(n, 1)))
             view = buf[done:done + k] if buf is not None else None
             if fused and parallel:
                 launch_imh_parallel(run, flow, pot, logq, k, done, done > 0,

@@ -121,8 +121,9 @@ def launch_flow_mh(run: Run, flow, pot, logq, k, step0, cached, adjusted, stats_
 
 
 def imh_parallel_ok(run: Run, flow) -> bool:
-    """FixedIMH as a data-parallel problem (csrc/imh_parallel.hip) pays when the chains alone do not fill the GPU
-    (sequential transitions are latency-bound there); register-layout flows only.  NFMC_IMH_PARALLEL=0/1 overrides."""
+    """FixedIMH as a data-parallel problem (csrc/imh_parallel.hip): register-layout flows only.  It wins most when the
+    chains alone do not fill the GPU (sequential transitions are latency-bound there), and still by 10-15 % when they
+    do.  NFMC_IMH_PARALLEL=0/1 overrides."""
     bij = getattr(flow, 'bijection', None)
     if not flow_is_native(flow) or bij.n_hidden > 8 or bij.n_bins != 0 or bij.d > 512:
         return False
@@ -138,7 +139,9 @@ def imh_parallel_ok(run: Run, flow) -> bool:
     env = os.environ.get('NFMC_IMH_PARALLEL')
     if env is not None:
         return env == '1'
-    return run.n <= 8192   # d = 64, 1000 steps: 2.6 vs 3.0 ms at n = 8192, 4.2 vs 3.9 ms at n = 16384
+    # d = 64, 1000 steps, parallel vs sequential: 1.0 vs 3.0 ms at n = 1000, 1.98 vs 3.0 at 8192, 5.7 vs 6.7 at 32768,
+    # 10.6 vs 12.3 at 65536 (one accept-uniform draw per row instead of per lane, no per-step select / moments)
+    return True
 
 
 def launch_imh_parallel(run: Run, flow, pot, logq, k, step0, cached, stats_struct, samples=None, masks_out=None,
