@@ -38,15 +38,20 @@ namespace nfmc {
 //       distributed: weight position r belongs to hidden unit (g % HP) ^ unit_xor(r)
 // followed, after all layers, by the ElementwiseAffine parameters per slot:
 //   ea0_ls | ea0_sh | ea1_ls | ea1_sh   (DP each; ea1 already mapped through the final reversal)
-template <int CPL, int LPC, int HP>
+// EXACT (d == DP, CPL >= 8): a layer's sources are one half of every lane's registers and its targets the other
+// half, so W1 keeps only the source slots' rows and W3 only the target slots' rows (DP/2 each, indexed by
+// (i - first register of the half) * LPC + g): half the image -- 31 instead of 62 KB at d = 256, HP = 8, which
+// lifts the LDS limit from 2 to 5 workgroups per CU -- and half the staging work per workgroup.
+template <int CPL, int LPC, int HP, bool EXACT = false>
 struct FlowImage {
     static constexpr int RS = 2 * HP + 4;
     static constexpr int DP = CPL * LPC;
+    static constexpr int ROWS = EXACT ? DP / 2 : DP;         // rows of W1 / of W3 per layer
     static constexpr bool DIST = LPC >= HP;                  // one lane class per hidden unit
     static constexpr int HROW = HP + 4;                      // distributed hidden-layer row: HP weights | bias | pad
     static constexpr int HL = DIST ? HP * HROW : HP * HP + HP;  // floats per hidden layer after the first
     __host__ __device__ static int mid_floats(int n_hl) { return HP + (n_hl - 1) * HL; }
-    __host__ __device__ static int layer_floats(int n_hl) { return DP * HP + mid_floats(n_hl) + DP * RS; }
+    __host__ __device__ static int layer_floats(int n_hl) { return ROWS * HP + mid_floats(n_hl) + ROWS * RS; }
     __host__ __device__ static int total_floats(int n_hl, int n_coupling) { return n_coupling * layer_floats(n_hl) + 4 * DP; }
 
     // all `nthreads` threads of the workgroup; blob layout: flow_device.hpp (W1T | b1 | [WhT | bh] | W3 | b3).
@@ -63,7 +68,7 @@ struct FlowImage {
             const float* W3 = W + d_a * HP + bmid;
             const float* b3 = W3 + 2 * d_b * HP;
             float* o = img + l * lf;
-            float* o3 = o + DP * HP + nmid;
+            float* o3 = o + ROWS * HP + nmid;
             for (int s = threadIdx.x; s < DP; s += nthreads) {
                 const int c = coord_of<CPL, LPC>(s % LPC, s / LPC);
                 const int j = rev ? d - 1 - c : c;
@@ -85,25 +90,31 @@ struct FlowImage {
                 r3[2 * HP + 1] = tgt ? b3[d_b + tt] : 0.f;
                 r3[2 * HP + 2] = tgt ? 1.f : 0.f;
                 r3[2 * HP + 3] = 0.f;
+                // EXACT: registers [0, CPL/2) are the first half of the coordinates; row within the half's block
+                const int sh = EXACT ? (s >= DP / 2 ? s - DP / 2 : s) : s;
+                if (!EXACT || src) {
 #pragma unroll
-                for (int k = 0; k < HP; k += 4)
-                    *reinterpret_cast<float4*>(o + s * HP + k) = make_float4(r1[k], r1[k + 1], r1[k + 2], r1[k + 3]);
+                    for (int k = 0; k < HP; k += 4)
+                        *reinterpret_cast<float4*>(o + sh * HP + k) = make_float4(r1[k], r1[k + 1], r1[k + 2], r1[k + 3]);
+                }
+                if (!EXACT || tgt) {
 #pragma unroll
-                for (int k = 0; k < RS; k += 4)
-                    *reinterpret_cast<float4*>(o3 + s * RS + k) = make_float4(r3[k], r3[k + 1], r3[k + 2], r3[k + 3]);
+                    for (int k = 0; k < RS; k += 4)
+                        *reinterpret_cast<float4*>(o3 + sh * RS + k) = make_float4(r3[k], r3[k + 1], r3[k + 2], r3[k + 3]);
+                }
             }
             if constexpr (DIST) {
-                for (int t = threadIdx.x; t < HP; t += nthreads) o[DP * HP + t] = W[d_a * HP + t];
+                for (int t = threadIdx.x; t < HP; t += nthreads) o[ROWS * HP + t] = W[d_a * HP + t];
                 for (int hl = 1; hl < n_hl; ++hl) {
                     const float* sw = W + d_a * HP + HP + (hl - 1) * (HP * HP + HP);   // WhT[in][out] | bh
-                    float* dw = o + DP * HP + HP + (hl - 1) * HL;
+                    float* dw = o + ROWS * HP + HP + (hl - 1) * HL;
                     for (int t = threadIdx.x; t < HL; t += nthreads) {
                         const int u = t / HROW, r = t % HROW;
                         dw[t] = r < HP ? sw[(u ^ unit_xor<HP>(r)) * HP + u] : (r == HP ? sw[HP * HP + u] : 0.f);
                     }
                 }
             } else {
-                for (int t = threadIdx.x; t < nmid; t += nthreads) o[DP * HP + t] = W[d_a * HP + t];
+                for (int t = threadIdx.x; t < nmid; t += nthreads) o[ROWS * HP + t] = W[d_a * HP + t];
             }
         }
         float* ea = img + f.n_coupling * lf;
@@ -146,7 +157,7 @@ __device__ __forceinline__ void load_row16(float (&w)[N], const float* __restric
 
 template <int CPL, int LPC, int HP, bool LEAN = false, bool EXACT = false>
 struct FlowB {
-    using Img = FlowImage<CPL, LPC, HP>;
+    using Img = FlowImage<CPL, LPC, HP, EXACT>;
     static constexpr int DP = CPL * LPC;
     static constexpr bool kExact = EXACT;
     static_assert(!EXACT || CPL >= 8, "EXACT needs whole register quads per half");
@@ -179,14 +190,14 @@ struct FlowB {
         // hidden-stack weights come from the LDS image (one row per lane class when distributed, else wave-uniform
         // broadcast reads).  Through the scalar cache -- constant address space, s_load, SGPR operands -- the
         // redundant form cost 24 (HP = 4) / 80 (HP = 8) SGPRs per layer and measured 3-5 % slower at both widths.
-        const float* b1 = img + l * lf + DP * HP;
+        const float* b1 = img + l * lf + Img::ROWS * HP;
         float h[HP];
 #pragma unroll
         for (int k = 0; k < HP; ++k) h[k] = 0.f;
 #pragma unroll
         for (int i = S0; i < S1; ++i) {  // generic path: zero rows for coordinates that are not sources of this layer
             float w[HP];
-            load_row16<HP>(w, W1 + i * LPC * HP);
+            load_row16<HP>(w, W1 + (i - S0) * LPC * HP);
 #pragma unroll
             for (int k = 0; k < HP; ++k) h[k] = fmaf(w[k], x[i], h[k]);
             if constexpr (LEAN) __builtin_amdgcn_sched_barrier(0);
@@ -230,12 +241,12 @@ struct FlowB {
                 Wh = bh + HP;
             }
         }
-        const float* W3 = img + l * lf + DP * HP + Img::mid_floats(n_hl) + g * Img::RS;
+        const float* W3 = img + l * lf + Img::ROWS * HP + Img::mid_floats(n_hl) + g * Img::RS;
         float ld = 0.f;
 #pragma unroll
         for (int i = T0; i < T1; ++i) {
             float w[Img::RS];
-            load_row16<Img::RS>(w, W3 + i * LPC * Img::RS);
+            load_row16<Img::RS>(w, W3 + (i - T0) * LPC * Img::RS);
             float ua = w[2 * HP], ub = w[2 * HP + 1];
 #pragma unroll
             for (int k = 0; k < HP; ++k) {

@@ -17,9 +17,10 @@ __global__ void __launch_bounds__(kBlock, NFMC_FLOWB_WPE) flow_mh_b_kernel(NfmcF
     const int g = lane % LPC, cw = lane / LPC;
     const int d = a.flow.d;
     const int64_t n = a.n;
-    FlowImage<CPL, LPC, HP>::stage(lds, a.flow, kBlock);
+    using Flow = FlowB<CPL, LPC, HP, false, (FAST && CPL >= 8)>;
+    Flow::Img::stage(lds, a.flow, kBlock);
     __syncthreads();
-    FlowB<CPL, LPC, HP, false, (FAST && CPL >= 8)> fl;
+    Flow fl;
     fl.init(lds, a.flow, g);
     Pot<CPL, LPC, FAST> pot;
     pot.init(a.pot, g, d);
@@ -124,10 +125,11 @@ static const BCfg kBCfgs[] = {{4, 1}, {4, 2}, {4, 4}, {4, 8}, {8, 8}, {4, 16}, {
 
 template <int CPL, int LPC, int HP>
 static int launch_b(const NfmcFlowMhArgs& a, bool fast, int64_t tiles, int grid, hipStream_t st) {
-    const size_t lds = (size_t)FlowImage<CPL, LPC, HP>::total_floats(a.flow.n_hidden_layers, a.flow.n_coupling) * sizeof(float);
-    if (lds > 120 * 1024) return NFMC_EUNSUPPORTED;
 #define NFMC_LB(POT, F)                                                                                         \
     {                                                                                                           \
+        const size_t lds = (size_t)FlowImage<CPL, LPC, HP, (F && CPL >= 8)>::total_floats(a.flow.n_hidden_layers, \
+                                                                                       a.flow.n_coupling) * sizeof(float); \
+        if (lds > 120 * 1024) return NFMC_EUNSUPPORTED;                                                         \
         auto kern = flow_mh_b_kernel<CPL, LPC, HP, POT, F>;                                                     \
         if (lds > 48 * 1024) {                                                                                  \
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,   \

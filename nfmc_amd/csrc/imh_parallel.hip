@@ -67,9 +67,10 @@ __global__ void __launch_bounds__(kBlock) imh_eval_kernel(NfmcFlowMhArgs a, ImhW
     const int d = a.flow.d;
     const int64_t n = a.n, total = n * (int64_t)a.n_steps;
     const bool small = total < (1ll << 31);
-    FlowImage<CPL, LPC, HP>::stage(lds, a.flow, kBlock);
+    using Flow = FlowB<CPL, LPC, HP, false, (FAST && CPL >= 8)>;
+    Flow::Img::stage(lds, a.flow, kBlock);
     __syncthreads();
-    FlowB<CPL, LPC, HP, false, (FAST && CPL >= 8)> fl;
+    Flow fl;
     fl.init(lds, a.flow, g);
     Pot<CPL, LPC, FAST> pot;
     pot.init(a.pot, g, d);
@@ -188,9 +189,10 @@ __global__ void __launch_bounds__(kBlock) imh_replay_kernel(NfmcFlowMhArgs a, Im
     const int d = a.flow.d;
     const int64_t n = a.n, total = n * (int64_t)a.n_steps + n;   // proposals, then the n initial states
     const bool small = total < (1ll << 31);
-    FlowImage<CPL, LPC, HP>::stage(lds, a.flow, kBlock);
+    using Flow = FlowB<CPL, LPC, HP, false, (FAST && CPL >= 8)>;
+    Flow::Img::stage(lds, a.flow, kBlock);
     __syncthreads();
-    FlowB<CPL, LPC, HP, false, (FAST && CPL >= 8)> fl;
+    Flow fl;
     fl.init(lds, a.flow, g);
     Pot<CPL, LPC, FAST> pot;
     pot.init(a.pot, g, d);
@@ -258,8 +260,9 @@ static const PCfg kPCfgs[] = {{4, 1}, {4, 2}, {4, 4}, {4, 8}, {8, 8}, {8, 16}, {
 
 template <int CPL, int LPC, int HP>
 static int launch_imh(const NfmcFlowMhArgs& a, const ImhWork& w, hipStream_t st, int* grid_c, int* dp_out) {
-    const size_t lds = (size_t)FlowImage<CPL, LPC, HP>::total_floats(a.flow.n_hidden_layers, a.flow.n_coupling) * sizeof(float);
-    if (lds > 120 * 1024) return NFMC_EUNSUPPORTED;
+    // sized for the generic image; the exact-fit kernels use (and are launched with) half of it
+    if ((size_t)FlowImage<CPL, LPC, HP>::total_floats(a.flow.n_hidden_layers, a.flow.n_coupling) * sizeof(float) > 120 * 1024)
+        return NFMC_EUNSUPPORTED;
     const int64_t total_a = a.n * (int64_t)a.n_steps, total_c = total_a + a.n;
     const int64_t tiles_a = (total_a + kWavesPerBlock * kWave - 1) / (kWavesPerBlock * kWave);   // 64 rows per wave and tile
     const int64_t tiles_c = (total_c + kWavesPerBlock * kWave - 1) / (kWavesPerBlock * kWave);   // 64 rows per wave look
@@ -270,6 +273,8 @@ static int launch_imh(const NfmcFlowMhArgs& a, const ImhWork& w, hipStream_t st,
     if (check_defer(a.stats, dp, a.flow.d)) return NFMC_EINVAL;
 #define NFMC_LI(POT, F)                                                                                           \
     {                                                                                                             \
+        const size_t lds = (size_t)FlowImage<CPL, LPC, HP, (F && CPL >= 8)>::total_floats(a.flow.n_hidden_layers,  \
+                                                                                       a.flow.n_coupling) * sizeof(float); \
         auto ka = imh_eval_kernel<CPL, LPC, HP, POT, F>;                                                          \
         auto kc = imh_replay_kernel<CPL, LPC, HP, POT, F>;                                                        \
         if (lds > 48 * 1024) {                                                                                    \

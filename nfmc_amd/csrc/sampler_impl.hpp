@@ -192,7 +192,7 @@ __global__ void __launch_bounds__(kBlock, NFMC_WPE) mala_kernel(NfmcMalaArgs a, 
     if constexpr (Pot<CPL, LPC, FAST>::kQuadratic) mc.init_quadratic(pot, rw);
     FlowB<CPL, LPC, JHP == 0 ? 4 : JHP, true, (FAST && CPL >= 8 && JHP > 0)> fl;
     if constexpr (JHP > 0) {
-        FlowImage<CPL, LPC, JHP>::stage(flow_lds, jd.flow, kBlock);
+        decltype(fl)::Img::stage(flow_lds, jd.flow, kBlock);
         __syncthreads();
         fl.init(flow_lds, jd.flow, g);
     }
@@ -331,7 +331,7 @@ __global__ void __launch_bounds__(kBlock, NFMC_WPE) hmc_kernel(NfmcHmcArgs a, in
     pot.init(a.pot, g, d);
     FlowB<CPL, LPC, JHP == 0 ? 4 : JHP, true, (FAST && CPL >= 8 && JHP > 0)> fl;
     if constexpr (JHP > 0) {
-        FlowImage<CPL, LPC, JHP>::stage(flow_lds, jd.flow, kBlock);
+        decltype(fl)::Img::stage(flow_lds, jd.flow, kBlock);
         __syncthreads();
         fl.init(flow_lds, jd.flow, g);
     }
