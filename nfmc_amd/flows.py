@@ -119,7 +119,13 @@ class RealNVP(nn.Module):
         return c[0].n_layers if c else 1
 
     def _version_key(self, device):
-        return (str(device),) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        # live parameter dicts of a cached module list: `self.parameters()` re-walks the module tree (~50 us for the
+        # default flow, once per jump launch); reassigned or in-place updated parameters still change the key
+        mods = self.__dict__.get('_mods_cache')
+        if mods is None:
+            mods = self.__dict__['_mods_cache'] = [m for m in self.modules() if m._parameters]
+        return (str(device),) + tuple((p.data_ptr(), p._version) for m in mods for p in m._parameters.values()
+                                      if p is not None)
 
     def default_min_hidden(self) -> int:
         """Width to present to the flow kernels by default: at d = 64 / 128 a conditioner of width 9..32 is faster

@@ -173,7 +173,14 @@ def ptr(t, dtype=torch.float32):
     return C.c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def stream():
+    """torch's current stream on the current device as a hipStream_t (the raw binding: the public
+    `torch.cuda.current_stream()` builds a Stream object, ~10 us per call, once per kernel launch)."""
+    if _raw_stream is not None:
+        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
