@@ -103,7 +103,21 @@ def main():
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        # stdout carries exactly one JSON line: RCCL prints its init banner ("RCCL version : ...", debug level VERSION,
+        # which the bench box sets) with printf, so file descriptor 1 points at stderr while the communicator is built
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+            dist.barrier()
+        finally:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)   # the banner sits in C stdio's buffer when stdout is a pipe
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
+
     from nfmc_amd.dist import Shard
     shard = Shard(rank=rank, world=world) if distributed else None
 
