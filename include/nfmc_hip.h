@@ -223,6 +223,12 @@ typedef struct {
 
 int nfmc_flow_mh_steps_f32(const NfmcFlowMhArgs* args, nfmc_stream_t stream);
 
+/* NFMC_OK when nfmc_flow_mh_steps_f32 has a kernel for `args` (launches nothing), NFMC_EUNSUPPORTED when not -- e.g.
+ * ragged d > ~300 with a narrow conditioner whose weight image does not fit the LDS and whose wave tiles do not
+ * either: the caller then composes the transition from nfmc_realnvp_inverse_f32 / nfmc_realnvp_forward_f32 and
+ * nfmc_mh_accept_select_f32 (the split path every foreign flow object takes; jump.py:205-231). */
+int nfmc_flow_mh_supported_f32(const NfmcFlowMhArgs* args);
+
 /* The same run of n_steps independent-MH transitions (FixedIMH.sample, imh.py:200-255) as a data-parallel problem:
  * the proposals of an independence sampler do not depend on the state, so all n * n_steps of them are evaluated at
  * once, a per-chain scan applies the Metropolis tests, and the accepted proposals are replayed, weighted by their
@@ -233,6 +239,8 @@ int nfmc_flow_mh_steps_f32(const NfmcFlowMhArgs* args, nfmc_stream_t stream);
 #define NFMC_IMH_PARALLEL_MAX_STEPS 65536
 int64_t nfmc_imh_parallel_work_bytes(int64_t n, int32_t d, int32_t n_steps);
 int nfmc_imh_parallel_f32(const NfmcFlowMhArgs* args, void* work, int64_t work_bytes, nfmc_stream_t stream);
+/* NFMC_OK when nfmc_imh_parallel_f32 has a kernel for `args` (validates, launches nothing). */
+int nfmc_imh_parallel_supported_f32(const NfmcFlowMhArgs* args);
 
 /* ---- K5 + K2: HMC in latent space on U~(z) = U(f^-1(z)) - logdet_inv(z), gradient by a hand-written
  * VJP through the coupling stack.  Replaces `NeuTra.adjusted_target` under `HMC.propose`

@@ -124,12 +124,13 @@ static const BCfg kBCfgs[] = {{4, 1}, {4, 2}, {4, 4}, {4, 8}, {8, 8}, {4, 16}, {
 #define NFMC_FOR_BCFG(M) M(4, 1) M(4, 2) M(4, 4) M(4, 8) M(8, 8) M(4, 16) M(8, 16) M(4, 32) M(8, 32) M(4, 64) M(8, 64)
 
 template <int CPL, int LPC, int HP>
-static int launch_b(const NfmcFlowMhArgs& a, bool fast, int64_t tiles, int grid, hipStream_t st) {
+static int launch_b(const NfmcFlowMhArgs& a, bool fast, int64_t tiles, int grid, hipStream_t st, bool dry) {
 #define NFMC_LB(POT, F)                                                                                         \
     {                                                                                                           \
         const size_t lds = (size_t)FlowImage<CPL, LPC, HP, (F && CPL >= 8)>::total_floats(a.flow.n_hidden_layers, \
                                                                                        a.flow.n_coupling) * sizeof(float); \
         if (lds > 120 * 1024) return NFMC_EUNSUPPORTED;                                                         \
+        if (dry) return 0;                                                                                      \
         auto kern = flow_mh_b_kernel<CPL, LPC, HP, POT, F>;                                                     \
         if (lds > 48 * 1024) {                                                                                  \
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,   \
@@ -146,7 +147,8 @@ static int launch_b(const NfmcFlowMhArgs& a, bool fast, int64_t tiles, int grid,
 }
 
 // Returns NFMC_EUNSUPPORTED when this path does not cover the request (caller falls back to flow_mh_kernel).
-int flow_mh_b_launch(const NfmcFlowMhArgs& a, hipStream_t st, int* grid_out, int* dp_out) {
+// dry: decide only, launch nothing (nfmc_flow_mh_supported_f32).
+int flow_mh_b_launch(const NfmcFlowMhArgs& a, hipStream_t st, int* grid_out, int* dp_out, bool dry) {
     const int d = a.flow.d;
     const int hp = a.flow.n_hidden <= 4 ? 4 : 8;
     if (a.flow.n_hidden > 8 || d > 512) return NFMC_EUNSUPPORTED;
@@ -181,7 +183,7 @@ int flow_mh_b_launch(const NfmcFlowMhArgs& a, hipStream_t st, int* grid_out, int
     int rc = NFMC_EUNSUPPORTED;
 #define M(CPL, LPC)                                                                      \
     if (c.cpl == CPL && c.lpc == LPC)                                                    \
-        rc = hp == 4 ? launch_b<CPL, LPC, 4>(a, fast, tiles, grid, st) : launch_b<CPL, LPC, 8>(a, fast, tiles, grid, st);
+        rc = hp == 4 ? launch_b<CPL, LPC, 4>(a, fast, tiles, grid, st, dry) : launch_b<CPL, LPC, 8>(a, fast, tiles, grid, st, dry);
     NFMC_FOR_BCFG(M)
 #undef M
     *grid_out = grid;

@@ -15,7 +15,7 @@ namespace nfmc {
 constexpr int kFlowBlock = 64;
 
 // flow_b_kernels.hip: register-layout path for narrow conditioners
-int flow_mh_b_launch(const NfmcFlowMhArgs& a, hipStream_t st, int* grid_out, int* dp_out);
+int flow_mh_b_launch(const NfmcFlowMhArgs& a, hipStream_t st, int* grid_out, int* dp_out, bool dry);
 constexpr int kMaxSlots = 8;  // d <= 512 -> at most 8 coordinates per lane in the column-sum pass
 
 template <int HP>
@@ -261,8 +261,11 @@ static bool al16(const void* p) { return ((uintptr_t)p & 15u) == 0; }   // NULL 
 
 static int hp_bucket(int h) { return h <= 4 ? 4 : (h <= 8 ? 8 : (h <= 16 ? 16 : 32)); }
 
+constexpr size_t kMaxLdsBytes = 160 * 1024;   // per workgroup on gfx950
+
 template <class K>
 static int set_lds(K kernel, size_t bytes) {
+    if (bytes > kMaxLdsBytes) return NFMC_EUNSUPPORTED;   // the wave tile(s) of this d do not fit the LDS
     if (bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         if (e != hipSuccess) return (int)e;
@@ -351,9 +354,7 @@ extern "C" int nfmc_realnvp_inverse_f32(const NfmcRealNVP* flow, const float* z,
     return NFMC_OK;
 }
 
-extern "C" int nfmc_flow_mh_steps_f32(const NfmcFlowMhArgs* args, nfmc_stream_t stream) {
-    if (!args) return NFMC_EINVAL;
-    NfmcFlowMhArgs a = *args;
+static int check_flow_mh(const NfmcFlowMhArgs& a) {
     int rc = check_flow(&a.flow);
     if (rc) return rc;
     if (!a.x || !a.logq || a.n <= 0 || a.n_steps <= 0) return NFMC_EINVAL;
@@ -361,11 +362,33 @@ extern "C" int nfmc_flow_mh_steps_f32(const NfmcFlowMhArgs* args, nfmc_stream_t 
     if (a.pot.kind != NFMC_POT_QUADRATIC && a.pot.kind != NFMC_POT_FUNNEL) return NFMC_EUNSUPPORTED;
     if (a.stats.sum_x && (!a.stats.sum_x2 || !a.stats.counters || !a.stats.scratch)) return NFMC_EINVAL;
     if (a.adjusted && (a.rng.replay_normals != nullptr) != (a.rng.replay_uniforms != nullptr)) return NFMC_EINVAL;
+    return NFMC_OK;
+}
+
+static size_t flow_mh_tile_lds(const NfmcRealNVP& f) { return (size_t)2 * 64 * tile_stride(f.d) * sizeof(float) + hbuf_bytes(f.n_hidden); }
+
+extern "C" int nfmc_flow_mh_supported_f32(const NfmcFlowMhArgs* args) {
+    if (!args) return NFMC_EINVAL;
+    const NfmcFlowMhArgs& a = *args;
+    int rc = check_flow_mh(a);
+    if (rc) return rc;
+    int grid = 0, dp = 0;
+    rc = (getenv("NFMC_FLOW_TILE_PATH") || a.flow.n_bins != 0) ? NFMC_EUNSUPPORTED : flow_mh_b_launch(a, nullptr, &grid, &dp, true);
+    if (rc != NFMC_EUNSUPPORTED) return rc;
+    if (use_mfma_flow(&a.flow) && al16(a.x) && al16(a.samples)) return NFMC_OK;
+    return flow_mh_tile_lds(a.flow) <= kMaxLdsBytes ? NFMC_OK : NFMC_EUNSUPPORTED;
+}
+
+extern "C" int nfmc_flow_mh_steps_f32(const NfmcFlowMhArgs* args, nfmc_stream_t stream) {
+    if (!args) return NFMC_EINVAL;
+    NfmcFlowMhArgs a = *args;
+    int rc = check_flow_mh(a);
+    if (rc) return rc;
     const int d = a.flow.d;
     int dp = padded_d(d);
     hipStream_t st = (hipStream_t)stream;
     int grid = 0;
-    rc = (getenv("NFMC_FLOW_TILE_PATH") || a.flow.n_bins != 0) ? NFMC_EUNSUPPORTED : flow_mh_b_launch(a, st, &grid, &dp);
+    rc = (getenv("NFMC_FLOW_TILE_PATH") || a.flow.n_bins != 0) ? NFMC_EUNSUPPORTED : flow_mh_b_launch(a, st, &grid, &dp, false);
     if (rc == NFMC_EUNSUPPORTED && use_mfma_flow(&a.flow) && al16(a.x) && al16(a.samples)) {
         // wide conditioners at d = 64 / 128 (16-byte aligned rows): matrix cores
         rc = nfmc_flow_mh_steps_mfma_f32(a, stream, &grid, &dp);
@@ -377,7 +400,7 @@ extern "C" int nfmc_flow_mh_steps_f32(const NfmcFlowMhArgs* args, nfmc_stream_t 
         if (a.stats.sum_x && a.stats.scratch_bytes < (int64_t)grid * (2 * dp + kStatTail) * (int64_t)sizeof(double))
             return NFMC_ESCRATCH;
         if (check_defer(a.stats, dp, d)) return NFMC_EINVAL;
-        const size_t lds = (size_t)2 * 64 * tile_stride(d) * sizeof(float) + hbuf_bytes(a.flow.n_hidden);
+        const size_t lds = flow_mh_tile_lds(a.flow);
         NFMC_HP_DISPATCH(nfmc_realnvp_padded_hidden(a.flow.n_hidden), {
             if ((rc = set_lds(flow_mh_kernel<HP>, lds))) return rc;
             hipLaunchKernelGGL((flow_mh_kernel<HP>), dim3(grid), dim3(kFlowBlock), lds, st, a, tiles, dp);

@@ -259,10 +259,7 @@ static const PCfg kPCfgs[] = {{4, 1}, {4, 2}, {4, 4}, {4, 8}, {8, 8}, {8, 16}, {
 #define NFMC_FOR_PCFG(M) M(4, 1) M(4, 2) M(4, 4) M(4, 8) M(8, 8) M(8, 16) M(8, 32) M(8, 64)
 
 template <int CPL, int LPC, int HP>
-static int launch_imh(const NfmcFlowMhArgs& a, const ImhWork& w, hipStream_t st, int* grid_c, int* dp_out) {
-    // sized for the generic image; the exact-fit kernels use (and are launched with) half of it
-    if ((size_t)FlowImage<CPL, LPC, HP>::total_floats(a.flow.n_hidden_layers, a.flow.n_coupling) * sizeof(float) > 120 * 1024)
-        return NFMC_EUNSUPPORTED;
+static int launch_imh(const NfmcFlowMhArgs& a, const ImhWork& w, hipStream_t st, int* grid_c, int* dp_out, bool dry) {
     const int64_t total_a = a.n * (int64_t)a.n_steps, total_c = total_a + a.n;
     const int64_t tiles_a = (total_a + kWavesPerBlock * kWave - 1) / (kWavesPerBlock * kWave);   // 64 rows per wave and tile
     const int64_t tiles_c = (total_c + kWavesPerBlock * kWave - 1) / (kWavesPerBlock * kWave);   // 64 rows per wave look
@@ -275,6 +272,8 @@ static int launch_imh(const NfmcFlowMhArgs& a, const ImhWork& w, hipStream_t st,
     {                                                                                                             \
         const size_t lds = (size_t)FlowImage<CPL, LPC, HP, (F && CPL >= 8)>::total_floats(a.flow.n_hidden_layers,  \
                                                                                        a.flow.n_coupling) * sizeof(float); \
+        if (lds > 120 * 1024) return NFMC_EUNSUPPORTED;                                                           \
+        if (dry) return 0;                                                                                        \
         auto ka = imh_eval_kernel<CPL, LPC, HP, POT, F>;                                                          \
         auto kc = imh_replay_kernel<CPL, LPC, HP, POT, F>;                                                        \
         if (lds > 48 * 1024) {                                                                                    \
@@ -311,8 +310,20 @@ extern "C" int64_t nfmc_imh_parallel_work_bytes(int64_t n, int32_t d, int32_t n_
     return imh_work_floats(n, d, n_steps) * 4 + 64;
 }
 
+static int imh_parallel_run(const NfmcFlowMhArgs* args, void* work, int64_t work_bytes, nfmc_stream_t stream, bool dry);
+
 extern "C" int nfmc_imh_parallel_f32(const NfmcFlowMhArgs* args, void* work, int64_t work_bytes, nfmc_stream_t stream) {
-    if (!args || !work) return NFMC_EINVAL;
+    if (!work) return NFMC_EINVAL;
+    return imh_parallel_run(args, work, work_bytes, stream, false);
+}
+
+// NFMC_OK when nfmc_imh_parallel_f32 has a kernel for `args` (validates, launches nothing), else the error it would return
+extern "C" int nfmc_imh_parallel_supported_f32(const NfmcFlowMhArgs* args) {
+    return imh_parallel_run(args, nullptr, 0, nullptr, true);
+}
+
+static int imh_parallel_run(const NfmcFlowMhArgs* args, void* work, int64_t work_bytes, nfmc_stream_t stream, bool dry) {
+    if (!args) return NFMC_EINVAL;
     NfmcFlowMhArgs a = *args;
     const NfmcRealNVP& f = a.flow;
     if (!a.x || !a.logq || a.n <= 0 || a.n_steps <= 0 || !a.adjusted) return NFMC_EINVAL;
@@ -323,7 +334,7 @@ extern "C" int nfmc_imh_parallel_f32(const NfmcFlowMhArgs* args, void* work, int
     if (a.stats.sum_x && (!a.stats.sum_x2 || !a.stats.counters || !a.stats.scratch)) return NFMC_EINVAL;
     if (a.stats.sum_x && a.stats.defer && a.stats.tail_slot != 0) return NFMC_EINVAL;
     if ((a.rng.replay_normals != nullptr) != (a.rng.replay_uniforms != nullptr)) return NFMC_EINVAL;
-    if (work_bytes < nfmc_imh_parallel_work_bytes(a.n, f.d, a.n_steps)) return NFMC_ESCRATCH;
+    if (!dry && work_bytes < nfmc_imh_parallel_work_bytes(a.n, f.d, a.n_steps)) return NFMC_ESCRATCH;
     hipStream_t st = (hipStream_t)stream;
     const int64_t kn = a.n * (int64_t)a.n_steps;
     ImhWork w;
@@ -335,12 +346,14 @@ extern "C" int nfmc_imh_parallel_f32(const NfmcFlowMhArgs* args, void* work, int
     w.last = w.dwell0 + a.n;
     w.x0 = (float*)(w.last + a.n);
     w.x0 += (4 - ((4 * kn + 2 * a.n) & 3)) & 3;   // keep the copy of the states 16-byte aligned (vector IO)
-    if (!a.logq_cached) {   // flow.log_prob(x0): imh.py:214
-        const int rc = nfmc_realnvp_forward_f32(&f, a.x, a.n, nullptr, nullptr, a.logq, stream);
-        if (rc) return rc;
+    if (!dry) {
+        if (!a.logq_cached) {   // flow.log_prob(x0): imh.py:214
+            const int rc = nfmc_realnvp_forward_f32(&f, a.x, a.n, nullptr, nullptr, a.logq, stream);
+            if (rc) return rc;
+        }
+        hipError_t e = hipMemcpyAsync(w.x0, a.x, (size_t)a.n * f.d * sizeof(float), hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return (int)e;
     }
-    hipError_t e = hipMemcpyAsync(w.x0, a.x, (size_t)a.n * f.d * sizeof(float), hipMemcpyDeviceToDevice, st);
-    if (e != hipSuccess) return (int)e;
     const int d = f.d, hp = f.n_hidden <= 4 ? 4 : 8;
     PCfg c = {0, 0};
     for (const PCfg& k : kPCfgs) {   // smallest capacity; CPL = 4 first (more lanes per row for small batches)
@@ -351,10 +364,10 @@ extern "C" int nfmc_imh_parallel_f32(const NfmcFlowMhArgs* args, void* work, int
     int rc = NFMC_EUNSUPPORTED, grid = 0, dp = 0;
 #define M(CPL, LPC)                   \
     if (c.cpl == CPL && c.lpc == LPC) \
-        rc = hp == 4 ? launch_imh<CPL, LPC, 4>(a, w, st, &grid, &dp) : launch_imh<CPL, LPC, 8>(a, w, st, &grid, &dp);
+        rc = hp == 4 ? launch_imh<CPL, LPC, 4>(a, w, st, &grid, &dp, dry) : launch_imh<CPL, LPC, 8>(a, w, st, &grid, &dp, dry);
     NFMC_FOR_PCFG(M)
 #undef M
-    if (rc) return rc;
+    if (rc || dry) return rc;
     NFMC_HIP_CHECK_LAUNCH();
     if (a.stats.sum_x && !a.stats.defer) {
         hipLaunchKernelGGL(stats_finish_kernel<true>, dim3(stats_finish_grid(dp)), dim3(kFinishBlock), 0, st, a.stats.scratch, grid, dp, d,

@@ -103,6 +103,8 @@ SYMBOLS = [
     ('nfmc_realnvp_inverse_f32', C.c_int, [C.POINTER(NfmcRealNVP), c_fp, C.c_int64, c_fp, c_fp, c_fp,
                                            C.POINTER(NfmcRng), c_fp]),
     ('nfmc_flow_mh_steps_f32', C.c_int, [C.POINTER(NfmcFlowMhArgs), c_fp]),
+    ('nfmc_flow_mh_supported_f32', C.c_int, [C.POINTER(NfmcFlowMhArgs)]),
+    ('nfmc_imh_parallel_supported_f32', C.c_int, [C.POINTER(NfmcFlowMhArgs)]),
     ('nfmc_imh_parallel_work_bytes', C.c_int64, [C.c_int64, C.c_int32, C.c_int32]),
     ('nfmc_imh_parallel_f32', C.c_int, [C.POINTER(NfmcFlowMhArgs), c_fp, C.c_int64, c_fp]),
     ('nfmc_neutra_scratch_bytes', C.c_int64, [C.c_int64, C.c_int32, C.c_int32]),

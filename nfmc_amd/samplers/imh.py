@@ -13,7 +13,8 @@ from tqdm import tqdm
 from .. import hip
 from ..containers import MCMCOutput, NFMCKernel, NFMCParameters, Sampler
 from .common import Run, chunks, resolve_target
-from .jump import flow_is_native, imh_parallel_ok, launch_flow_mh, launch_imh_parallel, split_flow_mh
+from .jump import (flow_is_native, flow_mh_supported, imh_parallel_ok, launch_flow_mh, launch_imh_parallel,
+                   split_flow_mh)
 
 
 @dataclass
@@ -81,11 +82,12 @@ class FixedIMH(AbstractIMH):
         fused = pot is not None and flow_is_native(flow)
         buf = torch.empty(T, n, d, dtype=torch.float32, device=run.dev) if (self.params.store_samples and T > 0) else None
         logq = torch.empty(n, dtype=torch.float32, device=run.dev)
+        fused = fused and flow_mh_supported(run, flow, pot, logq)
         t0 = time.time()
         done = 0
         unlimited = time_limit_seconds is None and not show_progress
         limit = hip.MAX_STEPS_PER_CALL if unlimited else 16
-        parallel = fused and imh_parallel_ok(run, flow)
+        parallel = fused and imh_parallel_ok(run, flow, pot, logq)
         bar = tqdm(total=T, desc=self.name, disable=not show_progress)
         if not fused:
             logq.copy_(flow.log_prob(run.x.reshape(n, *event_shape)).detach().to(run.dev, torch.float32))  # imh.py:214
@@ -199,6 +201,7 @@ class AdaptiveIMH(AbstractIMH):
         host = HostDraws(run.shard, *(self.host_draws or (None, None)))
         buf = torch.empty(max(T, 1), n, d, dtype=torch.float32, device=run.dev)
         logq = torch.empty(n, dtype=torch.float32, device=run.dev)
+        fused = fused and flow_mh_supported(run, flow, pot, logq)
         t0 = time.time()
         done, n_refits = 0, 0
         bar = tqdm(total=T, desc=self.name, disable=not show_progress)

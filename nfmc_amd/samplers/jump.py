@@ -102,6 +102,14 @@ def make_jump_tail(run: Run, flow, adjusted):
     return t
 
 
+def flow_mh_supported(run: Run, flow, pot, logq, adjusted=True) -> bool:
+    """Whether nfmc_flow_mh_steps_f32 has a kernel for this flow / shape (nfmc_flow_mh_supported_f32).  When it has
+    not (e.g. ragged d > ~300: neither the weight image nor the wave tiles fit the LDS) the samplers compose the
+    transition from the flow's own kernels (split_flow_mh), like for a foreign flow object."""
+    a, _keep = _flow_mh_probe_args(run, flow, pot, logq, adjusted)
+    return _supported(int(hip.lib().nfmc_flow_mh_supported_f32(C.byref(a))), 'nfmc_flow_mh_supported_f32')
+
+
 def launch_flow_mh(run: Run, flow, pot, logq, k, step0, cached, adjusted, stats_struct, samples=None,
                    masks_out=None, log_ratio_out=None):
     a = hip.NfmcFlowMhArgs()
@@ -120,28 +128,38 @@ def launch_flow_mh(run: Run, flow, pot, logq, k, step0, cached, adjusted, stats_
         hip.check(hip.lib().nfmc_flow_mh_steps_f32(C.byref(a), hip.stream()), 'nfmc_flow_mh_steps_f32')
 
 
-def imh_parallel_ok(run: Run, flow) -> bool:
-    """FixedIMH as a data-parallel problem (csrc/imh_parallel.hip): register-layout flows only.  It wins most when the
-    chains alone do not fill the GPU (sequential transitions are latency-bound there), and still by 10-15 % when they
-    do.  NFMC_IMH_PARALLEL=0/1 overrides."""
+def _flow_mh_probe_args(run: Run, flow, pot, logq, adjusted):
+    a = hip.NfmcFlowMhArgs()
+    st, _keep = flow.bijection.packed(run.dev)
+    a.x, a.logq, a.n, a.n_steps = hip.ptr(run.x), hip.ptr(logq), run.n, 1
+    a.adjusted = 1 if adjusted else 0
+    a.flow = st
+    a.pot = pot.descriptor(run.dev)
+    a.rng = hip.make_rng(run.seed, run.chain_offset, 0)
+    a.stats = hip.null_stats()
+    return a, _keep
+
+
+def _supported(rc, what) -> bool:
+    if rc == hip.EUNSUPPORTED:
+        return False
+    hip.check(rc, what)
+    return True
+
+
+def imh_parallel_ok(run: Run, flow, pot, logq) -> bool:
+    """FixedIMH as a data-parallel problem (csrc/imh_parallel.hip): register-layout flows whose weight image fits the
+    LDS (nfmc_imh_parallel_supported_f32 decides).  It wins most when the chains alone do not fill the GPU (sequential
+    transitions are latency-bound there), and still by 10-15 % when they do.  NFMC_IMH_PARALLEL=0 turns it off."""
     bij = getattr(flow, 'bijection', None)
     if not flow_is_native(flow) or bij.n_hidden > 8 or bij.n_bins != 0 or bij.d > 512:
         return False
-    # the register-layout kernels keep every layer's weight image in LDS (flow_b.hpp: FlowImage): deep flows do not fit
-    hp = 4 if bij.n_hidden <= 4 else 8
-    dp = 4
-    while dp < bij.d:
-        dp *= 2
-    hl = hp * (hp + 4)   # flow_b.hpp FlowImage::HL, distributed form (an upper bound of the other)
-    image_floats = bij.n_coupling * (dp * hp + hp + (bij.n_hidden_layers - 1) * hl + dp * (2 * hp + 4)) + 4 * dp
-    if image_floats * 4 > 120 * 1024:
-        return False
-    env = os.environ.get('NFMC_IMH_PARALLEL')
-    if env is not None:
-        return env == '1'
     # d = 64, 1000 steps, parallel vs sequential: 1.0 vs 3.0 ms at n = 1000, 1.98 vs 3.0 at 8192, 5.7 vs 6.7 at 32768,
     # 10.6 vs 12.3 at 65536 (one accept-uniform draw per row instead of per lane, no per-step select / moments)
-    return True
+    if os.environ.get('NFMC_IMH_PARALLEL') == '0':
+        return False
+    a, _keep = _flow_mh_probe_args(run, flow, pot, logq, True)
+    return _supported(int(hip.lib().nfmc_imh_parallel_supported_f32(C.byref(a))), 'nfmc_imh_parallel_supported_f32')
 
 
 def launch_imh_parallel(run: Run, flow, pot, logq, k, step0, cached, stats_struct, samples=None, masks_out=None,
@@ -274,6 +292,8 @@ class JumpNFMC(Sampler):
         buf = torch.empty(T * (K + 1), n, d, dtype=torch.float32, device=run.dev) if self.params.store_samples else None
         fit_buf = torch.empty(K, n, d, dtype=torch.float32, device=run.dev) if (self.params.fit_nf and buf is None) else None
         logq = torch.empty(n, dtype=torch.float32, device=run.dev)
+        if fused and not flow_mh_supported(run, flow, pot, logq, self.params.adjusted_jumps):
+            fused = tail_ok = False   # the jump through the flow's own kernels (split_flow_mh)
 
         t0 = time.time()
         done = 0
