@@ -144,6 +144,20 @@ def lib():
     return _lib
 
 
+class NfmcArgumentError(ValueError):
+    """A negative status of the library (`code`): ValueError is the reference's only error channel."""
+
+    def __init__(self, message, code):
+        super().__init__(message)
+        self.code = code
+
+    @property
+    def no_kernel(self):
+        """The request is valid but no kernel covers it (shape / width beyond a fused kernel): callers that have a
+        composed path take it."""
+        return self.code in (EUNSUPPORTED, ESHAPE)
+
+
 def check(rc, what):
     """Map a return code to the reference's error channels: ValueError for argument errors
     (the reference's only error type, langevin.py:111), RuntimeError for HIP errors."""
@@ -151,7 +165,7 @@ def check(rc, what):
         return
     msg = lib().nfmc_error_string(rc).decode()
     if rc < 0:
-        raise ValueError('%s: %s (code %d)' % (what, msg, rc))
+        raise NfmcArgumentError('%s: %s (code %d)' % (what, msg, rc), rc)
     raise RuntimeError('%s: HIP error %d: %s' % (what, rc, msg))
 
 

@@ -58,21 +58,31 @@ class NeuTra(Sampler):
         inner_params.n_iterations = self.params.n_iterations
         self.inner_sampler = inner_sampler_class(event_shape, self.adjusted_target, inner_kernel, inner_params)
         self.inner_sampler.fuse = False  # adjusted_target is a Python closure; the fused route is sample() below
+        self._grad_kernel_ok = True
 
     def adjusted_target(self, _z, return_data: bool = False):
         """neutra.py:58-68 through the flow's API (split path and external callers)."""
         n = _z.shape[0]
         dev = hip.require_gpu()
         grad_needed = torch.is_grad_enabled() and _z.requires_grad
-        if grad_needed and getattr(self.kernel.flow.bijection, 'n_bins', 0):
-            # spline couplings have no reverse-sweep kernel: differentiate the torch restatement of the flow
+        if grad_needed and not getattr(self.kernel.flow.bijection, 'n_bins', 0) and self._grad_kernel_ok:
+            try:
+                return _AdjustedPotential.apply(_z, self)
+            except hip.NfmcArgumentError as e:
+                if not e.no_kernel:
+                    raise
+                self._grad_kernel_ok = False   # e.g. d > ~200 (three wave tiles exceed the LDS), H > 32 off the MFMA shapes
+        if grad_needed:
+            # spline couplings / shapes without a reverse-sweep kernel: differentiate the torch restatement of the
+            # flow (on the GPU; the target is the user's callable)
             from ..flow_training import inverse_torch
-            x, log_det_inverse = inverse_torch(self.kernel.flow.bijection, _z.to(dev, torch.float32))
+            flow = self.kernel.flow
+            if flow.get_device() != dev:
+                flow.to(dev)
+            x, log_det_inverse = inverse_torch(flow.bijection, _z.to(dev, torch.float32))
             x = x.reshape(n, *self.event_shape)
             adjusted_potential = self.target(x).reshape(-1) - log_det_inverse.reshape(-1)
             return (adjusted_potential, x) if return_data else adjusted_potential
-        if grad_needed:
-            return _AdjustedPotential.apply(_z, self)
         x, log_det_inverse = self.kernel.flow.bijection.inverse(_z)
         log_prob = -self.target(x)
         adjusted_potential = -(log_prob.reshape(-1) + log_det_inverse.to(log_prob).reshape(-1))
@@ -126,12 +136,16 @@ class NeuTra(Sampler):
         run = Run(self, x0)
         n, d, event_shape = run.n, run.d, run.event_shape
         pot = resolve_target(self.target, event_shape)
-        if not isinstance(inner, HMC) or pot is None or getattr(self.kernel.flow.bijection, 'n_bins', 0):
-            # NeuTraMH / arbitrary targets: the inner sampler's split path on the adjusted target (neutra.py:116-127)
+        def split():
+            # NeuTraMH / arbitrary targets / shapes without a fused kernel: the inner sampler's split path on the
+            # adjusted target (neutra.py:116-127)
             inner.seed, inner.shard, inner.replay = self.seed, self.shard, self.replay
             out = inner.sample(x0, show_progress=show_progress, time_limit_seconds=time_limit_seconds)
             out.kernel.flow = self.kernel.flow
             return out
+
+        if not isinstance(inner, HMC) or pot is None or getattr(self.kernel.flow.bijection, 'n_bins', 0):
+            return split()
         out = MCMCOutput(event_shape, store_samples=self.params.store_samples)
         T = int(self.params.n_iterations)
         buf = torch.empty(T, n, d, dtype=torch.float32, device=run.dev) if (self.params.store_samples and T > 0) else None
@@ -162,7 +176,13 @@ class NeuTra(Sampler):
             a.stats = run.stats.struct()
             a.samples = hip.ptr(buf[done:done + k]) if buf is not None else None
             a.scratch, a.scratch_bytes = hip.ptr(scratch), sbytes
-            hip.check(hip.lib().nfmc_neutra_hmc_steps_f32(C.byref(a), hip.stream()), 'nfmc_neutra_hmc_steps_f32')
+            try:
+                hip.check(hip.lib().nfmc_neutra_hmc_steps_f32(C.byref(a), hip.stream()), 'nfmc_neutra_hmc_steps_f32')
+            except hip.NfmcArgumentError as e:
+                if done == 0 and e.no_kernel:   # validation precedes every launch: nothing has run yet
+                    bar.close()
+                    return split()
+                raise
             done += k
             bar.update(k)
         bar.close()

@@ -1321,3 +1321,54 @@ def test_register_flow_metropolis_matches_oracle_in_every_layout(dev, d, nh, cl,
     follows = agree[-1] & (got_m[-1] == want_m[-1])
     np.testing.assert_allclose(samples[-1].cpu().numpy()[follows], tr.samples[-1].numpy()[follows], atol=3e-5 * max(1.0, d / 64))
     assert want_m.any() or d >= 100   # small flows are close enough to the target for acceptances to happen
+
+
+@pytest.mark.parametrize('d,ck,kind', [(200, {}, 'realnvp'), (24, {'n_hidden': 40}, 'realnvp'), (10, {}, 'c-rqnsf')])
+def test_neutra_hmc_shapes_without_a_fused_kernel_match_oracle(dev, d, ck, kind):
+    """NeuTra HMC where nfmc_neutra_hmc_steps_f32 has no kernel (d > ~156: four wave tiles exceed the LDS; conditioners
+    wider than 32 off the matrix-core shapes; spline couplings): the sampler composes the transition from the inner
+    HMC's split path on the adjusted target -- same Philox streams as the fused kernel, so the oracle still applies."""
+    from nfmc_amd.samplers import neutra, mcmc
+    from nfmc_amd.flows import Flow, RealNVP, CRQNSF
+    from nfmc_amd.potentials import SumOfSquares
+    from oracle import flow as oflow, potentials as opot, samplers as osamp
+    n, T, L, h = 40, 3, 3, 0.05
+    torch.manual_seed(d)
+    ocls, cls = (oflow.CRQNSF, CRQNSF) if kind == 'c-rqnsf' else (oflow.RealNVP, RealNVP)
+    of = oflow.perturb_(oflow.Flow(ocls((d,), conditioner_kwargs=ck)), 9, 0.2)
+    f = Flow(cls((d,), conditioner_kwargs=ck))
+    f.load_state_dict(of.state_dict())
+    z0 = 0.5 * torch.randn(n, d)
+    s = neutra.NeuTraHMC((d,), SumOfSquares((d,)), mcmc.HMCKernel(event_size=d, n_leapfrog_steps=L, step_size=h),
+                         mcmc.HMCParameters(), neutra.NeuTraKernel((d,), flow=f), neutra.NeuTraParameters(n_iterations=T))
+    s.seed = 78
+    out = s.sample(z0, show_progress=False)
+    tr = osamp.neutra_hmc_sample(z0, opot.sum_squares, of, T, h, None, L, noise=osamp.PhiloxNoise(78))
+    got, want = out.samples.reshape(T, n, d), tr.stacked()
+    same = (got - want).abs().amax(dim=(0, 2)) < 5e-4
+    assert same.float().mean() > 0.9, float(same.float().mean())
+    assert out.statistics.n_attempted_trajectories == n * T
+    assert abs(out.statistics.n_accepted_trajectories - tr.n_accepted) <= 4
+
+
+@pytest.mark.parametrize('strategy', ['jump_mala', 'jump_hmc', 'jump_mh', 'imh', 'adaptive_imh', 'neutra_hmc', 'neutra_mh'])
+def test_every_flow_strategy_runs_on_awkward_shapes(dev, strategy):
+    """Event sizes around every tile / layout boundary (2 ... 511, odd, ragged), each flow kind, a conditioner width off
+    the matrix-core shapes: whichever kernel (fused, register, tile, matrix-core, composed) serves the shape, the call
+    returns finite samples of the right shape.  Flows stop at d = 512: one more is the reference's ValueError."""
+    from nfmc_amd import sample
+    from nfmc_amd.potentials import SumOfSquares
+    kw = {}
+    if strategy.startswith('jump'):
+        kw = dict(inner_param_kwargs={'n_iterations': 3})
+    elif strategy == 'neutra_hmc':
+        kw = dict(inner_kernel_kwargs={'n_leapfrog_steps': 2})
+    wide = 'realnvp%{"conditioner_kwargs":{"n_hidden":40}}'
+    cases = [(d, 'realnvp') for d in (2, 3, 5, 31, 65, 129, 257, 300, 511, 512)]
+    cases += [(d, fl) for d in (5, 65, 300) for fl in ('nice', 'c-rqnsf', wide)]
+    for d, fl in cases:
+        torch.manual_seed(0)
+        out = sample(SumOfSquares((d,)), strategy=strategy, flow=fl, n_chains=37, n_iterations=3, show_progress=False, **kw)
+        assert out.samples.shape[1:] == (37, d) and torch.isfinite(out.samples).all(), (strategy, d, fl)
+    with pytest.raises(ValueError, match='supported range'):
+        sample(SumOfSquares((513,)), strategy=strategy, flow='realnvp', n_chains=8, n_iterations=2, show_progress=False, **kw)
