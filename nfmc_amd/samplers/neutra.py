@@ -65,7 +65,8 @@ class NeuTra(Sampler):
         n = _z.shape[0]
         dev = hip.require_gpu()
         grad_needed = torch.is_grad_enabled() and _z.requires_grad
-        if grad_needed and not getattr(self.kernel.flow.bijection, 'n_bins', 0) and self._grad_kernel_ok:
+        if (grad_needed and not getattr(self.kernel.flow.bijection, 'n_bins', 0) and self._grad_kernel_ok
+                and self._closed_form() is not None):
             try:
                 return _AdjustedPotential.apply(_z, self)
             except hip.NfmcArgumentError as e:
@@ -96,13 +97,17 @@ class NeuTra(Sampler):
               and os.environ.get('NFMC_NEUTRA_VALU', '0') != '1')
         return 64 if ok else 0
 
+    def _closed_form(self):
+        """The target as a closed-form potential descriptor (None: an arbitrary callable, differentiated by autograd)."""
+        if getattr(self, '_pot_cache', None) is None or self._pot_cache[0] is not self.target:
+            self._pot_cache = (self.target, resolve_target(self.target, self.event_shape))
+        return self._pot_cache[1]
+
     def _potential_grad(self, z):
         """U~(z), grad U~(z) from nfmc_neutra_potential_grad_f32 (closed-form targets only)."""
         dev = hip.require_gpu()
         n = z.shape[0]
-        if getattr(self, '_pot_cache', None) is None or self._pot_cache[0] is not self.target:
-            self._pot_cache = (self.target, resolve_target(self.target, self.event_shape))
-        pot = self._pot_cache[1]
+        pot = self._closed_form()
         if pot is None:
             raise ValueError('NeuTra needs a closed-form potential (nfmc_amd.potentials) for the gradient kernel')
         zf = z.detach().to(dev, torch.float32).reshape(n, -1).contiguous()

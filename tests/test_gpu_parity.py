@@ -1372,3 +1372,31 @@ def test_every_flow_strategy_runs_on_awkward_shapes(dev, strategy):
         assert out.samples.shape[1:] == (37, d) and torch.isfinite(out.samples).all(), (strategy, d, fl)
     with pytest.raises(ValueError, match='supported range'):
         sample(SumOfSquares((513,)), strategy=strategy, flow='realnvp', n_chains=8, n_iterations=2, show_progress=False, **kw)
+
+
+def test_neutra_hmc_with_an_arbitrary_callable_target_matches_oracle(dev):
+    """neutra.py:58-68 with a target the library has no closed form for (a two-mode mixture): the adjusted potential is
+    differentiated by autograd through the torch restatement of the flow; momenta and accept uniforms are the fused
+    kernel's Philox streams."""
+    from nfmc_amd.samplers import neutra, mcmc
+    from nfmc_amd.flows import Flow, RealNVP
+    from oracle import flow as oflow, samplers as osamp
+
+    def target(x):
+        c = torch.tensor([-2.0, 2.0], device=x.device)
+        return -torch.logsumexp(-0.5 * (x.unsqueeze(-1) - c) ** 2, dim=-1).sum(-1)
+
+    d, n, T, L, h = 6, 48, 3, 4, 0.1
+    torch.manual_seed(5)
+    of = oflow.perturb_(oflow.Flow(oflow.RealNVP((d,))), 4, 0.2)
+    f = Flow(RealNVP((d,)))
+    f.load_state_dict(of.state_dict())
+    z0 = torch.randn(n, d)
+    s = neutra.NeuTraHMC((d,), target, mcmc.HMCKernel(event_size=d, n_leapfrog_steps=L, step_size=h),
+                         mcmc.HMCParameters(), neutra.NeuTraKernel((d,), flow=f), neutra.NeuTraParameters(n_iterations=T))
+    s.seed = 79
+    out = s.sample(z0, show_progress=False)
+    tr = osamp.neutra_hmc_sample(z0, target, of, T, h, None, L, noise=osamp.PhiloxNoise(79))
+    same = (out.samples.reshape(T, n, d) - tr.stacked()).abs().amax(dim=(0, 2)) < 5e-4
+    assert same.float().mean() > 0.9, float(same.float().mean())
+    assert abs(out.statistics.n_accepted_trajectories - tr.n_accepted) <= 3
