@@ -1400,3 +1400,42 @@ def test_neutra_hmc_with_an_arbitrary_callable_target_matches_oracle(dev):
     same = (out.samples.reshape(T, n, d) - tr.stacked()).abs().amax(dim=(0, 2)) < 5e-4
     assert same.float().mean() > 0.9, float(same.float().mean())
     assert abs(out.statistics.n_accepted_trajectories - tr.n_accepted) <= 3
+
+
+def test_edge_every_entry_point_rejects_null_and_zeroed_arguments(dev):
+    """Each C-ABI entry point called with NULL / zero-initialised arguments returns a negative status (the caller's
+    ValueError) -- it neither launches nor dereferences anything."""
+    from nfmc_amd import hip
+    L, st = hip.lib(), hip.stream()
+    z = lambda cls: C.byref(cls())
+    calls = {
+        'mala': lambda: L.nfmc_mala_steps_f32(z(hip.NfmcMalaArgs), st),
+        'hmc': lambda: L.nfmc_hmc_steps_f32(z(hip.NfmcHmcArgs), st),
+        'forward': lambda: L.nfmc_realnvp_forward_f32(z(hip.NfmcRealNVP), None, 4, None, None, None, st),
+        'inverse': lambda: L.nfmc_realnvp_inverse_f32(z(hip.NfmcRealNVP), None, 4, None, None, None, None, st),
+        'flow_mh': lambda: L.nfmc_flow_mh_steps_f32(z(hip.NfmcFlowMhArgs), st),
+        'flow_mh_supported': lambda: L.nfmc_flow_mh_supported_f32(z(hip.NfmcFlowMhArgs)),
+        'imh_parallel_supported': lambda: L.nfmc_imh_parallel_supported_f32(z(hip.NfmcFlowMhArgs)),
+        'imh_parallel': lambda: L.nfmc_imh_parallel_f32(z(hip.NfmcFlowMhArgs), None, 0, st),
+        'neutra_hmc': lambda: L.nfmc_neutra_hmc_steps_f32(z(hip.NfmcNeutraHmcArgs), st),
+        'neutra_grad': lambda: L.nfmc_neutra_potential_grad_f32(z(hip.NfmcRealNVP), z(hip.NfmcPotential), None, 4, None, None, st),
+        'select': lambda: L.nfmc_mh_accept_select_f32(z(hip.NfmcSelectArgs), st),
+        'langevin_propose': lambda: L.nfmc_langevin_propose_f32(None, None, None, 0.1, 4, 8, z(hip.NfmcRng), None, st),
+        'langevin_log_ratio': lambda: L.nfmc_langevin_log_ratio_f32(None, None, None, None, None, None, None, 0.1, 4, 8, None, st),
+        'moments': lambda: L.nfmc_moments_update_f32(None, 4, 8, z(hip.NfmcStats), st),
+        'stats_fold': lambda: L.nfmc_stats_fold_f32(z(hip.NfmcStats), 8, 0, None, 0, st),
+        'normals': lambda: L.nfmc_philox_normals_f32(z(hip.NfmcRng), hip.TAG_NOISE, 4, 8, None, st),
+        'uniforms': lambda: L.nfmc_philox_uniforms_f32(z(hip.NfmcRng), hip.TAG_ACCEPT, 4, None, st),
+        'limits': lambda: L.nfmc_limits(None),
+    }
+    for name, call in calls.items():
+        rc = int(call())
+        assert rc < 0, (name, rc)
+        with pytest.raises(ValueError):
+            hip.check(rc, name)
+    for name in ('mala', 'hmc', 'flow_mh', 'neutra_hmc', 'select', 'imh_parallel'):   # NULL struct pointers
+        fn = {'mala': L.nfmc_mala_steps_f32, 'hmc': L.nfmc_hmc_steps_f32, 'flow_mh': L.nfmc_flow_mh_steps_f32,
+              'neutra_hmc': L.nfmc_neutra_hmc_steps_f32, 'select': L.nfmc_mh_accept_select_f32}.get(name)
+        rc = int(fn(None, st)) if fn else int(L.nfmc_imh_parallel_f32(None, None, 0, st))
+        assert rc < 0, (name, rc)
+    torch.cuda.synchronize()
