@@ -1439,3 +1439,35 @@ def test_edge_every_entry_point_rejects_null_and_zeroed_arguments(dev):
         rc = int(fn(None, st)) if fn else int(L.nfmc_imh_parallel_f32(None, None, 0, st))
         assert rc < 0, (name, rc)
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize('strategy', ['hmc', 'mh', 'imh', 'jump_mala', 'jump_hmc', 'neutra_hmc', 'neutra_mh'])
+def test_sharded_chains_equal_single_run_for_every_strategy(dev, strategy, monkeypatch):
+    """noise keyed by the GLOBAL chain id -- three ranks' blocks of chains are bit for bit the rows of the
+    single-process run (sequential flow-MH here; the data-parallel IMH has its own bitwise test against it)."""
+    from nfmc_amd.sample import create_sampler
+    from nfmc_amd.potentials import SumOfSquares
+    from nfmc_amd.dist import Shard
+    monkeypatch.setenv('NFMC_IMH_PARALLEL', '0' if strategy == 'imh' else '1')
+    d, n = 16, 301
+    x0 = torch.randn(n, d, generator=torch.Generator().manual_seed(3))
+
+    def make():
+        torch.manual_seed(11)   # same flow weights in every "process"
+        kw = {}
+        if strategy.startswith('jump'):
+            kw = dict(inner_param_kwargs={'n_iterations': 4})
+        elif strategy == 'neutra_hmc':
+            kw = dict(inner_kernel_kwargs={'n_leapfrog_steps': 3})
+        s = create_sampler(SumOfSquares((d,)), strategy=strategy, flow='realnvp', param_kwargs={'n_iterations': 5}, **kw)
+        s.seed = 9
+        return s
+
+    full = make().sample(x0, show_progress=False).running_samples.last_sample
+    parts = []
+    for r in range(3):
+        s = make()
+        s.shard = Shard(rank=r, world=3)
+        s.shard.merge_statistics = lambda st: st
+        parts.append(s.sample(x0, show_progress=False).running_samples.last_sample)
+    assert torch.equal(torch.cat(parts), full)
