@@ -127,6 +127,8 @@ def sample(target: Union[callable, Potential],
         event_shape = flow.event_shape
     elif isinstance(target, Potential):
         event_shape = target.event_shape
+    if event_shape is None and x0 is not None:
+        event_shape = tuple(x0.shape[1:])   # (the reference fails on `*None` here)
     seed = kwargs.pop('seed', None)
     shard = kwargs.pop('shard', None)
     if 'param_kwargs' not in kwargs:

@@ -1471,3 +1471,26 @@ def test_sharded_chains_equal_single_run_for_every_strategy(dev, strategy, monke
         s.shard.merge_statistics = lambda st: st
         parts.append(s.sample(x0, show_progress=False).running_samples.last_sample)
     assert torch.equal(torch.cat(parts), full)
+
+
+def test_edge_state_with_more_than_2_to_31_elements(dev):
+    """34 M chains x 64 coordinates (2.2e9 floats, 8.7 GB): row offsets are 64-bit everywhere -- the last chains move
+    like the first ones, and the moments cover all of them."""
+    from nfmc_amd import sample
+    from nfmc_amd.potentials import SumOfSquares
+    n, d = 34_000_000, 64
+    x0 = torch.randn(n, d, device=dev) * 0.7071
+    for strategy, kw in (('mala', {}), ('jump_mala', {'inner_param_kwargs': {'n_iterations': 2}}), ('imh', {})):
+        out = sample(SumOfSquares((d,)), strategy=strategy, x0=x0, n_iterations=2, show_progress=False,
+                     param_kwargs={'store_samples': False}, seed=1, **kw)
+        last = out.running_samples.last_sample
+        assert last.shape == (n, d)
+        moved_head = (last[:1000].to(dev) != x0[:1000]).any(dim=1).float().mean()
+        moved_tail = (last[-1000:].to(dev) != x0[-1000:]).any(dim=1).float().mean()
+        if strategy != 'imh':   # the unfitted flow's independence proposals are almost never accepted
+            assert moved_head > 0.2 and moved_tail > 0.2, (strategy, float(moved_head), float(moved_tail))
+        assert abs(float(out.variance.mean()) - 0.5) < 5e-3
+        del out, last
+    x2 = torch.randn(50, 4, 4, device=dev)
+    out = sample(lambda x: (x ** 2).flatten(1).sum(1), strategy='hmc', x0=x2, n_iterations=2, show_progress=False)
+    assert out.samples.shape == (2, 50, 4, 4)   # event shape taken from x0
