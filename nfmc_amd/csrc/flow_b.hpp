@@ -34,8 +34,8 @@ namespace nfmc {
 //   W1 (DP x HP): row s = W1T[logical j] if the slot's coordinate is a SOURCE of this layer, else 0
 //   b1 HP | [WhT HP x HP | bh HP] x (n_hl - 1)                                   (LPC < HP)
 //   b1 HP | [HP rows of HP + 4: row u = weights INTO unit u, position r = from unit u ^ unit_xor(r) | bh[u] | 0 0 0] x (n_hl - 1)
-//   W3 (DP x RS): row s = [alpha weights HP | beta weights HP | b3_alpha | b3_beta | is_target | 0] (zeros if not target);
-//       distributed: weight position r belongs to hidden unit (g % HP) ^ unit_xor(r)
+//   W3 (DP x RS): row s = [(alpha weight, beta weight) x HP | b3_alpha | b3_beta | is_target | 0] (zeros if not target);
+//       distributed: pair r belongs to hidden unit (g % HP) ^ unit_xor(r)
 // followed, after all layers, by the ElementwiseAffine parameters per slot:
 //   ea0_ls | ea0_sh | ea1_ls | ea1_sh   (DP each; ea1 already mapped through the final reversal)
 // EXACT (d == DP, CPL >= 8): a layer's sources are one half of every lane's registers and its targets the other
@@ -83,8 +83,8 @@ struct FlowImage {
                 for (int k = 0; k < HP; ++k) {
                     const int kk = DIST ? (ub ^ unit_xor<HP>(k)) : k;
                     r1[k] = src ? w1[k] : 0.f;
-                    r3[k] = tgt ? wa[kk] : 0.f;
-                    r3[HP + k] = tgt ? wb[kk] : 0.f;
+                    r3[2 * k] = tgt ? wa[kk] : 0.f;
+                    r3[2 * k + 1] = tgt ? wb[kk] : 0.f;
                 }
                 r3[2 * HP] = tgt ? b3[tt] : 0.f;
                 r3[2 * HP + 1] = tgt ? b3[d_b + tt] : 0.f;
@@ -155,6 +155,14 @@ __device__ __forceinline__ void load_row16(float (&w)[N], const float* __restric
     }
 }
 
+// Two multiply-adds per instruction (v_pk_fma_f32, 1.25x the issue cost of one v_fma): (a.x, a.y) * b + (c.x, c.y).
+// The operands are register PAIRS as the 128-bit LDS reads deliver them, so no moves are needed to form them: the
+// image interleaves what is consumed together (hidden units k, k+1 of one source coordinate; the alpha and beta
+// weights of one target coordinate).  Left to itself the compiler packs across two target coordinates and spends the
+// gain on v_mov (20 % of the output-layer instructions).
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 pk_fma(f2 a, float b, f2 c) { return __builtin_elementwise_fma(a, (f2){b, b}, c); }
+
 template <int CPL, int LPC, int HP, bool LEAN = false, bool EXACT = false>
 struct FlowB {
     using Img = FlowImage<CPL, LPC, HP, EXACT>;
@@ -192,15 +200,23 @@ struct FlowB {
         // redundant form cost 24 (HP = 4) / 80 (HP = 8) SGPRs per layer and measured 3-5 % slower at both widths.
         const float* b1 = img + l * lf + Img::ROWS * HP;
         float h[HP];
+        {
+            f2 hh[HP / 2];
 #pragma unroll
-        for (int k = 0; k < HP; ++k) h[k] = 0.f;
+            for (int k = 0; k < HP / 2; ++k) hh[k] = (f2){0.f, 0.f};
 #pragma unroll
-        for (int i = S0; i < S1; ++i) {  // generic path: zero rows for coordinates that are not sources of this layer
-            float w[HP];
-            load_row16<HP>(w, W1 + (i - S0) * LPC * HP);
+            for (int i = S0; i < S1; ++i) {  // generic path: zero rows for coordinates that are not sources of this layer
+                float w[HP];
+                load_row16<HP>(w, W1 + (i - S0) * LPC * HP);
 #pragma unroll
-            for (int k = 0; k < HP; ++k) h[k] = fmaf(w[k], x[i], h[k]);
-            if constexpr (LEAN) __builtin_amdgcn_sched_barrier(0);
+                for (int k = 0; k < HP / 2; ++k) hh[k] = pk_fma((f2){w[2 * k], w[2 * k + 1]}, x[i], hh[k]);
+                if constexpr (LEAN) __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int k = 0; k < HP / 2; ++k) {
+                h[2 * k] = hh[k].x;
+                h[2 * k + 1] = hh[k].y;
+            }
         }
         if constexpr (Img::DIST) {
             const int ub = g & (HP - 1);
@@ -247,12 +263,10 @@ struct FlowB {
         for (int i = T0; i < T1; ++i) {
             float w[Img::RS];
             load_row16<Img::RS>(w, W3 + (i - T0) * LPC * Img::RS);
-            float ua = w[2 * HP], ub = w[2 * HP + 1];
+            f2 uab = {w[2 * HP], w[2 * HP + 1]};   // (alpha, beta) pre-activations, advanced together
 #pragma unroll
-            for (int k = 0; k < HP; ++k) {
-                ua = fmaf(w[k], h[k], ua);
-                ub = fmaf(w[HP + k], h[k], ub);
-            }
+            for (int k = 0; k < HP; ++k) uab = pk_fma((f2){w[2 * k], w[2 * k + 1]}, h[k], uab);
+            const float ua = uab.x, ub = uab.y;
             // generic path: pass-through and padding coordinates (flag 0) stay bitwise unchanged
             const float alpha = (EXACT || w[2 * HP + 2] != 0.f) ? fast_exp(fmaf(0.5f, ua, log1m)) + m : 1.f;
             const float beta = 0.5f * ub;
