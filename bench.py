@@ -140,6 +140,12 @@ def main():
             dist.barrier()
         return time.perf_counter() - t0, out
 
+    # one-time initialisation outside the timed region whatever W is: library load, code-object load of the two
+    # kernels (first launch), packing of the flow weights -- a 256-chain, one-step run of the same path
+    prime = build_sampler(1)
+    prime.seed = 0
+    prime.sample(x0[:256], show_progress=False)
+    torch.cuda.synchronize(dev)
     if args.warmup > 0:
         run(args.warmup)
     # HIP events only around the dominant kernel's launches: every event pair costs ~6 us of stream time
