@@ -1,59 +1,77 @@
-"""Kernel / parameter dataclasses and the result containers of the path, name-for-name with
-nfmc/algorithms/sampling/base.py, re-designed for a device-resident run:
+"""Host-side containers of a device-resident run.  The public names and attributes are the ones callers of
+nfmc/algorithms/sampling/base.py use (so results read the same), the implementation is this package's own:
 
-* `MCMCStatistics` keeps fp64 per-coordinate sums and integer counters that the HIP kernels accumulate
-  on the GPU (hip.DeviceStats); `running_first_moment`, `running_second_moment`, `acceptance_rate`
-  are derived on access.  The streaming formula of `MCMCExpectation.update` (base.py:88-95) equals the
-  plain mean over everything seen, which is what sums / n_seen gives.
-* `MCMCSamples` stores kept states in one pre-sized device tensor written by the kernels, with the
-  thinning / max_samples / last_sample semantics of base.py:234-263; `.as_tensor()` hands back a CPU
-  tensor like the reference (`as_device_tensor()` avoids the copy).
+* moments are fp64 per-coordinate SUMS that the HIP kernels accumulate on the GPU (hip.DeviceStats) plus a count;
+  `running_first_moment` etc. divide on access.  The reference's streaming update (base.py:88-95) is the plain mean
+  over everything seen, which is what sum / count gives (tests/test_host_cpu.py checks the two against each other).
+* counters live in one table per statistics class (`COUNTERS`), so `update_counters`, `as_dict` and the multi-GPU
+  merge (dist.Shard.merge_statistics) are generic over them; subclasses extend the table (jump counters).
+* kept states are slabs `(k, n_chains, *event)` that the kernels write straight into device memory, one slab per
+  launch; thinning / `max_samples` / `last_sample` follow base.py:234-263; the only device-to-host copy happens
+  when `.samples` is read (`samples_device` avoids it).
 """
-from dataclasses import dataclass, field
-from typing import Any, Dict, List, Optional, Tuple, Union
+import math
+from dataclasses import dataclass
+from typing import Any, Callable, Dict, List, Optional, Sequence
 
 import torch
 
 
+def _shape(event_shape) -> tuple:
+    return tuple(int(s) for s in event_shape)
+
+
+# ------------------------------------------------------------------------------------------------ kernels / parameters
 @dataclass
 class MCMCKernel:
-    def __repr__(self):
-        raise NotImplementedError
+    """State a sampler tunes and returns with its output (`MCMCOutput.kernel`)."""
 
-    def __post_init__(self):
-        pass
+    def __post_init__(self):   # subclasses chain through here
+        return None
+
+    def __repr__(self):
+        raise NotImplementedError('kernels describe themselves')
 
 
 @dataclass
 class NFMCKernel(MCMCKernel):
-    event_shape: Union[Tuple[int, ...], torch.Size]
-    flow: Any = None
+    event_shape: Sequence[int]
+    flow: Any = None   # duck-typed: anything with the Flow methods; default: this package's RealNVP
 
     def __post_init__(self):
         super().__post_init__()
-        if self.flow is None:  # base.py:24-26
-            from .flows import Flow, RealNVP
-            self.flow = Flow(RealNVP(self.event_shape))
+        if self.flow is not None:
+            return
+        from .flows import Flow, RealNVP
+        self.flow = Flow(RealNVP(self.event_shape))
 
     def __repr__(self):
-        return f'NFMCKernel(event_shape={tuple(self.event_shape)})'
+        return 'NFMCKernel(event_shape=%s)' % (_shape(self.event_shape),)
 
 
 @dataclass
 class MCMCParameters:
     n_iterations: int = 100
     n_warmup_iterations: int = 100
-    tuning: bool = False
+    tuning: bool = False          # True while warmup adapts the kernel
     store_samples: bool = True
 
     def __post_init__(self):
-        pass
+        return None
+
+    def _set_tuning(self, flag: bool):
+        self.tuning = bool(flag)
 
     def tuning_mode(self):
-        self.tuning = True
+        self._set_tuning(True)
 
     def sampling_mode(self):
-        self.tuning = False
+        self._set_tuning(False)
+
+
+# defaults of the refit inside a run (base.py:46-61): short, early-stopped, quiet
+_REFIT_DEFAULTS = (('early_stopping', True), ('early_stopping_threshold', 50), ('batch_size', 'adaptive'),
+                   ('show_progress', False))
 
 
 @dataclass
@@ -61,116 +79,116 @@ class NFMCParameters(MCMCParameters):
     train_pct: float = 0.7
     max_train_size: int = 4096
     max_val_size: int = 4096
-    flow_fit_kwargs: Dict[str, Any] = None
+    flow_fit_kwargs: Optional[Dict[str, Any]] = None
 
     def __post_init__(self):
         super().__post_init__()
         if self.flow_fit_kwargs is None:
-            self.flow_fit_kwargs = {
-                'early_stopping': True,
-                'early_stopping_threshold': 50,
-                'batch_size': 'adaptive',
-                'show_progress': False
-            }
+            self.flow_fit_kwargs = dict(_REFIT_DEFAULTS)
 
 
+# ------------------------------------------------------------------------------------------------ moments
 class MCMCExpectation:
-    """E[f(x)] over everything seen, from a running fp64 sum (f = identity or square)."""
+    """E[x^power] per coordinate over every (step, chain) seen: an fp64 sum and a count."""
 
     def __init__(self, event_shape, power: int):
-        self.event_shape = tuple(event_shape)
-        self.power = power
-        self.n_seen = 0
-        self.total = torch.zeros(self.event_shape, dtype=torch.float64)
+        self.event_shape = _shape(event_shape)
+        self.power = int(power)
+        self.reset()
 
-    def update(self, x: torch.Tensor):
-        if x.dim() == len(self.event_shape) + 1:
-            x = x[None]
-        elif x.dim() != len(self.event_shape) + 2:
-            raise ValueError
-        v = x.detach().to('cpu', torch.float64)
-        self.total = self.total + (v ** self.power).sum(dim=(0, 1))
-        self.n_seen += x.shape[0] * x.shape[1]
+    def reset(self):
+        self.total = torch.zeros(self.event_shape, dtype=torch.float64)
+        self.n_seen = 0
 
     def add_sums(self, total: torch.Tensor, n_new: int):
+        """Sums the kernels accumulated over `n_new` (step, chain) pairs."""
         self.total = self.total + total.detach().to('cpu', torch.float64).reshape(self.event_shape)
         self.n_seen += int(n_new)
 
-    def reset(self):
-        self.n_seen = 0
-        self.total = torch.zeros(self.event_shape, dtype=torch.float64)
+    def update(self, x: torch.Tensor):
+        """Host-side path: x is (n_chains, *event) or (n_steps, n_chains, *event)."""
+        lead = x.dim() - len(self.event_shape)
+        if lead not in (1, 2):
+            raise ValueError('expected (n_chains, *event) or (n_steps, n_chains, *event), got %s' % (tuple(x.shape),))
+        rows = x.detach().to('cpu', torch.float64).reshape(-1, *self.event_shape)
+        self.add_sums(rows.pow(self.power).sum(dim=0), rows.shape[0])
 
-    @property
-    def running_value(self):
-        return self.as_tensor()
-
-    def as_tensor(self):
-        if self.n_seen == 0:
+    def as_tensor(self) -> torch.Tensor:
+        if not self.n_seen:
             return torch.zeros(self.event_shape)
         return (self.total / self.n_seen).float()
 
+    running_value = property(as_tensor)
+
 
 class MCMCExpectationDict:
-    def __init__(self, expectations: Dict[str, MCMCExpectation], data_transform=lambda v: v):
+    """Named expectations fed from the same (optionally transformed) states."""
+
+    def __init__(self, expectations: Dict[str, MCMCExpectation], data_transform: Callable = None):
         self.expectations = expectations
-        self.data_transform = data_transform
+        self.data_transform = data_transform if data_transform is not None else (lambda v: v)
+
+    def __getitem__(self, name):
+        return self.expectations[name]
 
     def update(self, x: torch.Tensor):
-        xt = self.data_transform(x)
-        for e in self.expectations.values():
-            e.update(xt)
+        seen = self.data_transform(x)
+        for member in self.expectations.values():
+            member.update(seen)
 
     def reset(self):
-        for e in self.expectations.values():
-            e.reset()
+        for member in self.expectations.values():
+            member.reset()
 
-    def as_tensor(self):
-        return {k: v.as_tensor() for k, v in self.expectations.items()}
+    def as_tensor(self) -> Dict[str, torch.Tensor]:
+        return {name: member.as_tensor() for name, member in self.expectations.items()}
 
-    def __getitem__(self, key):
-        return self.expectations[key]
+
+def _rate(numerator, denominator):
+    return numerator / denominator if denominator > 0 else math.nan
 
 
 @dataclass
 class MCMCStatistics:
-    event_shape: Union[Tuple[int, ...], torch.Size]
+    event_shape: Sequence[int]
     n_accepted_trajectories: Optional[int] = 0
     n_attempted_trajectories: Optional[int] = 0
     n_divergences: Optional[int] = 0
     n_target_gradient_calls: Optional[int] = 0
     n_target_calls: Optional[int] = 0
     elapsed_time_seconds: Optional[float] = 0.0
-    n_nonfinite_log_ratios: int = 0  # chains whose log acceptance ratio was NaN/inf (rejected, langevin.py:106)
-
+    n_nonfinite_log_ratios: int = 0   # transitions whose log acceptance ratio was NaN / inf: rejected (langevin.py:106)
     data_transform: Any = None
     expectations: MCMCExpectationDict = None
 
+    # integer counters `update_counters` accepts and `as_dict` reports; subclasses extend the tuple
+    COUNTERS = ('n_accepted_trajectories', 'n_attempted_trajectories', 'n_divergences', 'n_target_gradient_calls',
+                'n_target_calls')
+
     def __post_init__(self):
-        self.event_shape = tuple(self.event_shape)
+        self.event_shape = _shape(self.event_shape)
         if self.data_transform is None:
             self.data_transform = lambda v: v
-        # the reference builds the dict with the identity transform and never rebinds it (App. C #1)
-        self.expectations = MCMCExpectationDict({
-            'first_moment': MCMCExpectation(self.event_shape, 1),
-            'second_moment': MCMCExpectation(self.event_shape, 2),
-        })
+        # moments of the UNtransformed state, like the reference, whose dict never sees a transform (SURVEY App. C #1)
+        self.expectations = MCMCExpectationDict({name: MCMCExpectation(self.event_shape, power)
+                                                 for name, power in (('first_moment', 1), ('second_moment', 2))})
 
-    def update_counters(self, n_accepted_trajectories: int = 0, n_attempted_trajectories: int = 0,
-                        n_divergences: int = 0, n_target_gradient_calls: int = 0, n_target_calls: int = 0):
-        self.n_accepted_trajectories = int(self.n_accepted_trajectories + n_accepted_trajectories)
-        self.n_attempted_trajectories = int(self.n_attempted_trajectories + n_attempted_trajectories)
-        self.n_divergences = int(self.n_divergences + n_divergences)
-        self.n_target_gradient_calls = int(self.n_target_gradient_calls + n_target_gradient_calls)
-        self.n_target_calls = int(self.n_target_calls + n_target_calls)
+    # -- accumulation
+    def update_counters(self, **increments):
+        for name, inc in increments.items():
+            if name not in self.COUNTERS:
+                raise TypeError('unknown counter %r' % name)
+            setattr(self, name, int(getattr(self, name) + inc))
 
     def update_elapsed_time(self, delta_time_seconds: float):
-        self.elapsed_time_seconds = float(self.elapsed_time_seconds + delta_time_seconds)
+        self.elapsed_time_seconds = float(self.elapsed_time_seconds) + float(delta_time_seconds)
 
     def absorb_device_sums(self, sum_x: torch.Tensor, sum_x2: torch.Tensor, n_new: int):
-        """Fold kernel-accumulated sums (hip.DeviceStats) into the expectations."""
-        self.expectations['first_moment'].add_sums(sum_x, n_new)
-        self.expectations['second_moment'].add_sums(sum_x2, n_new)
+        """Per-coordinate sums of x and x^2 over `n_new` (step, chain) pairs, from hip.DeviceStats."""
+        for name, total in (('first_moment', sum_x), ('second_moment', sum_x2)):
+            self.expectations[name].add_sums(total, n_new)
 
+    # -- derived quantities
     @property
     def running_first_moment(self):
         return self.expectations['first_moment'].as_tensor()
@@ -181,111 +199,98 @@ class MCMCStatistics:
 
     @property
     def running_variance(self):
-        return self.running_second_moment - self.running_first_moment ** 2
+        mean = self.running_first_moment
+        return self.running_second_moment - mean * mean
 
     @property
     def acceptance_rate(self):
-        if self.n_attempted_trajectories == 0:
-            return torch.nan
-        return self.n_accepted_trajectories / self.n_attempted_trajectories
+        return _rate(self.n_accepted_trajectories, self.n_attempted_trajectories)
 
     @property
     def calls_per_second(self):
-        if self.elapsed_time_seconds > 0:
-            return self.n_target_calls / self.elapsed_time_seconds
-        return torch.nan
+        return _rate(self.n_target_calls, self.elapsed_time_seconds)
 
     @property
     def grads_per_second(self):
-        if self.elapsed_time_seconds > 0:
-            return self.n_target_gradient_calls / self.elapsed_time_seconds
-        return torch.nan
+        return _rate(self.n_target_gradient_calls, self.elapsed_time_seconds)
+
+    RATES = ('grads_per_second', 'acceptance_rate', 'calls_per_second')
+
+    def as_dict(self) -> Dict[str, Any]:
+        names = self.COUNTERS + ('elapsed_time_seconds',) + self.RATES
+        return {name: getattr(self, name) for name in names}
+
+    def _summary(self):
+        return [('acc-rate', '%.2f' % self.acceptance_rate), ('kcalls/s', '%.2f' % (self.calls_per_second / 1000)),
+                ('kgrads/s', '%.2f' % (self.grads_per_second / 1000)), ('divergences', str(self.n_divergences))]
 
     def __repr__(self):
-        return (f"acc-rate: {self.acceptance_rate:.2f}, "
-                f"kcalls/s: {self.calls_per_second / 1000:.2f}, "
-                f"kgrads/s: {self.grads_per_second / 1000:.2f}, "
-                f"divergences: {self.n_divergences}")
-
-    def as_dict(self):
-        return {
-            'n_accepted_trajectories': self.n_accepted_trajectories,
-            'n_attempted_trajectories': self.n_attempted_trajectories,
-            'n_divergences': self.n_divergences,
-            'n_target_gradient_calls': self.n_target_gradient_calls,
-            'n_target_calls': self.n_target_calls,
-            'elapsed_time_seconds': self.elapsed_time_seconds,
-            'grads_per_second': self.grads_per_second,
-            'acceptance_rate': self.acceptance_rate,
-            'calls_per_second': self.calls_per_second,
-        }
+        return ', '.join('%s: %s' % pair for pair in self._summary())
 
 
+# ------------------------------------------------------------------------------------------------ kept states
 class MCMCSamples:
-    """Kept states `(n_kept, n_chains, *event_shape)`; semantics of base.py:215-271.
-
-    The samplers let the kernels write every step of a launch straight into a device buffer `(k, n, d)` and
-    `add` it once per launch; rows stay on the device (`as_device_tensor`) until `.samples` is read, which is the
-    only device-to-host copy (the reference does one `.cpu()` per step, base.py:257).
-    """
+    """States kept from a run, `(n_kept, n_chains, *event_shape)`."""
 
     def __init__(self, event_shape, store_samples: bool = True, thinning: int = 1, max_samples: int = None):
-        self.event_shape = tuple(event_shape)
+        self.event_shape = _shape(event_shape)
         self.store_samples = store_samples
         self.thinning = thinning
         self.max_samples = max_samples
         self.reset()
 
     def reset(self):
-        self._chunks: List[torch.Tensor] = []  # each (k, n, *event)
-        self.n_samples = 0
-        self.seen_samples = 0
-        self.last_sample = None
+        self._slabs: List[torch.Tensor] = []   # device tensors (k, n_chains, *event), in order
+        self.n_samples = 0                      # rows kept
+        self.seen_samples = 0                   # rows offered (thinning counts these)
+        self.last_sample = None                 # newest state, kept even when nothing is stored
 
-    def __getitem__(self, index):
-        if index == -1 or index == self.n_samples - 1:
-            return self.last_sample
-        return self.as_device_tensor()[index]
+    def _as_steps(self, x: torch.Tensor) -> torch.Tensor:
+        lead = x.dim() - len(self.event_shape)
+        if lead in (1, 2) and tuple(x.shape[lead:]) == self.event_shape:
+            return x if lead == 2 else x.unsqueeze(0)
+        raise ValueError('states must be (n_chains, *%s) or (n_steps, n_chains, *%s), got %s'
+                         % (self.event_shape, self.event_shape, tuple(x.shape)))
 
     def add(self, x: torch.Tensor):
-        nd = len(self.event_shape)
-        if x.dim() == nd + 1 and tuple(x.shape[1:]) == self.event_shape:
-            x = x[None]
-        elif x.dim() == nd + 2 and tuple(x.shape[2:]) == self.event_shape:
-            pass
-        else:
-            raise ValueError(f"Expected x.shape[1:] or x.shape[2:] to be {self.event_shape}, got {x.shape = }")
-        self.last_sample = x[-1].detach().clone()
+        steps = self._as_steps(x).detach()
+        self.last_sample = steps[-1].clone()
         if not self.store_samples:
             return
-        idx = torch.arange(self.seen_samples, self.seen_samples + len(x))
-        keep = (idx % self.thinning) == 0
-        self.seen_samples += len(x)
-        kept = x.detach()[keep.to(x.device)] if self.thinning != 1 else x.detach()
-        if len(kept):
-            self._chunks.append(kept)
-            self.n_samples += len(kept)
+        first = self.seen_samples
+        self.seen_samples += len(steps)
+        if self.thinning != 1:
+            offset = (-first) % self.thinning          # first offered row whose global index is kept
+            steps = steps[offset::self.thinning]
+        if len(steps):
+            self._slabs.append(steps)
+            self.n_samples += len(steps)
         if self.max_samples is not None and self.n_samples > self.max_samples:
-            full = torch.cat(self._chunks, dim=0)[-self.max_samples:]
-            self._chunks = [full]
-            self.n_samples = len(full)
+            newest = self.as_device_tensor()[-self.max_samples:]
+            self._slabs, self.n_samples = [newest], len(newest)
 
     def as_device_tensor(self) -> torch.Tensor:
-        if not self._chunks:   # nothing kept yet (n_iterations = 0): an empty (0, n_chains, *event) tensor
-            if self.last_sample is not None:
-                return self.last_sample.new_empty((0,) + tuple(self.last_sample.shape))
+        if len(self._slabs) > 1:
+            self._slabs = [torch.cat(self._slabs, dim=0)]
+        if self._slabs:
+            return self._slabs[0]
+        # nothing kept (e.g. n_iterations = 0): an empty stack over the chains seen so far
+        if self.last_sample is None:
             return torch.empty((0, 0) + self.event_shape)
-        if len(self._chunks) > 1:
-            self._chunks = [torch.cat(self._chunks, dim=0)]
-        return self._chunks[0]
+        return self.last_sample.new_empty((0,) + tuple(self.last_sample.shape))
 
     def as_tensor(self) -> torch.Tensor:
         return self.as_device_tensor().cpu()
 
+    def __getitem__(self, index):
+        if index in (-1, self.n_samples - 1):
+            return self.last_sample
+        return self.as_device_tensor()[index]
+
 
 @dataclass
 class MCMCOutput:
-    event_shape: Union[Tuple[int, ...], torch.Size]
+    event_shape: Sequence[int]
     running_samples: MCMCSamples = None
     statistics: Optional[MCMCStatistics] = None
     kernel: Optional[MCMCKernel] = None
@@ -293,59 +298,61 @@ class MCMCOutput:
     max_samples: int = None
 
     def __post_init__(self):
-        self.event_shape = tuple(self.event_shape)
+        self.event_shape = _shape(self.event_shape)
+        if self.statistics is None:
+            self.statistics = MCMCStatistics(self.event_shape)
         if self.running_samples is None:
             self.running_samples = MCMCSamples(self.event_shape, store_samples=self.store_samples,
                                                max_samples=self.max_samples)
-        if self.statistics is None:
-            self.statistics = MCMCStatistics(self.event_shape)
 
-    @property
-    def samples(self) -> Union[torch.Tensor, None]:
+    def _kept(self, on_device: bool):
         if not self.store_samples:
             return None
-        return self.running_samples.as_tensor()
+        store = self.running_samples
+        return store.as_device_tensor() if on_device else store.as_tensor()
 
     @property
-    def samples_device(self) -> Union[torch.Tensor, None]:
-        if not self.store_samples:
-            return None
-        return self.running_samples.as_device_tensor()
+    def samples(self) -> Optional[torch.Tensor]:
+        """(n_kept, n_chains, *event) on the host, or None when the run did not store samples."""
+        return self._kept(False)
+
+    @property
+    def samples_device(self) -> Optional[torch.Tensor]:
+        return self._kept(True)
 
     def resample(self, n: int) -> torch.Tensor:
-        flat = self.samples.flatten(0, 1)
-        mask = torch.randint(low=0, high=len(flat), size=(n,))
-        return flat[mask]
+        """n draws with replacement from all kept (step, chain) states."""
+        pool = self.samples.flatten(0, 1)
+        return pool[torch.randint(len(pool), (n,))]
 
     @property
     def mean(self):
         return self.statistics.running_first_moment
 
     @property
-    def variance(self):
-        return self.statistics.running_second_moment - self.statistics.running_first_moment ** 2
-
-    @property
     def second_moment(self):
         return self.statistics.running_second_moment
 
+    @property
+    def variance(self):
+        return self.statistics.running_variance
 
+
+# ------------------------------------------------------------------------------------------------ sampler protocol
 class Sampler:
-    """Sampler protocol of base.py:317-348: `.warmup(x0, ...)` / `.sample(x0, ...)` -> MCMCOutput."""
+    """`.warmup(x0, ...)` / `.sample(x0, ...)` -> MCMCOutput (the protocol `sample()` drives, base.py:317-348)."""
+
+    name = 'Generic sampler'
 
     def __init__(self, event_shape, target, kernel: MCMCKernel, params: MCMCParameters):
-        self.event_shape = tuple(event_shape)
+        self.event_shape = _shape(event_shape)
+        self.event_size = math.prod(self.event_shape)
         self.target = target
         self.kernel = kernel
         self.params = params
-        self.event_size = int(torch.prod(torch.as_tensor(self.event_shape)))
-        self.seed = None          # native-stream seed; None -> drawn from torch's global RNG per sample() call
-        self.shard = None         # dist.Shard when chains are split over GPUs
-        self.replay = None        # ReplayNoise-like object for parity tests (see samplers/common.py)
-
-    @property
-    def name(self):
-        return "Generic sampler"
+        self.seed = None      # native-stream seed; None: drawn from torch's global RNG per sample() call
+        self.shard = None     # dist.Shard when the chains are split over GPUs
+        self.replay = None    # (normals, uniforms) to replay instead of the native streams (parity tests)
 
     def warmup(self, x0, show_progress: bool = True, time_limit_seconds=None) -> MCMCOutput:
         raise NotImplementedError

@@ -4,6 +4,7 @@ the fused inner kernel (K transitions, state in registers) and `nfmc_flow_mh_ste
 (flow.sample + flow.log_prob + 2 target calls + MH test + masked update + moments in one kernel).
 """
 import ctypes as C
+import math
 import os
 import time
 from copy import deepcopy
@@ -47,26 +48,16 @@ class JumpNFMCStatistics(MCMCStatistics):
     n_accepted_jumps: int = 0
     n_attempted_jumps: int = 0
 
+    COUNTERS = MCMCStatistics.COUNTERS + ('n_accepted_jumps', 'n_attempted_jumps')
+    RATES = MCMCStatistics.RATES + ('jump_acceptance_rate',)
+
     @property
     def jump_acceptance_rate(self):
-        if self.n_attempted_jumps == 0:
-            return torch.nan
-        return self.n_accepted_jumps / self.n_attempted_jumps
+        return self.n_accepted_jumps / self.n_attempted_jumps if self.n_attempted_jumps else math.nan
 
-    def update_counters(self, n_accepted_jumps: int = 0, n_attempted_jumps: int = 0, **kwargs):
-        super().update_counters(**kwargs)
-        self.n_accepted_jumps = int(self.n_accepted_jumps + n_accepted_jumps)
-        self.n_attempted_jumps = int(self.n_attempted_jumps + n_attempted_jumps)
-
-    def __repr__(self):
-        return (f"MCMC acc-rate: {self.acceptance_rate:.2f}, "
-                f"Jump acc-rate: {self.jump_acceptance_rate:.2f}, "
-                f"kcalls/s: {self.calls_per_second / 1000:.2f}, "
-                f"kgrads/s: {self.grads_per_second / 1000:.2f}, "
-                f"divergences: {self.n_divergences}")
-
-    def as_dict(self):
-        return {**super().as_dict(), 'jump_acceptance_rate': self.jump_acceptance_rate}
+    def _summary(self):
+        rows = super()._summary()
+        return [('MCMC acc-rate', rows[0][1]), ('Jump acc-rate', '%.2f' % self.jump_acceptance_rate)] + rows[1:]
 
 
 class JumpNFMCOutput(MCMCOutput):

@@ -1,4 +1,5 @@
-"""Step-size dual averaging and the refit-buffer split (nfmc/algorithms/sampling/tuning.py)."""
+"""Warmup helpers next to the hot path: the step-size controller and the refit-buffer split
+(what nfmc/algorithms/sampling/tuning.py provides to the samplers)."""
 import math
 from dataclasses import dataclass
 
@@ -7,52 +8,64 @@ import torch
 
 @dataclass
 class DualAveragingParams:
+    """Constants of the controller; the defaults are the reference's (tuning.py:8-12)."""
     target_acceptance_rate: float = 0.651
-    kappa: float = 0.75
-    gamma: float = 0.05
-    t0: int = 10
+    kappa: float = 0.75    # decay exponent of the averaging weight t^-kappa
+    gamma: float = 0.05    # shrinkage towards the anchor log(10 h0)
+    t0: int = 10           # iteration count the schedule starts from
 
 
 class DualAveraging:
-    """tuning.py:15-41: log-step dual averaging driven by (target - observed) acceptance."""
+    """Nesterov dual averaging of log(step size), driven by `step(target_rate - observed_rate)`.
+
+    State: the running sum E of the errors fed so far and the iteration count t (starting at t0).
+      raw      log h_t   = log(10 h0) - E / (gamma sqrt(t))
+      smoothed log hbar  <- w log h_t + (1 - w) log hbar,   w = t^-kappa
+    `value` is exp(log hbar), the step size the sampler uses next (same recurrences, constants and update order
+    as tuning.py:15-41: `test_mala_warmup_tuning_golden` replays the reference's tuned step sizes through it)."""
 
     def __init__(self, initial_step_size, params: DualAveragingParams):
-        self.t = params.t0
+        self.params = params
+        self.iteration = int(params.t0)
         self.error_sum = 0.0
-        self.log_step_averaged = math.log(initial_step_size)
-        self.log_step = math.inf
-        self.mu = math.log(10 * initial_step_size)
-        self.p = params
+        self.anchor = math.log(10 * initial_step_size)
+        self.log_raw = math.inf                          # no raw estimate before the first error
+        self.log_smooth = math.log(initial_step_size)
 
     def step(self, acceptance_rate_error):
+        p, t = self.params, self.iteration
         self.error_sum += float(acceptance_rate_error)
-        self.log_step = self.mu - self.error_sum / (math.sqrt(self.t) * self.p.gamma)
-        eta = self.t ** -self.p.kappa
-        self.log_step_averaged = eta * self.log_step + (1 - eta) * self.log_step_averaged
-        self.t += 1
+        self.log_raw = self.anchor - self.error_sum / (math.sqrt(t) * p.gamma)
+        weight = t ** -p.kappa
+        self.log_smooth = weight * self.log_raw + (1 - weight) * self.log_smooth
+        self.iteration = t + 1
 
     @property
-    def value(self):
-        return math.exp(self.log_step_averaged)
+    def value(self) -> float:
+        return math.exp(self.log_smooth)
 
     def __repr__(self):
-        return f'DA error: {self.error_sum:.2f}'
+        return 'DualAveraging(step=%.4g, error_sum=%.2f, t=%d)' % (self.value, self.error_sum, self.iteration)
+
+
+def _shuffled(rows: torch.Tensor) -> torch.Tensor:
+    return rows[torch.randperm(rows.shape[0], device=rows.device)]
 
 
 def train_val_split(x: torch.Tensor, train_pct: float, max_train_size: int, max_val_size: int, shuffle: bool = True,
                     shard=None):
-    """tuning.py:44-65.  x: (n_iterations, n_chains, *event).  With `shard` (chains split over GPUs) every
-    rank contributes an equal share of the capped buffer and the shares are all-gathered (collective C1), so
-    each rank fits the flow on the same rows."""
+    """(n_iterations, n_chains, *event) -> (x_train, x_val): all (step, chain) rows pooled, shuffled, cut at
+    `train_pct` and capped (tuning.py:44-65).
+
+    With `shard` (chains split over GPUs) every rank contributes an equal share of the capped buffer, drawn from its
+    own shuffled rows, and the shares are all-gathered (collective C1 of SURVEY 8e): every rank then fits the flow
+    on the same rows, in rank order."""
     rows = x.flatten(0, 1)
     if shard is not None and shard.world > 1:
-        per_rank = -(-(max_train_size + max_val_size) // shard.world)
-        if shuffle:
-            rows = rows[torch.randperm(len(rows), device=rows.device)]
-        rows = shard.all_gather_rows(rows[:per_rank].contiguous())
-        shuffle = False  # already shuffled per rank; gathered order is deterministic
-    if shuffle:
-        rows = rows[torch.randperm(len(rows), device=rows.device)]
-    n_train = int(train_pct * len(rows))
-    x_train, x_val = rows[:n_train], rows[n_train:]
-    return x_train[:max_train_size], x_val[:max_val_size]
+        share = -(-(max_train_size + max_val_size) // shard.world)
+        local = _shuffled(rows) if shuffle else rows
+        rows = shard.all_gather_rows(local[:share].contiguous())
+    elif shuffle:
+        rows = _shuffled(rows)
+    cut = int(train_pct * rows.shape[0])
+    return rows[:cut][:max_train_size], rows[cut:][:max_val_size]
