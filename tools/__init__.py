@@ -1,0 +1,1 @@
+"""Measurement and tuning scripts (see tools/README.md); not part of the product path."""
