@@ -219,8 +219,27 @@ class RealNVP(nn.Module):
         n = v.shape[0]
         return dev, n, v.detach().to(dev, torch.float32).reshape(n, self.d).contiguous()
 
+    def beyond_kernels(self) -> bool:
+        """Shapes the flow kernels do not take (events wider than 512, conditioners wider than 128, 32 for splines):
+        the passes are then composed from torch ops on the GPU (flow_training.forward_torch / inverse_torch, the same
+        arithmetic the training path differentiates), so every flow strategy still runs -- through the samplers'
+        split path -- instead of raising."""
+        lim = hip.limits()
+        return self.d > lim.max_d_flow or self.n_hidden > (32 if self.n_bins else lim.max_hidden)
+
+    def _composed(self, v, inverse: bool):
+        from .flow_training import forward_torch, inverse_torch
+        dev, n, vf = self._prep(v)
+        if next(self.parameters()).device != dev:
+            self.to(dev)
+        with torch.no_grad():
+            out, ld = (inverse_torch if inverse else forward_torch)(self, vf)
+        return out.reshape(n, *self.event_shape), ld
+
     def forward(self, x):
         """x -> (z, log|det dz/dx|)  [HIP kernel nfmc_realnvp_forward_f32]."""
+        if self.beyond_kernels():
+            return self._composed(x, False)
         dev, n, xf = self._prep(x)
         st, _keep = self.packed(dev)
         z = torch.empty_like(xf)
@@ -231,6 +250,8 @@ class RealNVP(nn.Module):
 
     def inverse(self, z):
         """z -> (x, log|det dx/dz|)  [HIP kernel nfmc_realnvp_inverse_f32]."""
+        if self.beyond_kernels():
+            return self._composed(z, True)
         dev, n, zf = self._prep(z)
         st, _keep = self.packed(dev)
         x = torch.empty_like(zf)
@@ -275,7 +296,15 @@ class Flow(nn.Module):
     def get_device(self):
         return next(self.parameters()).device
 
+    @staticmethod
+    def _base_log_prob(z):
+        zf = z.flatten(1)
+        return -0.5 * (zf * zf).sum(-1) - 0.5 * zf.shape[1] * math.log(2.0 * math.pi)
+
     def log_prob(self, x):
+        if self.bijection.beyond_kernels():
+            z, ld = self.bijection.forward(x)
+            return self._base_log_prob(z) + ld
         dev, n, xf = self.bijection._prep(x)
         st, _keep = self.bijection.packed(dev)
         lp = torch.empty(n, dtype=torch.float32, device=dev)
@@ -286,12 +315,18 @@ class Flow(nn.Module):
     def sample(self, n, return_log_prob=False, no_grad=False, rng=None):
         """x ~ q (inverse pass of in-kernel z ~ N(0, I)); optionally log q(x).  `rng`: hip.NfmcRng override."""
         dev = hip.require_gpu()
-        st, _keep = self.bijection.packed(dev)
         if rng is None:
             if self.seed is None:
                 self.seed = int(torch.randint(0, 2 ** 62, ()).item())
             rng = hip.make_rng(self.seed, 0, self._sample_calls)
             self._sample_calls += 1
+        if self.bijection.beyond_kernels():   # latents from the same Philox stream the kernel would draw in place
+            z = torch.empty(n, self.bijection.d, dtype=torch.float32, device=dev)
+            hip.check(hip.lib().nfmc_philox_normals_f32(C.byref(rng), hip.TAG_LATENT, n, self.bijection.d, hip.ptr(z),
+                                                        hip.stream()), 'nfmc_philox_normals_f32')
+            x, ld = self.bijection.inverse(z)
+            return (x, self._base_log_prob(z) - ld) if return_log_prob else x
+        st, _keep = self.bijection.packed(dev)
         x = torch.empty(n, self.bijection.d, dtype=torch.float32, device=dev)
         lq = torch.empty(n, dtype=torch.float32, device=dev) if return_log_prob else None
         hip.check(hip.lib().nfmc_realnvp_inverse_f32(C.byref(st), None, n, hip.ptr(x), None, hip.ptr(lq),

@@ -16,7 +16,7 @@ from tqdm import tqdm
 
 from .. import hip
 from ..containers import MCMCKernel, MCMCOutput, MCMCParameters, MCMCStatistics, NFMCKernel, NFMCParameters, Sampler
-from ..flows import RealNVP
+from ..flows import Flow, RealNVP
 from ..tuning import train_val_split
 from ..util import metropolis_acceptance_log_ratio
 from .common import Run, chunks, resolve_target
@@ -182,7 +182,7 @@ def split_flow_mh(run: Run, flow, target, event_shape, step, adjusted, stats_str
     the GPU, test + masked update + moments in nfmc_mh_accept_select_f32."""
     n, d = run.n, run.d
     with torch.no_grad():
-        if flow_is_native(flow):
+        if flow_is_native(flow) or isinstance(flow, Flow):   # this package's flow: the run's own noise streams
             rng = hip.make_rng(run.seed, run.chain_offset, step)
             if run.replay is not None:
                 nz, un = run.replay.take(1, with_uniforms=adjusted)

@@ -1355,7 +1355,7 @@ def test_neutra_hmc_shapes_without_a_fused_kernel_match_oracle(dev, d, ck, kind)
 def test_every_flow_strategy_runs_on_awkward_shapes(dev, strategy):
     """Event sizes around every tile / layout boundary (2 ... 511, odd, ragged), each flow kind, a conditioner width off
     the matrix-core shapes: whichever kernel (fused, register, tile, matrix-core, composed) serves the shape, the call
-    returns finite samples of the right shape.  Flows stop at d = 512: one more is the reference's ValueError."""
+    returns finite samples of the right shape."""
     from nfmc_amd import sample
     from nfmc_amd.potentials import SumOfSquares
     kw = {}
@@ -1370,8 +1370,10 @@ def test_every_flow_strategy_runs_on_awkward_shapes(dev, strategy):
         torch.manual_seed(0)
         out = sample(SumOfSquares((d,)), strategy=strategy, flow=fl, n_chains=37, n_iterations=3, show_progress=False, **kw)
         assert out.samples.shape[1:] == (37, d) and torch.isfinite(out.samples).all(), (strategy, d, fl)
-    with pytest.raises(ValueError, match='supported range'):
-        sample(SumOfSquares((513,)), strategy=strategy, flow='realnvp', n_chains=8, n_iterations=2, show_progress=False, **kw)
+    # beyond the flow kernels (d > 512): the flow passes are composed from torch ops on the GPU, the samplers take
+    # the split path
+    out = sample(SumOfSquares((513,)), strategy=strategy, flow='realnvp', n_chains=8, n_iterations=2, show_progress=False, **kw)
+    assert out.samples.shape[1:] == (8, 513) and torch.isfinite(out.samples).all()
 
 
 def test_neutra_hmc_with_an_arbitrary_callable_target_matches_oracle(dev):
@@ -1494,3 +1496,41 @@ def test_edge_state_with_more_than_2_to_31_elements(dev):
     x2 = torch.randn(50, 4, 4, device=dev)
     out = sample(lambda x: (x ** 2).flatten(1).sum(1), strategy='hmc', x0=x2, n_iterations=2, show_progress=False)
     assert out.samples.shape == (2, 50, 4, 4)   # event shape taken from x0
+
+
+@pytest.mark.parametrize('d,ck', [(600, {}), (20, {'n_hidden': 200})])
+def test_flows_beyond_the_kernel_shapes_match_oracle(dev, d, ck):
+    """Events wider than 512 / conditioners wider than 128: forward, inverse, log_prob and sampling are composed from
+    torch ops on the GPU (same spec), latents from the same Philox stream; IMH through the split path follows the
+    oracle on native streams."""
+    from nfmc_amd import hip
+    from nfmc_amd.samplers import imh
+    from nfmc_amd.flows import Flow, RealNVP
+    from nfmc_amd.potentials import SumOfSquares
+    from oracle import flow as oflow, potentials as opot, samplers as osamp, philox
+    torch.manual_seed(d)
+    of = oflow.perturb_(oflow.Flow(oflow.RealNVP((d,), conditioner_kwargs=ck)), 3, 0.1, 0.75)
+    f = Flow(RealNVP((d,), conditioner_kwargs=ck))
+    f.load_state_dict(of.state_dict())
+    assert f.bijection.beyond_kernels()
+    x = 0.7 * torch.randn(50, d)
+    z, ld = f.bijection.forward(x)
+    zo, ldo = of.bijection.forward(x)
+    np.testing.assert_allclose(z.cpu().numpy(), zo.detach().numpy(), atol=2e-5)
+    np.testing.assert_allclose(ld.cpu().numpy(), ldo.detach().numpy(), atol=2e-4 * max(1, d / 64))
+    xb, _ = f.bijection.inverse(z)
+    np.testing.assert_allclose(xb.cpu().numpy(), x.numpy(), atol=2e-5)
+    np.testing.assert_allclose(f.log_prob(x).cpu().numpy(), of.log_prob(x).detach().numpy(), atol=3e-4 * max(1, d / 64), rtol=1e-5)
+    xs, lq = f.sample(40, return_log_prob=True, rng=hip.make_rng(5, 0, 7))
+    zz = philox.normal_field(5, np.arange(40), 7, d, philox.TAG_LATENT)
+    xo, ldi = of.bijection.inverse(torch.from_numpy(zz))
+    np.testing.assert_allclose(xs.cpu().numpy(), xo.detach().numpy(), atol=3e-5)
+    n, T = 60, 4
+    x0 = 0.7 * torch.randn(n, d)
+    s = imh.FixedIMH((d,), SumOfSquares((d,)), imh.IMHKernel((d,), flow=f), imh.IMHParameters(n_iterations=T))
+    s.seed = 21
+    out = s.sample(x0, show_progress=False)
+    tr = osamp.imh_sample(x0, opot.sum_squares, of, T, noise=osamp.PhiloxNoise(21))
+    same = (out.samples.reshape(T, n, d) - tr.stacked()).abs().amax(dim=(0, 2)) < 3e-4
+    assert same.float().mean() > 0.95
+    assert abs(out.statistics.n_accepted_trajectories - tr.n_accepted) <= 3
