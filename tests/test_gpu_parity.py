@@ -773,9 +773,17 @@ torch.manual_seed(1)   # identical flow weights on every rank
 out = sample(SumOfSquares((d,)), strategy='jump_mala', n_iterations=3, show_progress=False, x0=x0, seed=11,
              shard=Shard(), inner_param_kwargs={'n_iterations': 10}, param_kwargs={'store_samples': False})
 st = out.statistics
+# warmup with a flow fit: every rank contributes its share of the refit buffer (all-gather C1) and fits the same rows
+torch.manual_seed(2)
+out2 = sample(SumOfSquares((d,)), strategy='jump_mala', n_iterations=2, n_warmup_iterations=6, warmup=True,
+              show_progress=False, x0=x0[:600], seed=12, shard=Shard(), inner_param_kwargs={'n_iterations': 4},
+              param_kwargs={'flow_fit_kwargs': {'n_epochs': 3}})
+weights = torch.cat([p.detach().flatten().cpu() for p in out2.kernel.flow.parameters()])
 torch.save({'last': out.running_samples.last_sample.cpu(), 'mean': out.mean, 'second': out.second_moment,
             'acc': st.n_accepted_trajectories, 'att': st.n_attempted_trajectories, 'jacc': st.n_accepted_jumps,
-            'jatt': st.n_attempted_jumps, 'calls': st.n_target_calls}, os.path.join(outdir, f'r{rank}.pt'))
+            'jatt': st.n_attempted_jumps, 'calls': st.n_target_calls, 'weights': weights,
+            'att2': out2.statistics.n_attempted_trajectories, 'mean2': out2.mean},
+           os.path.join(outdir, f'r{rank}.pt'))
 dist.barrier()
 dist.destroy_process_group()
 '''
@@ -812,6 +820,10 @@ def test_two_rank_sharded_sampling_matches_single_process(dev, tmp_path):
         assert r['calls'] == ref.statistics.n_target_calls
         np.testing.assert_allclose(r['mean'].numpy(), ref.mean.numpy(), atol=1e-6)
         np.testing.assert_allclose(r['second'].numpy(), ref.second_moment.numpy(), atol=1e-6)
+    # the warmup fit: both ranks hold the same fitted flow (same gathered rows, same optimiser steps) and the merged
+    # statistics of all 600 chains
+    assert torch.isfinite(r0['weights']).all() and torch.equal(r0['weights'], r1['weights'])
+    assert r0['att2'] == r1['att2'] == 600 * 2 * 4 and torch.equal(r0['mean2'], r1['mean2'])
 
 
 def test_integration_stub_runs_and_matches_the_package(dev):
