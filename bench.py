@@ -24,6 +24,7 @@ cpu_baseline: the CPU oracle (oracle/samplers.py: the reference's op sequence, e
 one outer iteration of the same workload (65536 chains, 100 MALA + 1 jump), rank 0, N = 1 only.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -148,8 +149,15 @@ def main():
     torch.cuda.synchronize(dev)
     if args.warmup > 0:
         run(args.warmup)
+    # CPython's cyclic collector must not fire inside the timed region: with torch imported a full (generation 2)
+    # collection takes ~35 ms on this host -- five times the 20 timed steps -- and its trigger depends on allocation
+    # counts, i.e. on luck.  Collect now, keep it off while timing (reference counting still frees everything the
+    # run allocates), turn it back on afterwards.
+    gc.collect()
+    gc.disable()
     # HIP events only around the dominant kernel's launches: every event pair costs ~6 us of stream time
     dt, out = run(args.steps, time_kernels=False if args.no_kernel_events else 'mala_steps')
+    gc.enable()
     if distributed:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
