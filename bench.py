@@ -142,10 +142,11 @@ def main():
         return time.perf_counter() - t0, out
 
     # one-time initialisation outside the timed region whatever W is: library load, code-object load of the two
-    # kernels (first launch), packing of the flow weights -- a 256-chain, one-step run of the same path
+    # kernels (first launch), allocator warm-up -- ONE outer step of the same path at the same per-GPU size, so that
+    # every launch a profiler sees has the same shape (per-kernel averages agree with the HIP-event mean below)
     prime = build_sampler(1)
     prime.seed = 0
-    prime.sample(x0[:256], show_progress=False)
+    prime.sample(x0[:N_PER_GPU], show_progress=False)
     torch.cuda.synchronize(dev)
     if args.warmup > 0:
         run(args.warmup)
