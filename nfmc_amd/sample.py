@@ -127,6 +127,8 @@ def sample(target: Union[callable, Potential],
         event_shape = flow.event_shape
     elif isinstance(target, Potential):
         event_shape = target.event_shape
+    elif event_shape is None and hasattr(target, 'event_shape'):
+        event_shape = tuple(target.event_shape)   # a `potentials`-package object (sample.py:285-286), duck-typed
     if event_shape is None and x0 is not None:
         event_shape = tuple(x0.shape[1:])   # (the reference fails on `*None` here)
     seed = kwargs.pop('seed', None)

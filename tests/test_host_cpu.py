@@ -436,3 +436,41 @@ def test_metropolis_log_ratio_ordering():
     forward = metropolis_acceptance_log_ratio(-target(x0), -target(x1), -proposal(x0), -proposal(x1))
     inverse = metropolis_acceptance_log_ratio(-proposal(x0), -proposal(x1), -target(x0), -target(x1))
     assert forward > inverse
+
+
+def test_sample_store_slabs_equal_stepwise_reference_semantics():
+    """MCMCSamples fed whole launches (slabs of k steps) keeps exactly the rows the reference's step-by-step
+    `add` keeps (base.py:234-263: every `thinning`-th offered row, the newest `max_samples`, `last_sample` always),
+    whatever the slab sizes."""
+    import random
+    from nfmc_amd.containers import MCMCSamples
+    rng = random.Random(0)
+    for trial in range(60):
+        thinning = rng.choice([1, 1, 2, 3, 5])
+        max_samples = rng.choice([None, None, 1, 4, 7])
+        store = rng.random() > 0.15
+        total = rng.randint(0, 40)
+        steps = torch.arange(total, dtype=torch.float32).reshape(total, 1, 1).expand(total, 3, 2).contiguous()
+        s = MCMCSamples((2,), store_samples=store, thinning=thinning, max_samples=max_samples)
+        kept, seen, i = [], 0, 0
+        while i < total:
+            k = rng.randint(1, 9)
+            slab = steps[i:i + k]
+            s.add(slab if len(slab) > 1 or rng.random() > 0.5 else slab[0])   # (k, n, *e) or a single (n, *e) state
+            for row in slab:                                                    # the reference, one step at a time
+                if store:
+                    if seen % thinning == 0:
+                        kept.append(row)
+                        if max_samples is not None and len(kept) > max_samples:
+                            kept.pop(0)
+                    seen += 1
+            i += len(slab)
+        if total:
+            assert torch.equal(s.last_sample, steps[-1]) and torch.equal(s[-1], steps[-1])
+        want = torch.stack(kept) if kept else None
+        got = s.as_tensor()
+        assert s.n_samples == len(kept)
+        if want is None:
+            assert got.shape[0] == 0
+        else:
+            assert torch.equal(got, want), (trial, thinning, max_samples)
