@@ -103,6 +103,14 @@ class RealNVP(nn.Module):
     def _make_coupling(self, ck):
         return AffineCoupling(self.d, ck.get('n_hidden'), ck.get('n_layers', 2))
 
+    def __getstate__(self):
+        """deepcopy / pickle / torch.save: the device-side caches (ctypes structs holding raw pointers, the module
+        list of the version key) are rebuilt on demand, never copied."""
+        state = self.__dict__.copy()
+        state['_pack_cache'] = None
+        state.pop('_mods_cache', None)
+        return state
+
     # ------------------------------------------------------------------ packing for the kernels
     @property
     def couplings(self):

@@ -67,6 +67,11 @@ def create_sampler(target: callable,
             raise ValueError("Flow object must be provided")
         if isinstance(flow, str):
             flow_object = create_flow_object(flow_string=flow, event_shape=event_shape, **flow_kwargs)
+            # the reference moves the new flow to its device here (sample.py:118-120 `.to(device)`); this build's
+            # equivalent is the packed weight blob the kernels read: uploaded now rather than inside sample()
+            bij = getattr(flow_object, 'bijection', None)
+            if torch.cuda.is_available() and hasattr(bij, 'packed') and not bij.beyond_kernels():
+                bij.packed(torch.device('cuda', torch.cuda.current_device()))
         elif hasattr(flow, 'sample') and hasattr(flow, 'log_prob'):
             flow_object = flow
         else:

@@ -1546,3 +1546,21 @@ def test_flows_beyond_the_kernel_shapes_match_oracle(dev, d, ck):
     same = (out.samples.reshape(T, n, d) - tr.stacked()).abs().amax(dim=(0, 2)) < 3e-4
     assert same.float().mean() > 0.95
     assert abs(out.statistics.n_accepted_trajectories - tr.n_accepted) <= 3
+
+
+def test_flow_objects_copy_and_pickle_after_use(dev):
+    """A flow that has been used (weights packed for the kernels) still deep-copies and pickles: the device-side
+    caches hold ctypes structs with raw pointers and are dropped from the copied state."""
+    import copy, io
+    from nfmc_amd import sample
+    from nfmc_amd.potentials import SumOfSquares
+    out = sample(SumOfSquares((8,)), strategy='imh', n_chains=16, n_iterations=2, show_progress=False)
+    flow = out.kernel.flow
+    twin = copy.deepcopy(flow)
+    x = torch.randn(5, 8)
+    assert torch.equal(flow.log_prob(x), twin.log_prob(x))
+    buf = io.BytesIO()
+    torch.save(flow, buf)
+    buf.seek(0)
+    back = torch.load(buf, weights_only=False)
+    assert torch.equal(flow.log_prob(x), back.log_prob(x))
