@@ -34,8 +34,11 @@ class MetropolisKernel(MCMCKernel):
         super().__post_init__()
         if self.inv_mass_diag is None:
             self.inv_mass_diag = torch.ones(self.event_size)
-        elif tuple(self.inv_mass_diag.shape) != (self.event_size,):
-            raise ValueError
+        else:
+            self.inv_mass_diag = torch.as_tensor(self.inv_mass_diag, dtype=torch.float32)   # lists / fp64 / any device
+            if tuple(self.inv_mass_diag.shape) != (self.event_size,):
+                raise ValueError('inv_mass_diag must have event_size = %d entries, got shape %s'
+                                 % (self.event_size, tuple(self.inv_mass_diag.shape)))
         if self.da_params is None:
             self.da_params = DualAveragingParams()
         if self.da is None:
