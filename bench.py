@@ -179,6 +179,19 @@ def main():
         except Exception:
             traffic = None
 
+    # what actually binds the kernel, from the committed PMC passes of this same command (profiles/): VALU wave
+    # instructions per coordinate-transition and the share of the launch the VALU was issuing
+    valu = None
+    ppath = os.path.join(ROOT, 'profiles', 'r01_bench_pmc_summary.json')
+    if os.path.exists(ppath):
+        try:
+            pm = json.load(open(ppath))['mala_kernel']
+            valu = {'insts_per_coordinate_transition': pm['SQ_INSTS_VALU'] * 64 / (N_PER_GPU * D * K_INNER),
+                    'busy_frac': (pm['SQ_ACTIVE_INST_VALU'] / 256) / (pm['GRBM_GUI_ACTIVE'] / 8),
+                    'source': 'profiles/r01_bench_pmc_summary.json (SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU, GRBM_GUI_ACTIVE)'}
+        except Exception:
+            valu = None
+
     if rank == 0:
         value = n_total * (K_INNER + 1) * args.steps / dt
         st = out.statistics
@@ -195,7 +208,7 @@ def main():
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': (achieved / HBM_PEAK_GBS) if achieved else None, 'traffic': traffic,
                          'kernel': 'mala_kernel', 'mean_launch_ms': mean_mala, 'launches': len(mala_ms),
-                         'algorithmic_bytes_per_launch': alg_bytes_per_launch,
+                         'algorithmic_bytes_per_launch': alg_bytes_per_launch, 'valu': valu,
                          'note': 'state stays in VGPRs for the 100 transitions of a launch: real HBM traffic (traffic) << '
                                  'algorithmic bytes; the kernel is VALU-issue bound (Philox4x32-10 + Box-Muller + MALA '
                                  'arithmetic), so frac vs the HBM roof can exceed 1',
