@@ -474,3 +474,31 @@ def test_sample_store_slabs_equal_stepwise_reference_semantics():
             assert got.shape[0] == 0
         else:
             assert torch.equal(got, want), (trial, thinning, max_samples)
+
+
+def test_flow_copy_state_and_kernel_shape_limits():
+    """Host logic around the flow object: the device caches never travel with a copy / pickle, and shapes beyond the
+    kernels (nfmc_limits: d > 512, conditioners wider than 128, 32 for splines) are recognised without a GPU."""
+    import copy, io
+    from nfmc_amd.flows import CRQNSF, Flow, RealNVP
+    f = Flow(RealNVP((6,)))
+    f.bijection._pack_cache = {0: ('key', object())}        # what a used flow carries (ctypes structs on a GPU box)
+    key = f.bijection._version_key('cpu')
+    assert '_mods_cache' in f.bijection.__dict__
+    twin = copy.deepcopy(f)
+    assert twin.bijection._pack_cache is None and '_mods_cache' not in twin.bijection.__dict__
+    assert twin.bijection._version_key('cpu') != key          # its own parameter storage
+    assert all(torch.equal(a, b) for a, b in zip(f.parameters(), twin.parameters()))
+    buf = io.BytesIO()
+    torch.save(f, buf)
+    buf.seek(0)
+    back = torch.load(buf, weights_only=False)
+    assert back.bijection._pack_cache is None
+    with torch.no_grad():
+        f.bijection.layers[0].shift.add_(1.0)
+    assert f.bijection._version_key('cpu') != key             # in-place update invalidates the packed blob
+    assert not RealNVP((512,)).beyond_kernels() and RealNVP((513,)).beyond_kernels()
+    assert not RealNVP((16,), conditioner_kwargs={'n_hidden': 128}).beyond_kernels()
+    assert RealNVP((16,), conditioner_kwargs={'n_hidden': 129}).beyond_kernels()
+    assert not CRQNSF((16,), conditioner_kwargs={'n_hidden': 32}).beyond_kernels()
+    assert CRQNSF((16,), conditioner_kwargs={'n_hidden': 33}).beyond_kernels()
