@@ -1564,3 +1564,82 @@ def test_flow_objects_copy_and_pickle_after_use(dev):
     buf.seek(0)
     back = torch.load(buf, weights_only=False)
     assert torch.equal(flow.log_prob(x), back.log_prob(x))
+
+
+def test_randomized_flow_kernel_parity(dev):
+    """Forty seeded random flows (kind, d in 2..512, conditioner width 1..128, hidden layers, coupling layers, chain
+    counts off and on the tile sizes): forward, inverse, log-determinants and log_prob of whichever kernel serves the
+    shape (register / one-chain-per-lane / matrix-core) against the oracle."""
+    import random
+    from nfmc_amd.flows import Flow, RealNVP, NICE, CRQNSF
+    from oracle import flow as oflow
+    rng = random.Random(7)
+    for trial in range(40):
+        kind = rng.choice(['realnvp', 'realnvp', 'nice', 'c-rqnsf'])
+        d = rng.choice([2, 3, 5, 8, 17, 32, 63, 64, 65, 100, 128, 129, 200, 256, 384, 511, 512])
+        widths = [1, 3, 4, 5, 8, 9, 16, 17, 32]
+        H = rng.choice(widths if kind == 'c-rqnsf' else widths + [33, 64, 100, 128])
+        cl, nl, n = rng.choice([1, 2, 3]), rng.choice([1, 2, 3, 4]), rng.choice([1, 7, 64, 65, 300])
+        ck = {'n_hidden': H, 'n_layers': cl}
+        ocls, cls = {'realnvp': (oflow.RealNVP, RealNVP), 'nice': (oflow.NICE, NICE), 'c-rqnsf': (oflow.CRQNSF, CRQNSF)}[kind]
+        torch.manual_seed(trial)
+        of = oflow.perturb_(oflow.Flow(ocls((d,), n_layers=nl, conditioner_kwargs=ck)), trial, 0.1 if kind == 'c-rqnsf' else 0.2)
+        f = Flow(cls((d,), n_layers=nl, conditioner_kwargs=ck))
+        f.load_state_dict(of.state_dict())
+        x = torch.randn(n, d)
+        z, ld = f.bijection.forward(x)
+        zo, ldo = of.bijection.forward(x)
+        xb, ldb = f.bijection.inverse(zo.detach())
+        xo, ldbo = of.bijection.inverse(zo.detach())
+        lp, lpo = f.log_prob(x).cpu(), of.log_prob(x).detach()
+        tol = 5e-5 * max(1, d / 64) * (4 if kind == 'c-rqnsf' else 1)
+        case = (kind, d, H, cl, nl, n)
+        assert float((z.cpu() - zo.detach()).abs().max()) < tol, case
+        assert float((xb.cpu() - xo.detach()).abs().max()) < 4 * tol, case
+        assert float((ld.cpu() - ldo.detach()).abs().max()) < 40 * tol and float((ldb.cpu() - ldbo.detach()).abs().max()) < 40 * tol, case
+        assert float((lp - lpo).abs().max() / (1 + lpo.abs().max())) < 1e-4, case
+
+
+def test_randomized_sampler_parity(dev):
+    """Forty seeded random sampler runs (MALA / ULA / HMC / UHMC / MH; d in 1..1024 over every lane layout; unit or
+    random mass diagonal; sum of squares / diagonal Gaussian / funnel; chain counts off the tile sizes) on the native
+    Philox streams against the oracle."""
+    import random
+    from nfmc_amd.samplers import mcmc
+    from nfmc_amd.potentials import SumOfSquares, DiagonalGaussian, Funnel
+    from oracle import samplers as osamp, potentials as opot
+    rng = random.Random(11)
+    for trial in range(40):
+        kind = rng.choice(['langevin', 'langevin', 'hmc', 'mh'])
+        d = rng.choice([1, 2, 3, 4, 7, 8, 16, 25, 31, 32, 64, 65, 100, 128, 200, 256, 300, 512, 700, 1024])
+        n, k = rng.choice([1, 5, 64, 130, 257]), rng.choice([1, 3, 7])
+        adjust, mass = rng.random() > 0.2, rng.random() > 0.5
+        potk = rng.choice(['sumsq', 'gauss', 'funnel']) if d >= 2 else 'sumsq'
+        torch.manual_seed(trial)
+        imd = torch.rand(d) + 0.5 if mass else None
+        if potk == 'sumsq':
+            pot, opt = SumOfSquares((d,)), opot.sum_squares
+        elif potk == 'gauss':
+            mu, sig = torch.randn(d) * 0.3, torch.rand(d) + 0.7
+            pot, opt = DiagonalGaussian((d,), mu, sig), (lambda v, mu=mu, sig=sig: (((v - mu) ** 2) / (2 * sig ** 2)).sum(-1))
+        else:
+            pot, opt = Funnel((d,), 3.0), opot.funnel(3.0)
+        h = 0.05 if kind == 'hmc' else 0.5 * d ** (-1 / 3)
+        x0 = 0.5 * torch.randn(n, d)
+        if kind == 'langevin':
+            s = (mcmc.MALA if adjust else mcmc.ULA)((d,), pot, mcmc.LangevinKernel(event_size=d, step_size=h, inv_mass_diag=imd),
+                                                    mcmc.LangevinParameters(n_iterations=k))
+        elif kind == 'hmc':
+            s = (mcmc.HMC if adjust else mcmc.UHMC)((d,), pot, mcmc.HMCKernel(event_size=d, step_size=h, n_leapfrog_steps=3,
+                                                                              inv_mass_diag=imd), mcmc.HMCParameters(n_iterations=k))
+        else:
+            adjust = True
+            s = mcmc.MH((d,), pot, mcmc.MHKernel(event_size=d, inv_mass_diag=(imd * 0.1 if mass else torch.full((d,), 0.1))),
+                        mcmc.MHParameters(n_iterations=k))
+        s.seed = 1000 + trial
+        out = s.sample(x0, show_progress=False)
+        tr = osamp.mcmc_sample(x0, opt, kind, k, None if kind == 'mh' else h, inv_mass_diag=s.kernel.inv_mass_diag.clone(),
+                               adjustment=adjust, noise=osamp.PhiloxNoise(1000 + trial), **(dict(n_leapfrog=3) if kind == 'hmc' else {}))
+        err = (out.samples.reshape(k, n, d) - tr.stacked()).abs().amax(dim=(0, 2))
+        same = err < 3e-4 * max(1, d / 64)   # chains whose accept decision sits on the boundary may differ
+        assert same.float().mean() >= (0.9 if n > 20 else 0.6), (kind, d, n, k, adjust, mass, potk, float(err.max()))
