@@ -1643,3 +1643,52 @@ def test_randomized_sampler_parity(dev):
         err = (out.samples.reshape(k, n, d) - tr.stacked()).abs().amax(dim=(0, 2))
         same = err < 3e-4 * max(1, d / 64)   # chains whose accept decision sits on the boundary may differ
         assert same.float().mean() >= (0.9 if n > 20 else 0.6), (kind, d, n, k, adjust, mass, potk, float(err.max()))
+
+
+def test_randomized_neutra_and_jump_parity(dev):
+    """Twenty-four seeded random NeuTra-HMC / JumpMALA / JumpHMC runs (d = 2..200, conditioner widths 3..128, one or two
+    hidden layers, one to three couplings, Gaussian and funnel targets) on the native Philox streams against the oracle:
+    whichever kernel serves the shape -- fused VALU, matrix-core, register flow, tile flow, or the composed path."""
+    import random
+    from nfmc_amd.samplers import neutra, mcmc, jump
+    from nfmc_amd.containers import NFMCKernel
+    from nfmc_amd.flows import Flow, RealNVP
+    from nfmc_amd.potentials import SumOfSquares, Funnel
+    from oracle import flow as oflow, potentials as opot, samplers as osamp
+    rng = random.Random(5)
+    for trial in range(24):
+        which = rng.choice(['neutra', 'neutra', 'jump_mala', 'jump_hmc'])
+        d = rng.choice([2, 5, 12, 33, 64, 64, 100, 128, 128, 150, 200])
+        H, cl, nl = rng.choice([3, 8, 16, 32, 40, 64, 128]), rng.choice([1, 2]), rng.choice([1, 2, 3])
+        n, T, K = rng.choice([3, 40, 70]), 2, 3
+        potk = rng.choice(['sumsq', 'funnel'])
+        pot, opt = (SumOfSquares((d,)), opot.sum_squares) if potk == 'sumsq' else (Funnel((d,), 3.0), opot.funnel(3.0))
+        ck = {'n_hidden': H, 'n_layers': cl}
+        torch.manual_seed(trial)
+        of = oflow.perturb_(oflow.Flow(oflow.RealNVP((d,), n_layers=nl, conditioner_kwargs=ck)), trial, 0.15,
+                            None if which == 'neutra' else 0.75)
+        f = Flow(RealNVP((d,), n_layers=nl, conditioner_kwargs=ck))
+        f.load_state_dict(of.state_dict())
+        x0 = 0.5 * torch.randn(n, d)
+        seed = 50 + trial
+        if which == 'neutra':
+            s = neutra.NeuTraHMC((d,), pot, mcmc.HMCKernel(event_size=d, n_leapfrog_steps=3, step_size=0.03), mcmc.HMCParameters(),
+                                 neutra.NeuTraKernel((d,), flow=f), neutra.NeuTraParameters(n_iterations=T))
+            s.seed = seed
+            got = s.sample(x0, show_progress=False).samples.reshape(T, n, d)
+            want = osamp.neutra_hmc_sample(x0, opt, of, T, 0.03, None, 3, noise=osamp.PhiloxNoise(seed)).stacked()
+        elif which == 'jump_mala':
+            s = jump.JumpMALA((d,), pot, NFMCKernel((d,), flow=f), jump.JumpNFMCParameters(n_iterations=T), None,
+                              mcmc.LangevinParameters(n_iterations=K))
+            s.seed = seed
+            got = s.sample(x0, show_progress=False).samples.reshape(T * (K + 1), n, d)
+            want = osamp.jump_sample(x0, opt, of, 'langevin', T, K, d ** (-1 / 3), noise=osamp.PhiloxNoise(seed)).stacked()
+        else:
+            s = jump.JumpHMC((d,), pot, NFMCKernel((d,), flow=f), jump.JumpNFMCParameters(n_iterations=T),
+                             mcmc.HMCKernel(event_size=d, n_leapfrog_steps=3, step_size=0.05), mcmc.HMCParameters(n_iterations=K))
+            s.seed = seed
+            got = s.sample(x0, show_progress=False).samples.reshape(T * (K + 1), n, d)
+            want = osamp.jump_sample(x0, opt, of, 'hmc', T, K, 0.05, n_leapfrog=3, noise=osamp.PhiloxNoise(seed)).stacked()
+        err = (got - want).abs().amax(dim=(0, 2))
+        same = err < 5e-4 * max(1, d / 64)
+        assert same.float().mean() >= (0.85 if n > 20 else 0.6), (which, d, H, cl, nl, n, potk, float(err.max()))
