@@ -1,88 +1,363 @@
 #!/usr/bin/env python
 """Headline benchmark: chain-steps/s of jump_mala + RealNVP on a synthetic Gaussian target (BASELINE.json).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config C3|C2|C4|C5] [--reps R] [--fit-nf]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[2], SURVEY.md section 8d "C3"): strategy jump_mala, U = sum x^2, d = 64,
-65536 chains PER GPU (weak scaling: global chain ids continue across ranks), 100 inner MALA transitions per
-jump (h = 64^(-1/3) = 0.25, unit mass), adjusted jumps with the build's default RealNVP (weights seed 1),
-store_samples=False.  One bench "step" = one outer iteration = 101 Markov transitions of every chain.
-metric value = n_chains_total * 101 * K / t, t = max over ranks of the wall time of `sampler.sample(x0)`
-(x0 already resident in HBM) bracketed by barrier + synchronize.
+Launching.  Under torchrun (WORLD_SIZE set) this process is one rank.  Without it and with --gpus N > 1 the
+parent -- BEFORE any GPU call; it never touches the GPU itself -- starts N fresh child processes of this same file,
+one per device (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT in their environment), relays
+rank 0's JSON line and exits with the children's status.  Ranks rendezvous over RCCL (`nccl` backend);
+`--backend gloo --rehearse` runs the same launcher / rendezvous / barrier / max-over-ranks code without any GPU
+work (what the CPU test of the launcher uses).
 
-roofline: the dominant kernel is `mala_kernel`.  achieved = (8*d bytes per chain-transition [SURVEY 8d] *
-n_local * 100 transitions per launch) / mean launch duration from HIP events recorded on the launch stream
-during the timed region.  The kernel keeps the state in registers for the 100 transitions of a launch, so its
-real HBM traffic (`traffic`, PMC-measured, profiles/) is ~1% of the algorithmic figure and the kernel is
-VALU-issue bound (profiles/: SQ_ACTIVE_INST_VALU ~ 100% of the launch); frac is quoted against the HBM roof
-because that is the per-transition bound SURVEY 8d names -- frac > 1 means the fused kernel runs faster than
-ANY kernel that streams the state once per transition could (it says nothing about being "over peak").
+Workload (default C3 = BASELINE.json configs[2]): strategy jump_mala, U = sum x^2, d = 64,
+65536 chains PER GPU (weak scaling: global chain ids continue across ranks), 100 inner MALA transitions per jump
+(h = 64^(-1/3) = 0.25, unit mass), adjusted jumps with the build's default RealNVP (weights seed 1),
+store_samples=False, x0 ~ N(0, I) from torch.manual_seed(0) on the CPU, uploaded before the timed region.  One bench
+"step" = one outer iteration = 101 Markov transitions of every chain.  W untimed warm-up steps carry the state from
+x0 to stationarity; then R (>= 5) timed repetitions of EXACTLY K steps each, every repetition bracketed by barrier +
+synchronize on both sides and reduced by MAX over ranks; `value` / `ms_per_step` come from the MEDIAN repetition
+(median of >= 5 runs), all repetitions are listed in `rep_ms`.
+  value = n_chains_total * transitions_per_step * K / t_median.
 
-cpu_baseline: the CPU oracle (oracle/samplers.py: the reference's op sequence, eager PyTorch + autograd) on
-one outer iteration of the same workload (65536 chains, 100 MALA + 1 jump), rank 0, N = 1 only.
+roofline.  The dominant kernel of C3 is `mala_kernel`: it keeps the state in VGPRs for the 100 transitions of a
+launch, so its HBM traffic is ~1 % of the per-transition algorithmic bytes of SURVEY 8d and the roof that BINDS is
+VALU issue (Philox4x32-10 + Box-Muller + the MALA arithmetic).  So:
+  bound     "valu"
+  achieved  VALU wave-instructions per second = SQ_INSTS_VALU per launch (committed rocprofv3 --pmc pass of this
+            same command, profiles/) / mean launch duration measured live here with HIP events on the launch stream
+  peak      1024 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction = 614.4 G wave-inst/s (the rate behind the
+            157.3 TFLOP/s fp32 vector peak of MI355X_MICROARCH.md, which counts packed FMAs: 2 x 2 flop per lane)
+  frac      achieved / peak  (<= 1)
+  hbm_algorithmic   SURVEY 8d's 8*d bytes per chain-transition x transitions per launch / launch time vs 8 TB/s --
+                    can exceed 1 for a kernel that fuses K transitions per launch; reported, not the bound
+  hbm_real_frac     PMC-measured HBM bytes per launch / launch time / 8 TB/s
+  flops_algorithmic SURVEY 8d's 30*d flop per MALA transition vs the 157.3 TFLOP/s vector peak
+C4's dominant kernel (`neutra_leapfrog_mfma_kernel`) is bound by fp32 MFMA: achieved TFLOP/s of conditioner GEMMs
+(sustained: measured over the whole timed region) vs 157.3.
+
+parity.  moments / acceptance of the timed run vs the analytic N(0, I/2), and -- north_star's "vs the CPU path on
+the same seeds" -- a leg that runs ONE outer iteration of the first 8192 chains on the GPU and through the CPU
+oracle (oracle/samplers.py, the reference's op sequence) fed the same x0 and the same Philox streams, and reports
+the differences of first / second moments and of the acceptance rates.
+
+cpu_baseline: the CPU oracle (eager PyTorch + autograd, torch's own generator like the reference) on a bounded
+sample of the same workload, rank 0, N = 1 only.
 """
 import argparse
 import gc
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-D = 64
-N_PER_GPU = 65536
-K_INNER = 100
 HBM_PEAK_GBS = 8000.0
+FP32_PEAK_TFLOPS = 157.3
+VALU_PEAK_GINST = 1024 * 2.4 / 4.0   # G wave64-instructions / s: 256 CUs x 4 SIMDs, 4 cycles per instruction, 2.4 GHz
+
+# ---------------------------------------------------------------------------------------------------- workloads
+CONFIGS = {
+    'C3': dict(strategy='jump_mala', d=64, n_per_gpu=65536, inner=100, transitions_per_step=101,
+               kernel='mala_kernel', label='mala_steps', bound='valu',
+               workload='BASELINE configs[2]: jump_mala + realnvp, U=sum x^2 (N(0, I/2)), d=64, 65536 chains per GPU, '
+                        '100 MALA transitions per jump, step 0.25',
+               metric='chain-steps/sec (n_chains x iters / s), jump_mala + RealNVP, d=64'),
+    'C2': dict(strategy='imh', d=64, n_per_gpu=8192, inner=50, transitions_per_step=50,
+               kernel='imh_eval_kernel', label='imh_parallel', bound='valu',
+               workload='BASELINE configs[1]: imh + realnvp, U=sum x^2, d=64, 8192 chains per GPU; one bench step = 50 '
+                        'independence-MH transitions (20 steps = SURVEY C2\'s T=1000)',
+               metric='chain-steps/sec (n_chains x iters / s), imh + RealNVP, d=64'),
+    'C4': dict(strategy='neutra_hmc', d=128, n_per_gpu=65536, inner=1, transitions_per_step=1,
+               kernel='neutra_leapfrog_mfma_kernel', label='neutra_hmc_steps', bound='mfma',
+               workload='BASELINE configs[3]: neutra_hmc + realnvp (conditioner 128 x 2), funnel potential d=128, 65536 '
+                        'chains per GPU, L=10 leapfrog steps (h=0.02); one bench step = one trajectory',
+               metric='chain-steps/sec (n_chains x iters / s), neutra_hmc + RealNVP, funnel d=128, L=10'),
+    'C5': dict(strategy='jump_hmc', d=256, n_per_gpu=32768, inner=5, transitions_per_step=6,
+               kernel='hmc_kernel', label='hmc_steps', bound='valu',
+               workload='BASELINE configs[4]: jump_hmc + realnvp, U=sum x^2, d=256, 32768 chains per GPU (262144 over 8), '
+                        'K=5 HMC trajectories of L=20 (h=0.05) per jump',
+               metric='chain-steps/sec (n_chains x iters / s), jump_hmc + RealNVP, d=256'),
+}
+C4_MACS_PER_GRADIENT = 245760     # per chain: 2 couplings x (forward 3 GEMMs + reverse sweep) at d=128, H=128 x 2
+PARITY_ROWS = 8192
 
 
-def build_sampler(n_outer, flow_seed=1):
+def build_sampler(cfg, n_steps, fit_nf=False, flow_seed=1):
+    """The sampler of one repetition: K bench steps.  Flow weights from torch.manual_seed(flow_seed)."""
+    import torch
+    from nfmc_amd.potentials import Funnel, SumOfSquares
     from nfmc_amd.sample import create_sampler
-    from nfmc_amd.potentials import SumOfSquares
+    d = cfg['d']
     torch.manual_seed(flow_seed)
-    s = create_sampler(SumOfSquares((D,)), strategy='jump_mala', flow='realnvp',
-                       param_kwargs={'n_iterations': n_outer, 'store_samples': False},
-                       inner_param_kwargs={'n_iterations': K_INNER})
-    return s
+    st = cfg['strategy']
+    if st == 'jump_mala':
+        pk = {'n_iterations': n_steps, 'store_samples': False}
+        if fit_nf:
+            pk.update(fit_nf=True, n_jumps_before_training=0, flow_fit_kwargs={'n_epochs': 2, 'show_progress': False})
+        return create_sampler(SumOfSquares((d,)), strategy=st, flow='realnvp', param_kwargs=pk,
+                              inner_param_kwargs={'n_iterations': cfg['inner']})
+    if st == 'jump_hmc':
+        pk = {'n_iterations': n_steps, 'store_samples': False}
+        if fit_nf:
+            pk.update(fit_nf=True, n_jumps_before_training=0, flow_fit_kwargs={'n_epochs': 2, 'show_progress': False})
+        return create_sampler(SumOfSquares((d,)), strategy=st, flow='realnvp', param_kwargs=pk,
+                              inner_kernel_kwargs={'n_leapfrog_steps': 20, 'step_size': 0.05},
+                              inner_param_kwargs={'n_iterations': cfg['inner']})
+    if st == 'imh':
+        return create_sampler(SumOfSquares((d,)), strategy=st, flow='realnvp',
+                              param_kwargs={'n_iterations': n_steps * cfg['inner'], 'store_samples': False})
+    if st == 'neutra_hmc':
+        return create_sampler(Funnel((d,), 3.0), strategy=st, flow='realnvp',
+                              flow_kwargs={'conditioner_kwargs': {'n_hidden': 128, 'n_layers': 2}},
+                              inner_kernel_kwargs={'n_leapfrog_steps': 10, 'step_size': 0.02},
+                              param_kwargs={'n_iterations': n_steps, 'store_samples': False})
+    raise ValueError(st)
 
 
-def cpu_baseline():
-    """One outer iteration of the same workload on the host cores with the CPU oracle (port of the reference).
-    Eager PyTorch on tensors of 16 MiB scales badly past a few dozen threads (measured on the bench box: 2.2e6
-    chain-steps/s at 16-32 threads, 5.8e5 at 128), so the thread count is calibrated on a short run first and the
-    best one is used and reported as `cores`."""
+def initial_state(cfg, n_total):
+    """x0 ~ N(0, I), f32, from torch.manual_seed(0) on the CPU, so CPU and GPU legs share it.  The
+    funnel's NeuTra run starts closer in (0.5 N(0, I)): an untrained flow + N(0, I) in 128 dimensions puts most chains
+    where a step of 0.02 rejects, which measures nothing."""
+    import torch
+    gen = torch.Generator(device='cpu').manual_seed(0)
+    x0 = torch.randn(n_total, cfg['d'], generator=gen)
+    return 0.5 * x0 if cfg['strategy'] == 'neutra_hmc' else x0
+
+
+# ---------------------------------------------------------------------------------------------------- CPU legs
+def _oracle_flow(cfg):
+    import torch
     from oracle import flow as oflow
+    torch.manual_seed(1)
+    if cfg['strategy'] == 'neutra_hmc':
+        return oflow.Flow(oflow.RealNVP((cfg['d'],), conditioner_kwargs={'n_hidden': 128, 'n_layers': 2}))
+    return oflow.Flow(oflow.RealNVP((cfg['d'],)))
+
+
+def _oracle_run(cfg, x0, flow, n_steps, noise=None):
+    """`n_steps` bench steps of the workload through the CPU oracle; returns (Trace, transitions per chain)."""
     from oracle import potentials as opot
     from oracle import samplers as osamp
-    torch.manual_seed(1)
-    flow = oflow.Flow(oflow.RealNVP((D,)))
-    torch.manual_seed(0)
-    x0 = torch.randn(N_PER_GPU, D)
-    h = D ** (-1 / 3)
-    osamp.jump_sample(x0[:1024], opot.sum_squares, flow, 'langevin', 1, 5, h, store=False)  # warm
+    d, st = cfg['d'], cfg['strategy']
+    if st == 'jump_mala':
+        return osamp.jump_sample(x0, opot.sum_squares, flow, 'langevin', n_steps, cfg['inner'], d ** (-1 / 3),
+                                 noise=noise, store=False), n_steps * (cfg['inner'] + 1)
+    if st == 'jump_hmc':
+        return osamp.jump_sample(x0, opot.sum_squares, flow, 'hmc', n_steps, cfg['inner'], 0.05, n_leapfrog=20,
+                                 noise=noise, store=False), n_steps * (cfg['inner'] + 1)
+    if st == 'imh':
+        return osamp.imh_sample(x0, opot.sum_squares, flow, n_steps * cfg['inner'], noise=noise, store=False), \
+            n_steps * cfg['inner']
+    return osamp.neutra_hmc_sample(x0, opot.funnel(3.0), flow, n_steps, 0.02, None, 10, noise=noise), n_steps
+
+
+def cpu_baseline(cfg):
+    """A bounded sample of the same workload on the host cores with the CPU oracle (port of the reference: eager
+    PyTorch ops + autograd, torch's generator).  Eager PyTorch on 16 MiB tensors scales badly past a few dozen
+    threads (measured on the bench box: 2.2e6 chain-steps/s at 16-32 threads, 5.8e5 at 128), so the thread count is
+    calibrated on a short run first; the best one is used and reported as `cores`."""
+    import torch
+    flow = _oracle_flow(cfg)
+    n = cfg['n_per_gpu'] if cfg['strategy'] != 'neutra_hmc' else 4096
+    x0 = initial_state(cfg, n)
+    small = dict(cfg, inner=max(1, cfg['inner'] // 25))
+    _oracle_run(small, x0[:1024], flow, 1)   # warm
     avail = torch.get_num_threads()
     best_t, best_dt = avail, None
     for nt in sorted({t for t in (8, 16, 32, 64, avail) if t <= avail}):
         torch.set_num_threads(nt)
         t0 = time.perf_counter()
-        osamp.jump_sample(x0, opot.sum_squares, flow, 'langevin', 1, 4, h, store=False)
+        _oracle_run(small, x0, flow, 1)
         dt = time.perf_counter() - t0
         if best_dt is None or dt < best_dt:
             best_t, best_dt = nt, dt
     torch.set_num_threads(best_t)
     t0 = time.perf_counter()
-    osamp.jump_sample(x0, opot.sum_squares, flow, 'langevin', 1, K_INNER, h, store=False)
+    _tr, transitions = _oracle_run(cfg, x0, flow, 1)
     dt = time.perf_counter() - t0
     torch.set_num_threads(avail)
-    return {'value': N_PER_GPU * (K_INNER + 1) / dt, 'unit': 'chain-steps/s', 'cores': best_t,
-            'kind': 'port',
-            'sample': f'1 outer iteration (100 MALA + 1 jump) of {N_PER_GPU} chains, d={D}, oracle/samplers.py '
-                      f'jump_sample in {dt:.1f} s on {best_t} threads (best of 8/16/32/64/{avail} on a 4-step calibration)'}
+    return {'value': n * transitions / dt, 'unit': 'chain-steps/s', 'cores': best_t, 'kind': 'port',
+            'sample': f'1 bench step ({transitions} transitions) of {n} chains, d={cfg["d"]}, oracle/samplers.py in '
+                      f'{dt:.1f} s on {best_t} threads (best of 8/16/32/64/{avail} on a short calibration run)'}
+
+
+def parity_vs_oracle(cfg, dev):
+    """north_star: 'match the reference CPU path on identical seeds ... first/second moments and acceptance rate'.
+    ONE bench step of the first PARITY_ROWS chains: the GPU path and the CPU oracle get the same x0 rows and the
+    same Philox streams (oracle/philox.py is the executable spec of the kernels' generator), so the two runs are the
+    same Markov chains up to fp32 rounding (chains whose accept test lands within rounding of a tie may part)."""
+    import torch
+    from oracle import samplers as osamp
+    n, seed = PARITY_ROWS, 123
+    x0 = initial_state(cfg, n)
+    s = build_sampler(cfg, 1)
+    s.seed = seed
+    out = s.sample(x0.to(dev), show_progress=False)
+    tr, transitions = _oracle_run(cfg, x0, _oracle_flow(cfg), 1, noise=osamp.PhiloxNoise(seed))
+    m1, m2 = tr.moments.first, tr.moments.second
+    st = out.statistics
+    res = {'rows': n, 'transitions': transitions, 'seed': seed,
+           'first_moment_abs_diff_max': float((out.mean - m1).abs().max()),
+           'second_moment_rel_diff_max': float(((out.second_moment - m2).abs() / m2.abs().clamp_min(1e-6)).max()),
+           'acceptance_gpu': st.acceptance_rate, 'acceptance_cpu': tr.n_accepted / max(1, tr.n_attempted),
+           'last_state_agreeing_chains': float(((out.running_samples.last_sample.cpu() - tr.last).abs().amax(1) < 1e-3)
+                                               .float().mean())}
+    if hasattr(st, 'n_accepted_jumps'):
+        res['jump_acceptance_gpu'] = st.jump_acceptance_rate
+        res['jump_acceptance_cpu'] = tr.n_accepted_jumps / max(1, tr.n_attempted_jumps)
+    return res
+
+
+# ---------------------------------------------------------------------------------------------------- launcher
+def _free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n):
+    """Parent of `python bench.py --gpus N` (N > 1, no torchrun): N children, one per device.  Nothing here touches the
+    GPU (no HIP call, no torch.cuda query), and nothing is exec'ed from a process that did."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), NFMC_BENCH_CHILD='1')
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode]
+    for p in procs[1:]:
+        try:
+            rcs.append(p.wait(timeout=600))
+        except subprocess.TimeoutExpired:
+            p.kill()   # this exact child
+            rcs.append(-9)
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    bad = [rc for rc in rcs if rc != 0]
+    sys.exit(bad[0] if bad else 0)
+
+
+def _quiet_init(backend, rank, world, dev):
+    """stdout carries exactly one JSON line: RCCL prints its init banner with printf, so file descriptor 1 points at
+    stderr while the communicator is built."""
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+        dist.barrier()
+    finally:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
+def _reduce_times(dt, world, dist, dev):
+    """(max over ranks, [per-rank seconds]) of one repetition."""
+    import torch
+    if dist is None:
+        return dt, [dt]
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    allt = torch.empty(world, dtype=torch.float64, device=dev)
+    dist.all_gather_into_tensor(allt, t)
+    per = [float(v) for v in allt.cpu()]
+    return max(per), per
+
+
+def rehearse(args, rank, world):
+    """The launcher / rendezvous / barrier / max-over-ranks path without GPU work (CPU test of --gpus N)."""
+    import torch
+    import torch.distributed as dist
+    _quiet_init(args.backend, rank, world, None)
+    reps = []
+    for _ in range(args.reps):
+        dist.barrier()
+        t0 = time.perf_counter()
+        time.sleep(0.002 * (rank + 1))
+        dist.barrier()
+        reps.append(_reduce_times(time.perf_counter() - t0, world, dist, 'cpu'))
+    if rank == 0:
+        print(json.dumps({'metric': CONFIGS[args.config]['metric'], 'value': None, 'unit': 'chain-steps/s',
+                          'n_gpus': world, 'world_size_reported_by_backend': dist.get_world_size(),
+                          'backend': dist.get_backend(), 'steps': args.steps, 'warmup': args.warmup, 'rehearsal': True,
+                          'per_rank_ms': [1e3 * v for v in reps[len(reps) // 2][1]]}), flush=True)
+    dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------------- measurement
+def _pmc(cfg_name, kernel):
+    """Per-launch counter means of the dominant kernel from the committed rocprofv3 --pmc passes of this command."""
+    for name in ('r02_%s_pmc_summary.json' % cfg_name.lower(), 'r02_bench_pmc_summary.json', 'r01_bench_pmc_summary.json'):
+        p = os.path.join(ROOT, 'profiles', name)
+        if os.path.exists(p):
+            try:
+                pm = json.load(open(p)).get(kernel)
+            except Exception:
+                pm = None
+            if pm:
+                return pm, 'profiles/' + name
+    return None, None
+
+
+def roofline(cfg_name, cfg, n_local, mean_ms, launches, transitions_per_launch):
+    pm, src = _pmc(cfg_name, cfg['kernel'])
+    d = cfg['d']
+    r = {'kernel': cfg['kernel'], 'mean_launch_ms': mean_ms, 'launches': launches, 'pmc_source': src}
+    secs = mean_ms * 1e-3 if mean_ms else None
+    traffic = None
+    if pm and 'FETCH_SIZE' in pm and 'WRITE_SIZE' in pm:
+        traffic = (2 * pm['FETCH_SIZE'] + pm['WRITE_SIZE']) * 1024   # gfx950 correction: MI355X_MICROARCH.md, HBM section
+    if cfg['bound'] == 'mfma':
+        flops = 2.0 * C4_MACS_PER_GRADIENT * n_local * 10   # one launch = one trajectory = L gradient evaluations
+        ach = flops / secs / 1e12 if secs else None
+        r.update(bound='mfma', achieved=ach, peak=FP32_PEAK_TFLOPS, unit='TFLOP/s',
+                 frac=(ach / FP32_PEAK_TFLOPS) if ach else None, traffic=traffic,
+                 algorithmic_flops_per_launch=flops,
+                 note='mean over EVERY launch of the timed repetitions (sustained clocks, not a from-idle burst); one '
+                      'event pair brackets a whole nfmc_neutra_hmc_steps_f32 call (K trajectory launches + one '
+                      'gradient launch + K statistics folds), so the per-launch mean is <= 2 % pessimistic')
+        if pm and pm.get('SQ_VALU_MFMA_BUSY_CYCLES') and pm.get('GRBM_GUI_ACTIVE'):
+            r['mfma_busy_frac'] = (pm['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024) / (pm['GRBM_GUI_ACTIVE'] / 8)
+        return r
+    per_launch_transitions = n_local * transitions_per_launch
+    alg_bytes = (8 * d + (8 if cfg['strategy'] == 'imh' else 0)) * per_launch_transitions
+    insts = pm.get('SQ_INSTS_VALU') if pm else None
+    ach = insts / secs / 1e9 if (insts and secs) else None
+    r.update(bound='valu', achieved=ach, peak=VALU_PEAK_GINST, unit='G wave-inst/s',
+             frac=(ach / VALU_PEAK_GINST) if ach else None, traffic=traffic,
+             valu_wave_insts_per_launch=insts,
+             valu_insts_per_coordinate_transition=(insts * 64 / (per_launch_transitions * d)) if insts else None,
+             hbm_algorithmic={'bytes_per_launch': alg_bytes,
+                              'achieved_GBps': alg_bytes / secs / 1e9 if secs else None,
+                              'frac_of_8TBps': alg_bytes / secs / 1e9 / HBM_PEAK_GBS if secs else None},
+             hbm_real_frac=(traffic / secs / 1e9 / HBM_PEAK_GBS) if (traffic and secs) else None,
+             note='state stays in VGPRs for the transitions of a launch: HBM traffic << algorithmic bytes; the kernel is '
+                  'bound by VALU issue (generator + transition arithmetic); peak = 1024 SIMDs x 2.4 GHz / 4 cycles')
+    if pm and pm.get('SQ_ACTIVE_INST_VALU') and pm.get('GRBM_GUI_ACTIVE'):
+        r['valu_busy_frac_pmc'] = (pm['SQ_ACTIVE_INST_VALU'] / 256) / (pm['GRBM_GUI_ACTIVE'] / 8)
+    if cfg['strategy'] == 'jump_mala' and secs:
+        fl = 30.0 * d * per_launch_transitions
+        r['flops_algorithmic'] = {'flop_per_launch': fl, 'achieved_TFLOPs': fl / secs / 1e12,
+                                  'frac_of_fp32_vector_peak': fl / secs / 1e12 / FP32_PEAK_TFLOPS}
+    return r
 
 
 def main():
@@ -90,44 +365,44 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--reps', type=int, default=5, help='timed repetitions of K steps; value = median (SURVEY 8d)')
+    ap.add_argument('--config', choices=sorted(CONFIGS), default='C3')
+    ap.add_argument('--fit-nf', action='store_true', help='jump strategies: refit the flow every outer iteration, so the '
+                                                          'all-gather of the refit buffer (C1) is on the measured path')
+    ap.add_argument('--backend', choices=['nccl', 'gloo'], default='nccl')
+    ap.add_argument('--rehearse', action='store_true', help='launcher / rendezvous / reduction only, no GPU work')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-events', action='store_true', help='(experiment) no HIP events in the timed region')
     args = ap.parse_args()
+    args.reps = max(1, args.reps)
 
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        launch_ranks(args.gpus)   # does not return
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    # NFMC_BENCH_FORCE_DIST=1: take the multi-rank code path (RCCL init, barriers, all-reduce) with one rank (rehearsal)
+    if args.rehearse:
+        return rehearse(args, rank, world)
+
+    import torch
+    cfg = CONFIGS[args.config]
+    # NFMC_BENCH_FORCE_DIST=1: take the multi-rank code path (RCCL init, barriers, collectives) with one rank
     distributed = world > 1 or os.environ.get('NFMC_BENCH_FORCE_DIST') == '1'
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    dist = None
     if distributed:
         import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        # stdout carries exactly one JSON line: RCCL prints its init banner ("RCCL version : ...", debug level VERSION,
-        # which the bench box sets) with printf, so file descriptor 1 points at stderr while the communicator is built
-        sys.stdout.flush()
-        saved = os.dup(1)
-        os.dup2(2, 1)
-        try:
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
-            dist.barrier()
-        finally:
-            import ctypes
-            ctypes.CDLL(None).fflush(None)   # the banner sits in C stdio's buffer when stdout is a pipe
-            sys.stdout.flush()
-            os.dup2(saved, 1)
-            os.close(saved)
-
+        _quiet_init(args.backend, rank, world, dev)
     from nfmc_amd.dist import Shard
     shard = Shard(rank=rank, world=world) if distributed else None
 
-    n_total = N_PER_GPU * world
-    gen = torch.Generator(device='cpu').manual_seed(0)
-    x0 = (torch.randn(n_total, D, generator=gen) * 0.7071).to(dev)   # resident in HBM before the timed region
+    n_local = cfg['n_per_gpu']
+    n_total = n_local * world
+    x_start = initial_state(cfg, n_total).to(dev)   # resident in HBM before any timed region
 
-    def run(n_outer, time_kernels=False):
-        s = build_sampler(n_outer)
+    def run(n_steps, x, time_kernels=False):
+        s = build_sampler(cfg, n_steps, fit_nf=args.fit_nf)
         s.seed = 0
         s.shard = shard
         s.time_kernels = time_kernels
@@ -135,90 +410,88 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
-        out = s.sample(x0, show_progress=False)
+        out = s.sample(x, show_progress=False)
         torch.cuda.synchronize(dev)
         if distributed:
             dist.barrier()
         return time.perf_counter() - t0, out
 
-    # one-time initialisation outside the timed region whatever W is: library load, code-object load of the two
-    # kernels (first launch), allocator warm-up -- ONE outer step of the same path at the same per-GPU size, so that
-    # every launch a profiler sees has the same shape (per-kernel averages agree with the HIP-event mean below)
-    prime = build_sampler(1)
+    def carried(out, x_prev):
+        """The state after a run as the next run's x0 (global shape: every rank writes back its own block)."""
+        last = out.running_samples.last_sample.reshape(-1, cfg['d'])
+        if shard is None:
+            return last
+        lo, hi = shard.bounds(n_total)
+        x_next = x_prev.clone()
+        x_next[lo:hi] = last
+        return x_next
+
+    # one-time initialisation outside the timed region whatever W is: library / code-object load, allocator warm-up,
+    # weight packing -- ONE step of the same path at the same per-GPU size (every launch a profiler sees has the same
+    # shape, so per-kernel averages agree with the HIP-event mean below)
+    prime = build_sampler(cfg, 1)
     prime.seed = 0
-    prime.sample(x0[:N_PER_GPU], show_progress=False)
+    prime.sample(x_start[:n_local], show_progress=False)
     torch.cuda.synchronize(dev)
-    if args.warmup > 0:
-        run(args.warmup)
-    # CPython's cyclic collector must not fire inside the timed region: with torch imported a full (generation 2)
-    # collection takes ~35 ms on this host -- five times the 20 timed steps -- and its trigger depends on allocation
-    # counts, i.e. on luck.  Collect now, keep it off while timing (reference counting still frees everything the
-    # run allocates), turn it back on afterwards.
+    if args.warmup > 0:   # untimed; moves the state from x0 ~ N(0, I) to stationarity
+        _dt, wout = run(args.warmup, x_start)
+        x_start = carried(wout, x_start)
+    # CPython's cyclic collector must not fire inside a timed region (a generation-2 pass is ~35 ms with torch
+    # imported, several times one repetition): collect now, keep it off while timing.
     gc.collect()
     gc.disable()
-    # HIP events only around the dominant kernel's launches: every event pair costs ~6 us of stream time
-    dt, out = run(args.steps, time_kernels=False if args.no_kernel_events else 'mala_steps')
+    reps = []
+    label = cfg['label']
+    for _ in range(args.reps):
+        dt, out = run(args.steps, x_start, time_kernels=False if args.no_kernel_events else label)
+        dt_max, per_rank = _reduce_times(dt, world, dist, dev)
+        ev = [a.elapsed_time(b) for (l, a, b) in (getattr(out, 'kernel_events', None) or []) if l == label]
+        reps.append((dt_max, per_rank, out, ev))
     gc.enable()
-    if distributed:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    # dominant-kernel duration from the HIP events recorded on the launch stream during the timed region
-    ev = [(l, a.elapsed_time(b)) for (l, a, b) in (out.kernel_events or [])]
-    mala_ms = [ms for (l, ms) in ev if l == 'mala_steps']
-    jump_ms = [ms for (l, ms) in ev if l == 'flow_mh_steps']
-    mean_mala = sum(mala_ms) / max(1, len(mala_ms))
-    alg_bytes_per_launch = 8 * D * N_PER_GPU * K_INNER
-    achieved = alg_bytes_per_launch / (mean_mala * 1e-3) / 1e9 if mala_ms else None
-    traffic = None
-    tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get('mala_kernel_hbm_bytes_per_launch')
-        except Exception:
-            traffic = None
-
-    # what actually binds the kernel, from the committed PMC passes of this same command (profiles/): VALU wave
-    # instructions per coordinate-transition and the share of the launch the VALU was issuing
-    valu = None
-    ppath = os.path.join(ROOT, 'profiles', 'r01_bench_pmc_summary.json')
-    if os.path.exists(ppath):
-        try:
-            pm = json.load(open(ppath))['mala_kernel']
-            valu = {'insts_per_coordinate_transition': pm['SQ_INSTS_VALU'] * 64 / (N_PER_GPU * D * K_INNER),
-                    'busy_frac': (pm['SQ_ACTIVE_INST_VALU'] / 256) / (pm['GRBM_GUI_ACTIVE'] / 8),
-                    'source': 'profiles/r01_bench_pmc_summary.json (SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU, GRBM_GUI_ACTIVE)'}
-        except Exception:
-            valu = None
 
     if rank == 0:
-        value = n_total * (K_INNER + 1) * args.steps / dt
+        order = sorted(range(len(reps)), key=lambda i: reps[i][0])
+        med = order[len(order) // 2]
+        dt, per_rank, out, _ev = reps[med]
+        all_ev = [ms for r_ in reps for ms in r_[3]]
+        # what one HIP-event pair brackets: one launch of the inner kernel (C3: 100 MALA transitions, C5: 5
+        # trajectories); for C4 one nfmc_neutra_hmc_steps_f32 call = K trajectory launches; for C2 one
+        # nfmc_imh_parallel_f32 call = the three kernels of K*50 transitions (reported as ONE "launch")
+        launches_per_event = args.steps if cfg['strategy'] == 'neutra_hmc' else 1
+        mean_ms = (sum(all_ev) / len(all_ev) / launches_per_event) if all_ev else None
+        n_launches = len(all_ev) * launches_per_event
+        transitions_per_launch = cfg['inner'] * (args.steps if cfg['strategy'] == 'imh' else 1)
         st = out.statistics
+        value = n_total * cfg['transitions_per_step'] * args.steps / dt
+        rep_ms = [1e3 * r_[0] for r_ in reps]
         line = {
-            'metric': 'chain-steps/sec (n_chains x iters / s), jump_mala + RealNVP, d=64',
-            'value': value, 'unit': 'chain-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'BASELINE configs[2]: jump_mala + realnvp, U=sum x^2 (N(0, I/2)), d=64, '
-                                   '65536 chains per GPU, 100 MALA transitions per jump, step 0.25',
-                       'n_chains_total': n_total, 'n_chains_per_gpu': N_PER_GPU, 'n_dim': D, 'inner_steps': K_INNER,
-                       'transitions_per_step': K_INNER + 1, 'store_samples': False,
-                       'sharding': f'chains x{world}, no data-path collective; one statistics all-reduce per sample()'},
-            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': (achieved / HBM_PEAK_GBS) if achieved else None, 'traffic': traffic,
-                         'kernel': 'mala_kernel', 'mean_launch_ms': mean_mala, 'launches': len(mala_ms),
-                         'algorithmic_bytes_per_launch': alg_bytes_per_launch, 'valu': valu,
-                         'note': 'state stays in VGPRs for the 100 transitions of a launch: real HBM traffic (traffic) << '
-                                 'algorithmic bytes; the kernel is VALU-issue bound (Philox4x32-10 + Box-Muller + MALA '
-                                 'arithmetic), so frac vs the HBM roof can exceed 1',
-                         'flow_mh_mean_launch_ms': (sum(jump_ms) / len(jump_ms)) if jump_ms else None},
+            'metric': cfg['metric'], 'value': value, 'unit': 'chain-steps/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': cfg['workload'], 'name': args.config, 'n_chains_total': n_total,
+                       'n_chains_per_gpu': n_local, 'n_dim': cfg['d'], 'inner_steps': cfg['inner'],
+                       'transitions_per_step': cfg['transitions_per_step'], 'store_samples': False,
+                       'x0': 'N(0, I), torch.manual_seed(0) on the CPU, uploaded before timing; W warm-up steps carry it '
+                             'to stationarity' + (' (x 0.5 for the funnel)' if cfg['strategy'] == 'neutra_hmc' else ''),
+                       'fit_nf': bool(args.fit_nf),
+                       'sharding': f'chains x{world}, no data-path collective; one statistics all-reduce per sample()'
+                                   + ('; refit-buffer all-gather every outer iteration' if args.fit_nf else '')},
+            'repetitions': len(reps), 'rep_ms': rep_ms, 'rep_ms_median': statistics.median(rep_ms),
+            'rep_ms_min': min(rep_ms), 'rep_ms_max': max(rep_ms),
+            'world_size_reported_by_backend': dist.get_world_size() if dist is not None else 1,
+            'per_rank_ms': [1e3 * v for v in per_rank],
+            'roofline': roofline(args.config, cfg, n_local, mean_ms, n_launches, transitions_per_launch),
             'parity': {'mean_abs_max': float(out.mean.abs().max()), 'variance_mean': float(out.variance.mean()),
-                       'variance_rel_err_max': float(((out.variance - 0.5).abs() / 0.5).max()),
-                       'mcmc_acceptance': st.acceptance_rate, 'jump_acceptance': st.jump_acceptance_rate},
+                       'mcmc_acceptance': st.acceptance_rate},
         }
+        if cfg['strategy'] != 'neutra_hmc':   # U = sum x^2: N(0, I/2)
+            line['parity']['variance_rel_err_max'] = float(((out.variance - 0.5).abs() / 0.5).max())
+            line['parity']['second_moment_rel_err_max'] = float(((out.second_moment - 0.5).abs() / 0.5).max())
+        if hasattr(st, 'jump_acceptance_rate'):
+            line['parity']['jump_acceptance'] = st.jump_acceptance_rate
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline()
+            line['parity']['vs_cpu_oracle_same_seeds'] = parity_vs_oracle(cfg, dev)
+            line['cpu_baseline'] = cpu_baseline(cfg)
         else:
             line['cpu_baseline'] = None
         print(json.dumps(line), flush=True)

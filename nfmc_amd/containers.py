@@ -296,6 +296,7 @@ class MCMCOutput:
     kernel: Optional[MCMCKernel] = None
     store_samples: bool = True
     max_samples: int = None
+    kernel_events: Any = None   # bench.py: (label, start, end) HIP events of the launches, when kernel timing was on
 
     def __post_init__(self):
         self.event_shape = _shape(self.event_shape)

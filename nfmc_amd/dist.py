@@ -48,6 +48,27 @@ class Shard:
         tdist.broadcast(t, src=0, group=self.group)
         return int(t.item())
 
+    def _scalar(self, value, dtype):
+        dev = 'cpu' if tdist.get_backend(self.group) == 'gloo' else torch.device('cuda', torch.cuda.current_device())
+        return torch.tensor([value], dtype=dtype, device=dev)
+
+    def all_reduce_min_int(self, value: int) -> int:
+        """The smallest `value` over the ranks (row counts agreed before an all-gather of equal shares)."""
+        if self._single():
+            return int(value)
+        t = self._scalar(int(value), torch.int64)
+        tdist.all_reduce(t, op=tdist.ReduceOp.MIN, group=self.group)
+        return int(t.item())
+
+    def all_reduce_mean_(self, t: torch.Tensor, weight: float) -> torch.Tensor:
+        """In place: the `weight`-weighted mean of `t` over the ranks (per-rank statistics of unequal chain blocks)."""
+        if self._single():
+            return t
+        pack = torch.cat([t.detach().reshape(-1).double() * weight, t.new_tensor([weight]).double()])
+        self.all_reduce_sum_(pack)
+        t.copy_((pack[:-1] / pack[-1]).reshape(t.shape).to(t.dtype))
+        return t
+
     def all_gather_rows(self, rows: torch.Tensor) -> torch.Tensor:
         """C1: concatenate every rank's (k, ...) block in rank order (equal k on every rank)."""
         if self._single():

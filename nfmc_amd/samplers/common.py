@@ -100,6 +100,18 @@ class Run:
     def sync(self):
         torch.cuda.synchronize(self.dev)
 
+    def time_is_up(self, t0, limit_seconds) -> bool:
+        """The `time_limit_seconds` test of the sampling loops (mcmc/base.py:70-72).  With sharded chains rank 0's clock
+        decides for everybody, so all ranks stop after the same number of steps (their later collectives -- the refit
+        all-gather, the statistics all-reduce -- must see the same shapes)."""
+        if limit_seconds is None:
+            return False
+        self.sync()
+        up = time.time() - t0 >= limit_seconds
+        if self.shard is not None and self.shard.world > 1:
+            up = bool(self.shard.broadcast_int(1 if up else 0))
+        return up
+
     def elapsed(self):
         self.sync()
         return time.time() - self.t0

@@ -92,10 +92,8 @@ class FixedIMH(AbstractIMH):
         if not fused:
             logq.copy_(flow.log_prob(run.x.reshape(n, *event_shape)).detach().to(run.dev, torch.float32))  # imh.py:214
         while done < T:
-            if time_limit_seconds is not None:
-                run.sync()
-                if time.time() - t0 >= time_limit_seconds:
-                    break
+            if run.time_is_up(t0, time_limit_seconds):
+                break
             k = min(limit, T - done) if fused else 1
             if fused and parallel and unlimited:
                 # all proposals of the chunk at once: as many steps as 2^26 work items (1 GiB of work arrays) allow
@@ -126,10 +124,10 @@ class FixedIMH(AbstractIMH):
         out.running_samples.last_sample = run.x.reshape(n, *event_shape).clone()
         st.update_elapsed_time(time.time() - t0)
         out.kernel = self.kernel
+        out.kernel_events = run.kernel_events
         if run.shard is not None:
             run.shard.merge_statistics(st)
         return out
-
 
 
 class HostDraws:
@@ -206,10 +204,8 @@ class AdaptiveIMH(AbstractIMH):
         done, n_refits = 0, 0
         bar = tqdm(total=T, desc=self.name, disable=not show_progress)
         for i in range(T):
-            if time_limit_seconds is not None:
-                run.sync()
-                if time.time() - t0 >= time_limit_seconds:
-                    break
+            if run.time_is_up(t0, time_limit_seconds):
+                break
             if fused:
                 launch_flow_mh(run, flow, pot, logq, 1, i, False, True,
                                run.stats.struct(defer=True, attempted=n), buf[i:i + 1])              # :121-134

@@ -290,10 +290,8 @@ class JumpNFMC(Sampler):
         done = 0
         bar = tqdm(range(T), desc='Jump MCMC', disable=not show_progress)
         for i in bar:
-            if time_limit_seconds is not None:
-                run.sync()
-                if time.time() - t0 >= time_limit_seconds:
-                    break
+            if run.time_is_up(t0, time_limit_seconds):
+                break
             base = i * (K + 1)
             inner_view = buf[base:base + K] if buf is not None else fit_buf
             # ---- K inner transitions (jump.py:178); when the flow is narrow the jump rides at the end of

@@ -156,10 +156,8 @@ class MCMCSampler(Sampler):
         stepwise = self.params.tuning or pot is None
         limit = 1 if stepwise else (hip.MAX_STEPS_PER_CALL if time_limit_seconds is None and not show_progress else 32)
         while done < K:
-            if time_limit_seconds is not None:
-                run.sync()
-                if time.time() - t0 > time_limit_seconds:
-                    break
+            if run.time_is_up(t0, time_limit_seconds):
+                break
             k = min(limit, K - done)
             view = buf[done:done + k] if buf is not None else None
             if pot is not None:
@@ -189,6 +187,7 @@ class MCMCSampler(Sampler):
         rs.last_sample = run.x.reshape(n, *event_shape).clone()
         out.statistics.update_elapsed_time(time.time() - t0)
         out.kernel = self.kernel
+        out.kernel_events = run.kernel_events
         self._cur_run = None
         if run.shard is not None:
             run.shard.merge_statistics(out.statistics)
@@ -219,17 +218,34 @@ class MCMCSampler(Sampler):
 
 class MetropolisSampler(MCMCSampler):
     def update_kernel(self, data: Dict[str, Any]):
-        """mcmc/base.py:142-161: EMA of the per-coordinate variance + dual-averaging step size."""
+        """mcmc/base.py:142-161: EMA of the per-coordinate variance + dual-averaging step size.  With sharded chains
+        the variance and the acceptance rate are those of ALL chains (one all-reduce of [sum x, sum x^2, n, accepted]),
+        so every rank tunes the same kernel."""
         x = data['x']
         mask = data['mask']
+        shard = getattr(self, 'shard', None)
+        sharded = shard is not None and shard.world > 1
         n_chains = x.shape[0]
+        flat = x.flatten(1, -1)
+        acc_rate = None
+        if sharded:
+            d = flat.shape[1]
+            xd = flat.double()
+            pack = torch.cat([xd.sum(0), (xd * xd).sum(0),
+                              xd.new_tensor([float(n_chains), float(mask.sum()) if mask is not None else 0.0])])
+            shard.all_reduce_sum_(pack)
+            n_all = float(pack[2 * d])
+            n_chains = int(round(n_all))
+            var_all = ((pack[d:2 * d] - pack[:d] ** 2 / n_all) / max(n_all - 1.0, 1.0)).float()
+            acc_rate = float(pack[2 * d + 1]) / n_all
         if n_chains > 1 and self.params.tune_inv_mass_diag:
-            var = torch.var(x.flatten(1, -1), dim=0).to(self.kernel.inv_mass_diag)
+            var = (var_all if sharded else torch.var(flat, dim=0)).to(self.kernel.inv_mass_diag)
             self.kernel.inv_mass_diag = (self.params.imd_adjustment * var
                                          + (1 - self.params.imd_adjustment) * self.kernel.inv_mass_diag)
         if self.params.tune_step_size and self.params.adjustment:
-            acc_rate = torch.mean(mask.float())
-            error = self.kernel.da_params.target_acceptance_rate - float(acc_rate)
+            if acc_rate is None:
+                acc_rate = float(torch.mean(mask.float()))
+            error = self.kernel.da_params.target_acceptance_rate - acc_rate
             self.kernel.da.step(error)
             self.kernel.step_size = self.kernel.da.value
 

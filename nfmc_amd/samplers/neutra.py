@@ -164,10 +164,8 @@ class NeuTra(Sampler):
         limit = hip.MAX_STEPS_PER_CALL if (time_limit_seconds is None and not show_progress) else 4
         bar = tqdm(total=T, desc='NeuTra HMC', disable=not show_progress)
         while done < T:
-            if time_limit_seconds is not None:
-                run.sync()
-                if time.time() - t0 >= time_limit_seconds:
-                    break
+            if run.time_is_up(t0, time_limit_seconds):
+                break
             k = min(limit, T - done)
             a = hip.NfmcNeutraHmcArgs()
             a.z, a.n, a.n_steps = hip.ptr(run.x), n, k
@@ -182,7 +180,8 @@ class NeuTra(Sampler):
             a.samples = hip.ptr(buf[done:done + k]) if buf is not None else None
             a.scratch, a.scratch_bytes = hip.ptr(scratch), sbytes
             try:
-                hip.check(hip.lib().nfmc_neutra_hmc_steps_f32(C.byref(a), hip.stream()), 'nfmc_neutra_hmc_steps_f32')
+                with run.timed('neutra_hmc_steps'):
+                    hip.check(hip.lib().nfmc_neutra_hmc_steps_f32(C.byref(a), hip.stream()), 'nfmc_neutra_hmc_steps_f32')
             except hip.NfmcArgumentError as e:
                 if done == 0 and e.no_kernel:   # validation precedes every launch: nothing has run yet
                     bar.close()
@@ -206,6 +205,7 @@ class NeuTra(Sampler):
         st.update_elapsed_time(time.time() - t0)
         out.kernel = inner.kernel
         out.kernel.flow = self.kernel.flow  # neutra.py:128
+        out.kernel_events = run.kernel_events
         if run.shard is not None:
             run.shard.merge_statistics(st)
         return out

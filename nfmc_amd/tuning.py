@@ -57,14 +57,25 @@ def train_val_split(x: torch.Tensor, train_pct: float, max_train_size: int, max_
     """(n_iterations, n_chains, *event) -> (x_train, x_val): all (step, chain) rows pooled, shuffled, cut at
     `train_pct` and capped (tuning.py:44-65).
 
-    With `shard` (chains split over GPUs) every rank contributes an equal share of the capped buffer, drawn from its
-    own shuffled rows, and the shares are all-gathered (collective C1 of SURVEY 8e): every rank then fits the flow
-    on the same rows, in rank order."""
+    With `shard` (chains split over GPUs; collective C1 of SURVEY 8e) every rank contributes the same number of rows
+    of the capped buffer, drawn from its own shuffled rows, and the shares are all-gathered.  The row count is agreed
+    first (all-reduce MIN of what every rank can give: block sizes differ by one when the chain count does not divide,
+    and a time limit can leave ranks with different numbers of kept steps), so the collective always sees equal
+    sizes.  The gathered rows are then shuffled AGAIN with a seed broadcast from rank 0 before the `train_pct` cut:
+    train and validation both mix rows of every rank (a cut in rank order would validate on the last ranks' chains
+    only), and every rank fits the flow on the same rows in the same order."""
     rows = x.flatten(0, 1)
     if shard is not None and shard.world > 1:
         share = -(-(max_train_size + max_val_size) // shard.world)
+        share = shard.all_reduce_min_int(min(share, rows.shape[0]))
+        if share <= 0:
+            raise ValueError('train_val_split: a rank has no rows to contribute to the refit buffer')
         local = _shuffled(rows) if shuffle else rows
         rows = shard.all_gather_rows(local[:share].contiguous())
+        if shuffle:
+            seed = shard.broadcast_int(int(torch.randint(0, 2 ** 62, ()).item()))
+            perm = torch.randperm(rows.shape[0], generator=torch.Generator().manual_seed(seed))
+            rows = rows[perm.to(rows.device)]
     elif shuffle:
         rows = _shuffled(rows)
     cut = int(train_pct * rows.shape[0])

@@ -1,0 +1,261 @@
+"""GPU parity at the EXACT combinations BASELINE.json names (configs[2..4] = C3, C4, C5 of SURVEY.md section 8d):
+the same strategy x target x event size x conditioner x trajectory length the bench lines are quoted on, against the
+CPU oracle on the native Philox streams at a chain count the oracle finishes in seconds, and -- at the configs' full
+chain counts -- through size-independent properties (moments of the known target, run-twice bitwise identity,
+shard invariance: rows simulated alone equal the slice of the full run).
+
+Reference semantics followed: jump.py:156-246 (outer loop), langevin.py:61-122, hmc.py:96-126 (inner transitions),
+neutra.py:58-68,109-129 (adjusted target + HMC in latent space).
+Tolerance: fp32 states agree to 2e-4 .. 1e-3 (stated per test, scaled with the depth of the computation) on every
+chain whose accept decisions are not within 1e-4 of a tie; moments within 1e-3 relative of the oracle's / 5e-3 of the
+analytic value on finite runs.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'GPU tests need a ROCm device'
+    return torch.device('cuda', 0)
+
+
+def _pair_flows(d, seed, scale, target_std=None, n_layers=2, ck=None):
+    """The same RealNVP weights as a CPU oracle flow and as the package's flow."""
+    from nfmc_amd.flows import Flow, RealNVP
+    from oracle import flow as oflow
+    kw = {'conditioner_kwargs': ck} if ck else {}
+    of = oflow.perturb_(oflow.Flow(oflow.RealNVP((d,), n_layers=n_layers, **kw)), seed, scale, target_std)
+    f = Flow(RealNVP((d,), n_layers=n_layers, **kw))
+    f.load_state_dict(of.state_dict())
+    return of, f
+
+
+def _agreeing(got, want, tol):
+    err = (got - want).abs().amax(dim=(0, 2))
+    return err < tol
+
+
+# ================================================================================================ C3
+def test_C3_jump_mala_d64_k100_matches_oracle(dev):
+    """configs[2] at n = 256: jump_mala, U = sum x^2, d = 64, K = 100 inner MALA transitions (h = 64^(-1/3)) per
+    jump, default RealNVP architecture (perturbed weights so that jumps are accepted), 2 outer iterations = 202
+    transitions per chain, every one compared with the oracle."""
+    from nfmc_amd.containers import NFMCKernel
+    from nfmc_amd.potentials import SumOfSquares
+    from nfmc_amd.samplers import jump, mcmc
+    from oracle import potentials as opot, samplers as osamp
+    d, n, T, K, seed = 64, 256, 2, 100, 20240
+    torch.manual_seed(3)
+    of, f = _pair_flows(d, 7, 0.05, 0.7071)
+    x0 = torch.randn(n, d)
+    s = jump.JumpMALA((d,), SumOfSquares((d,)), NFMCKernel((d,), flow=f), jump.JumpNFMCParameters(n_iterations=T),
+                      None, mcmc.LangevinParameters(n_iterations=K))
+    s.seed = seed
+    out = s.sample(x0, show_progress=False)
+    tr = osamp.jump_sample(x0, opot.sum_squares, of, 'langevin', T, K, d ** (-1 / 3), noise=osamp.PhiloxNoise(seed))
+    got, want = out.samples.reshape(T * (K + 1), n, d), tr.stacked()
+    same = _agreeing(got, want, 3e-4)
+    # a near-tie flip changes the whole later trajectory of that chain; 202 accept tests per chain
+    assert same.float().mean() > 0.9, float(same.float().mean())
+    np.testing.assert_allclose(got[:, same].numpy(), want[:, same].numpy(), atol=3e-4, rtol=0)
+    st = out.statistics
+    assert st.n_attempted_trajectories == n * T * K and st.n_attempted_jumps == n * T
+    assert abs(st.n_accepted_trajectories - tr.n_accepted) <= 0.01 * n * T * K
+    assert abs(st.n_accepted_jumps - tr.n_accepted_jumps) <= max(3, 0.03 * n * T)
+    np.testing.assert_allclose(out.mean.numpy(), tr.moments.first.numpy(), atol=5e-3)
+    np.testing.assert_allclose(out.second_moment.numpy(), tr.moments.second.numpy(), rtol=2e-2)
+
+
+def test_C3_jump_mala_65536x64_full_size_properties(dev):
+    """configs[2] at its full size (65536 chains, d = 64, 100 MALA + 1 jump per outer iteration): moments of
+    N(0, I/2) (README.md:45-46), counters, run-twice bitwise identity, shard invariance."""
+    from nfmc_amd import sample
+    from nfmc_amd.dist import Shard
+    from nfmc_amd.potentials import SumOfSquares
+    d, n, T, K = 64, 65536, 4, 100
+    x0 = torch.randn(n, d, generator=torch.Generator().manual_seed(0))
+
+    def run(x, shard=None, T=T):
+        torch.manual_seed(1)   # flow weights
+        return sample(SumOfSquares((d,)), strategy='jump_mala', flow='realnvp', x0=x, n_iterations=T,
+                      show_progress=False, seed=0, shard=shard, inner_param_kwargs={'n_iterations': K},
+                      param_kwargs={'store_samples': False})
+
+    # burn-in from N(0, I) to the stationary N(0, I/2), then measure
+    burn = run(x0, T=1)
+    xs = burn.running_samples.last_sample
+    a, b = run(xs), run(xs)
+    assert a.samples is None
+    st = a.statistics
+    assert st.n_attempted_trajectories == n * T * K and st.n_attempted_jumps == n * T
+    assert st.n_target_calls == 2 * n * T * K + 2 * n * T and st.n_target_gradient_calls == 2 * n * T * K
+    assert float(a.mean.abs().max()) < 3e-3
+    np.testing.assert_allclose(a.variance.numpy(), 0.5, rtol=5e-3)
+    np.testing.assert_allclose(a.second_moment.numpy(), 0.5, rtol=5e-3)
+    assert 0.2 < st.acceptance_rate < 0.9
+    # run twice: bit for bit
+    assert torch.equal(a.running_samples.last_sample, b.running_samples.last_sample)
+    assert torch.equal(a.statistics.expectations['second_moment'].total, b.statistics.expectations['second_moment'].total)
+    assert st.n_accepted_trajectories == b.statistics.n_accepted_trajectories
+    assert st.n_accepted_jumps == b.statistics.n_accepted_jumps
+    # shard invariance: the middle block of a 4-way split simulated alone equals its slice of the full run
+    sh = Shard(rank=1, world=4)
+    sh.merge_statistics = lambda s_: s_
+    part = run(xs, shard=sh)
+    lo, hi = sh.bounds(n)
+    assert torch.equal(part.running_samples.last_sample, a.running_samples.last_sample[lo:hi])
+
+
+# ================================================================================================ C4
+def _c4_sampler(f, T, L, h, d=128):
+    from nfmc_amd.potentials import Funnel
+    from nfmc_amd.samplers import mcmc, neutra
+    return neutra.NeuTraHMC((d,), Funnel((d,), 3.0), mcmc.HMCKernel(event_size=d, n_leapfrog_steps=L, step_size=h),
+                            mcmc.HMCParameters(), neutra.NeuTraKernel((d,), flow=f),
+                            neutra.NeuTraParameters(n_iterations=T))
+
+
+def _no_split(sampler):
+    def boom(*a, **k):
+        raise AssertionError('NeuTra took the split path: the fused matrix-core kernel did not run')
+    sampler.inner_sampler.sample = boom
+
+
+def test_C4_neutra_hmc_funnel_d128_h128x2_L10_matches_oracle(dev):
+    """configs[3] at n = 150: neutra_hmc, funnel potential, d = 128, conditioner 128 x 2 hidden layers, L = 10
+    leapfrog steps on `neutra_leapfrog_mfma_kernel<8,8,2>` (fp32 MFMA), every transition compared with the oracle
+    (autograd through the CPU flow restatement, neutra.py:58-68 under hmc.py:96-126)."""
+    from oracle import potentials as opot, samplers as osamp
+    d, n, T, L, h, seed = 128, 150, 3, 10, 0.02, 404
+    torch.manual_seed(11)
+    of, f = _pair_flows(d, 13, 0.08, ck={'n_hidden': 128, 'n_layers': 2})
+    z0 = 0.5 * torch.randn(n, d)
+    s = _c4_sampler(f, T, L, h)
+    _no_split(s)
+    s.seed = seed
+    out = s.sample(z0, show_progress=False)
+    tr = osamp.neutra_hmc_sample(z0, opot.funnel(3.0), of, T, h, None, L, noise=osamp.PhiloxNoise(seed))
+    got, want = out.samples.reshape(T, n, d), tr.stacked()
+    # 2L + 2 = 22 flow passes per transition, each a 128-wide 3-GEMM conditioner per coupling layer: fp32 sums in a
+    # different order than torch's CPU GEMM -> 1e-3 on O(1) states
+    same = _agreeing(got, want, 1e-3)
+    assert same.float().mean() > 0.95, float(same.float().mean())
+    np.testing.assert_allclose(got[:, same].numpy(), want[:, same].numpy(), atol=1e-3, rtol=0)
+    st = out.statistics
+    assert st.n_attempted_trajectories == n * T
+    assert abs(st.n_accepted_trajectories - tr.n_accepted) <= 4
+    assert st.n_target_calls == (2 * L + 2) * n * T and st.n_target_gradient_calls == 2 * L * n * T   # hmc.py:122-125
+    np.testing.assert_allclose(out.mean.numpy(), tr.moments.first.numpy(), atol=3e-3)
+    np.testing.assert_allclose(out.second_moment.numpy(), tr.moments.second.numpy(), atol=5e-3)
+
+
+def test_C4_neutra_hmc_65536x128_full_size_properties(dev):
+    """configs[3] at its full size (65536 chains): finite states, acceptance, run-twice bitwise identity and shard
+    invariance of one trajectory launch of the matrix-core kernel; energy conservation of the integrator (the
+    Hamiltonian error of an L = 10, h = 0.02 trajectory stays small, so most proposals are accepted)."""
+    from nfmc_amd.dist import Shard
+    d, n, T, L, h = 128, 65536, 2, 10, 0.02
+    torch.manual_seed(11)
+    _of, f = _pair_flows(d, 13, 0.08, ck={'n_hidden': 128, 'n_layers': 2})
+    z0 = 0.5 * torch.randn(n, d, generator=torch.Generator().manual_seed(5))
+
+    def run(shard=None):
+        s = _c4_sampler(f, T, L, h)
+        _no_split(s)
+        s.params.store_samples = False
+        s.seed = 9
+        s.shard = shard
+        return s.sample(z0, show_progress=False)
+
+    a, b = run(), run()
+    la = a.running_samples.last_sample
+    assert torch.isfinite(la).all()
+    assert a.statistics.n_attempted_trajectories == n * T
+    assert a.statistics.acceptance_rate > 0.6
+    assert torch.equal(la, b.running_samples.last_sample)
+    assert a.statistics.n_accepted_trajectories == b.statistics.n_accepted_trajectories
+    sh = Shard(rank=2, world=8)
+    sh.merge_statistics = lambda s_: s_
+    lo, hi = sh.bounds(n)
+    part = run(sh)
+    assert torch.equal(part.running_samples.last_sample, la[lo:hi])
+
+
+# ================================================================================================ C5
+def test_C5_jump_hmc_d256_k5_L20_matches_oracle(dev):
+    """configs[4] at n = 100: jump_hmc, U = sum x^2, d = 256, K = 5 inner HMC trajectories (sample.py:161-162) of
+    L = 20 leapfrog steps (the HMCKernel default, hmc.py:10-18), default RealNVP, every transition compared."""
+    from nfmc_amd.containers import NFMCKernel
+    from nfmc_amd.potentials import SumOfSquares
+    from nfmc_amd.samplers import jump, mcmc
+    from oracle import potentials as opot, samplers as osamp
+    d, n, T, K, L, h, seed = 256, 100, 3, 5, 20, 0.05, 555
+    torch.manual_seed(21)
+    of, f = _pair_flows(d, 3, 0.03, 0.7071)
+    x0 = torch.randn(n, d)
+    s = jump.JumpHMC((d,), SumOfSquares((d,)), NFMCKernel((d,), flow=f), jump.JumpNFMCParameters(n_iterations=T),
+                     mcmc.HMCKernel(event_size=d, n_leapfrog_steps=L, step_size=h), mcmc.HMCParameters(n_iterations=K))
+    s.seed = seed
+    out = s.sample(x0, show_progress=False)
+    tr = osamp.jump_sample(x0, opot.sum_squares, of, 'hmc', T, K, h, n_leapfrog=L, noise=osamp.PhiloxNoise(seed))
+    got, want = out.samples.reshape(T * (K + 1), n, d), tr.stacked()
+    same = _agreeing(got, want, 5e-4)
+    assert same.float().mean() > 0.9, float(same.float().mean())
+    np.testing.assert_allclose(got[:, same].numpy(), want[:, same].numpy(), atol=5e-4, rtol=0)
+    st = out.statistics
+    assert st.n_attempted_trajectories == n * T * K and st.n_attempted_jumps == n * T
+    assert st.n_target_gradient_calls == 2 * L * n * T * K                       # hmc.py:122-125
+    assert st.n_target_calls == (2 * L + 2) * n * T * K + 2 * n * T              # + jump.py:212-213
+    assert abs(st.n_accepted_trajectories - tr.n_accepted) <= max(3, 0.02 * n * T * K)
+    assert abs(st.n_accepted_jumps - tr.n_accepted_jumps) <= max(3, 0.04 * n * T)
+
+
+def test_C5_jump_hmc_32768x256_shard_properties(dev):
+    """configs[4], one GPU's shard at full size (32768 of the 262144 chains, global chain ids of rank 3 of 8):
+    moments of N(0, I/2), run-twice bitwise identity, and equality with the same rows simulated as part of a larger
+    block (the property that makes G = 1/2/4/8 runs identical)."""
+    from nfmc_amd import sample
+    from nfmc_amd.dist import Shard
+    from nfmc_amd.potentials import SumOfSquares
+    d, n_global, T = 256, 262144, 8
+    sh8 = Shard(rank=3, world=8)
+    sh8.merge_statistics = lambda s_: s_
+    lo, hi = sh8.bounds(n_global)
+    n = hi - lo
+    assert n == 32768
+
+    class Rows:   # x0 of the global problem without materialising 262144 x 256 on the host: only shape and slices
+        shape = (n_global, d)
+
+        def __getitem__(self, sl):
+            assert sl.stop - sl.start in (32768, 65536)
+            blocks = [torch.randn(32768, d, generator=torch.Generator().manual_seed(100 + b)) * 0.7071
+                      for b in range(sl.start // 32768, sl.stop // 32768)]
+            return torch.cat(blocks)
+
+    def run(shard, T=T):
+        torch.manual_seed(1)
+        return sample(SumOfSquares((d,)), strategy='jump_hmc', flow='realnvp', x0=Rows(), n_iterations=T,
+                      show_progress=False, seed=0, shard=shard,
+                      inner_kernel_kwargs={'n_leapfrog_steps': 20, 'step_size': 0.05},
+                      param_kwargs={'store_samples': False})
+
+    a, b = run(sh8), run(sh8)
+    st = a.statistics
+    assert st.n_attempted_trajectories == n * T * 5 and st.n_attempted_jumps == n * T
+    assert float(a.mean.abs().max()) < 4e-3
+    np.testing.assert_allclose(a.variance.numpy(), 0.5, rtol=6e-3)
+    assert st.acceptance_rate > 0.5
+    assert torch.equal(a.running_samples.last_sample, b.running_samples.last_sample)
+    assert st.n_accepted_trajectories == b.statistics.n_accepted_trajectories
+    # the same rows as the second half of rank 1 of a 4-way split (65536 chains per rank)
+    sh4 = Shard(rank=1, world=4)
+    sh4.merge_statistics = lambda s_: s_
+    lo4, hi4 = sh4.bounds(n_global)
+    assert lo4 <= lo and hi <= hi4
+    c = run(sh4)
+    assert torch.equal(c.running_samples.last_sample[lo - lo4:hi - lo4], a.running_samples.last_sample)

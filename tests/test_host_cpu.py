@@ -257,6 +257,36 @@ gathered = [torch.empty_like(both) for _ in range(world)]
 dist.all_gather(gathered, both)
 assert all(torch.equal(g, gathered[0]) for g in gathered)
 assert (both.mean(1) > 5).any() and (both.mean(1) < 5).any()   # rows from both ranks
+# the gathered buffer is shuffled again (seed from rank 0) before the 70 % cut: train AND validation mix both ranks
+local = torch.randn(8, 16, d) + 10 * rank
+tr, va = train_val_split(local, 0.7, 64, 64, shard=sh)
+assert tr.shape[0] == 64 and va.shape[0] == 128 - int(0.7 * 128), (tr.shape, va.shape)
+for part in (tr, va):
+    assert (part.mean(1) > 5).any() and (part.mean(1) < 5).any(), 'rank-ordered cut'
+# uneven blocks (5 chains over 2 ranks: 3 + 2) and fewer rows than the share: the row count is agreed by an
+# all-reduce MIN, so the all-gather sees equal sizes on every rank
+lo, hi = sh.bounds(5)
+local = torch.randn(3, hi - lo, d) + 10 * rank          # 9 rows on rank 0, 6 on rank 1
+tr, va = train_val_split(local, 0.7, 4096, 4096, shard=sh)
+assert tr.shape[0] + va.shape[0] == 12 and tr.shape[0] == int(0.7 * 12), (tr.shape, va.shape)
+both = torch.cat([tr, va])
+gathered = [torch.empty_like(both) for _ in range(world)]
+dist.all_gather(gathered, both)
+assert all(torch.equal(g, gathered[0]) for g in gathered)
+assert sh.all_reduce_min_int(7 - rank) == 7 - (world - 1)
+# update_kernel's all-reduced tuning statistics: both ranks end with the kernel of the unsharded run
+from nfmc_amd.samplers import mcmc
+xs = torch.randn(10, d, generator=torch.Generator().manual_seed(9)) * 2
+ms = torch.rand(10, generator=torch.Generator().manual_seed(10)) > 0.4
+def tuned(shard, rows, mask):
+    smp = mcmc.MALA((d,), lambda v: (v ** 2).sum(-1))
+    smp.shard = shard
+    smp.update_kernel({'x': rows, 'mask': mask})
+    return smp.kernel.inv_mass_diag, smp.kernel.step_size
+lo, hi = sh.bounds(10)
+imd_s, h_s = tuned(sh, xs[lo:hi], ms[lo:hi])
+imd_1, h_1 = tuned(None, xs, ms)
+assert torch.allclose(imd_s, imd_1, atol=1e-6) and abs(h_s - h_1) < 1e-6, (imd_s, imd_1, h_s, h_1)
 dist.barrier()
 dist.destroy_process_group()
 print('ok', rank)
@@ -502,3 +532,21 @@ def test_flow_copy_state_and_kernel_shape_limits():
     assert RealNVP((16,), conditioner_kwargs={'n_hidden': 129}).beyond_kernels()
     assert not CRQNSF((16,), conditioner_kwargs={'n_hidden': 32}).beyond_kernels()
     assert CRQNSF((16,), conditioner_kwargs={'n_hidden': 33}).beyond_kernels()
+
+
+def test_bench_launcher_starts_one_process_per_gpu():
+    """`python bench.py --gpus 2` without torchrun: the parent starts two fresh ranks before touching any GPU, they
+    rendezvous (gloo here, nccl = RCCL on the GPU box: same code up to the backend name), and exactly ONE JSON line
+    comes back on stdout, carrying n_gpus = 2 and the world size the backend itself reported."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--rehearse',
+                        '--reps', '3'], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['world_size_reported_by_backend'] == 2 and len(line['per_rank_ms']) == 2
+    # under a launcher that already set WORLD_SIZE (torchrun) the same file is one rank and spawns nothing
+    src = open(os.path.join(ROOT, 'bench.py')).read()
+    assert "'WORLD_SIZE' not in os.environ and args.gpus > 1" in src
