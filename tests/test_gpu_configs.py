@@ -248,7 +248,7 @@ def test_C5_jump_hmc_32768x256_shard_properties(dev):
     st = a.statistics
     assert st.n_attempted_trajectories == n * T * 5 and st.n_attempted_jumps == n * T
     assert float(a.mean.abs().max()) < 4e-3
-    np.testing.assert_allclose(a.variance.numpy(), 0.5, rtol=6e-3)
+    np.testing.assert_allclose(a.variance.numpy(), 0.5, rtol=8e-3)   # sigma_rel = 1.35e-3 per coordinate at T = 8 (tools/probe_c5_var.py)
     assert st.acceptance_rate > 0.5
     assert torch.equal(a.running_samples.last_sample, b.running_samples.last_sample)
     assert st.n_accepted_trajectories == b.statistics.n_accepted_trajectories
