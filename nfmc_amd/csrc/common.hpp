@@ -182,11 +182,19 @@ __device__ __forceinline__ float group_broadcast0(float v) {
     return __shfl(v, (int)(threadIdx.x & 63) & ~(LPC - 1), kWave);
 }
 
-// Sum over the lanes of a wave that hold the SAME coordinates of DIFFERENT chains (stride LPC).
+// Sum over the lanes of a wave that hold the SAME coordinates of DIFFERENT chains (stride LPC), in fp32: the
+// addends are each lane's fp32 partial sums over the launch's transitions, at most 64 of them meet here, and the
+// result is widened to fp64 before it joins the other waves' sums.  Steps inside a 16-lane row are DPP moves, the
+// two across rows go through ds_bpermute: for LPC = 8 one DPP + two permutes per value instead of the six permutes
+// and three v_add_f64 of a double butterfly (the epilogue was ~25 % of a one-tile-per-wave flow-MH launch).
 template <int LPC>
-__device__ __forceinline__ double cross_chain_reduce(double v) {
-#pragma unroll
-    for (int m = LPC; m < kWave; m <<= 1) v += __shfl_xor(v, m, kWave);
+__device__ __forceinline__ float cross_chain_reduce(float v) {
+    if constexpr (LPC <= 1) v = dpp_add<0xB1>(v);
+    if constexpr (LPC <= 2) v = dpp_add<0x4E>(v);
+    if constexpr (LPC <= 4) v += dpp_xor4(v);
+    if constexpr (LPC <= 8) v += dpp_mov<0x128>(v);   // row_ror:8 : lane ^ 8 within the row
+    if constexpr (LPC <= 16) v += __shfl_xor(v, 16, kWave);
+    if constexpr (LPC <= 32) v += __shfl_xor(v, 32, kWave);
     return v;
 }
 
@@ -334,8 +342,8 @@ __device__ __forceinline__ void block_stats_flush(const float (&sx)[CPL], const 
     const int g = lane % LPC;
 #pragma unroll
     for (int i = 0; i < CPL; ++i) {
-        const double a = cross_chain_reduce<LPC>((double)sx[i]);
-        const double b = cross_chain_reduce<LPC>((double)sxx[i]);
+        const double a = (double)cross_chain_reduce<LPC>(sx[i]);
+        const double b = (double)cross_chain_reduce<LPC>(sxx[i]);
         if (lane < LPC) {
             red[wave][coord_of<CPL, LPC>(g, i)] = a;
             red[wave][DP + coord_of<CPL, LPC>(g, i)] = b;

@@ -36,8 +36,9 @@ namespace nfmc {
 //   b1 HP | [HP rows of HP + 4: row u = weights INTO unit u, position r = from unit u ^ unit_xor(r) | bh[u] | 0 0 0] x (n_hl - 1)
 //   W3 (DP x RS): row s = [(alpha weight, beta weight) x HP | b3_alpha | b3_beta | is_target | 0] (zeros if not target);
 //       distributed: pair r belongs to hidden unit (g % HP) ^ unit_xor(r)
-// followed, after all layers, by the ElementwiseAffine parameters per slot:
-//   ea0_ls | ea0_sh | ea1_ls | ea1_sh   (DP each; ea1 already mapped through the final reversal)
+// followed, after all layers, by the ElementwiseAffine parameters as eight planes of DP floats (slot-indexed, so the
+// lanes of a chain read consecutive words: conflict free):
+//   e^ls0 | sh0 | e^-ls0 | ls0 | e^ls1 | sh1 | e^-ls1 | ls1   (ea1 already mapped through the final reversal)
 // EXACT (d == DP, CPL >= 8): a layer's sources are one half of every lane's registers and its targets the other
 // half, so W1 keeps only the source slots' rows and W3 only the target slots' rows (DP/2 each, indexed by
 // (i - first register of the half) * LPC + g): half the image -- 31 instead of 62 KB at d = 256, HP = 8, which
@@ -52,81 +53,130 @@ struct FlowImage {
     static constexpr int HL = DIST ? HP * HROW : HP * HP + HP;  // floats per hidden layer after the first
     __host__ __device__ static int mid_floats(int n_hl) { return HP + (n_hl - 1) * HL; }
     __host__ __device__ static int layer_floats(int n_hl) { return ROWS * HP + mid_floats(n_hl) + ROWS * RS; }
-    __host__ __device__ static int total_floats(int n_hl, int n_coupling) { return n_coupling * layer_floats(n_hl) + 4 * DP; }
+    static constexpr int EA = 8;   // ElementwiseAffine planes of DP floats: e^ls0, sh0, e^-ls0, ls0, e^ls1, sh1, e^-ls1, ls1
+    __host__ __device__ static int total_floats(int n_hl, int n_coupling) { return n_coupling * layer_floats(n_hl) + EA * DP; }
 
-    // all `nthreads` threads of the workgroup; blob layout: flow_device.hpp (W1T | b1 | [WhT | bh] | W3 | b3).
-    // One thread builds one slot's rows (no per-element index arithmetic): staging used to cost ~13 us per
-    // workgroup at d = 256 (two integer divisions per element), most of the jump kernel's time.
+    // One slot's rows of one coupling layer (registers; loads only, so that a caller can issue the loads of several
+    // items before it stores any of them).
+    struct SlotRows {
+        float r1[HP], r3[RS];
+        bool src, tgt;
+    };
+    __device__ static __forceinline__ SlotRows load_slot(const NfmcRealNVP& f, int l, int s, int bmid) {
+        // 32-bit offsets from the (wave-uniform) blob base: scalar base + one VGPR offset per load instead of a 64-bit
+        // address pair per load (the hoisted loads of a thread would otherwise cost ~2 VGPRs each)
+        const int d = f.d, d_a = d / 2, d_b = d - d_a;
+        const bool rev = (l & 1) == 0;
+        const float* __restrict__ B = f.weights;
+        const int W = l * (int)f.layer_stride;
+        const int W3 = W + d_a * HP + bmid;
+        const int b3 = W3 + 2 * d_b * HP;
+        const int c = coord_of<CPL, LPC>(s % LPC, s / LPC);
+        const int j = rev ? d - 1 - c : c;
+        SlotRows o;
+        o.src = c < d && j < d_a;
+        o.tgt = c < d && j >= d_a;
+        const int w1 = W + (o.src ? j : 0) * HP;
+        const int tt = o.tgt ? j - d_a : 0;
+        const int wa = W3 + tt * HP;
+        const int wb = W3 + (d_b + tt) * HP;
+        const int ub = (s % LPC) % HP;                       // the slot's lane class
+#pragma unroll
+        for (int k = 0; k < HP; ++k) {
+            const int kk = DIST ? (ub ^ unit_xor<HP>(k)) : k;
+            const float a1 = B[w1 + k], aa = B[wa + kk], ab = B[wb + kk];   // always in bounds: predication below, not on the loads
+            o.r1[k] = o.src ? a1 : 0.f;
+            o.r3[2 * k] = o.tgt ? aa : 0.f;
+            o.r3[2 * k + 1] = o.tgt ? ab : 0.f;
+        }
+        const float ba = B[b3 + tt], bb = B[b3 + d_b + tt];
+        o.r3[2 * HP] = o.tgt ? ba : 0.f;
+        o.r3[2 * HP + 1] = o.tgt ? bb : 0.f;
+        o.r3[2 * HP + 2] = o.tgt ? 1.f : 0.f;
+        o.r3[2 * HP + 3] = 0.f;
+        return o;
+    }
+    __device__ static __forceinline__ void store_slot(float* __restrict__ img, const SlotRows& o, int l, int s, int lf, int nmid) {
+        float* w = img + l * lf;
+        float* w3 = w + ROWS * HP + nmid;
+        // EXACT: registers [0, CPL/2) are the first half of the coordinates; row within the half's block
+        const int sh = EXACT ? (s >= DP / 2 ? s - DP / 2 : s) : s;
+        if (!EXACT || o.src) {
+#pragma unroll
+            for (int k = 0; k < HP; k += 4)
+                *reinterpret_cast<float4*>(w + sh * HP + k) = make_float4(o.r1[k], o.r1[k + 1], o.r1[k + 2], o.r1[k + 3]);
+        }
+        if (!EXACT || o.tgt) {
+#pragma unroll
+            for (int k = 0; k < RS; k += 4)
+                *reinterpret_cast<float4*>(w3 + sh * RS + k) = make_float4(o.r3[k], o.r3[k + 1], o.r3[k + 2], o.r3[k + 3]);
+        }
+    }
+    __device__ static __forceinline__ void store_ea(float* __restrict__ ea, int s, float l0, float h0, float l1, float h1) {
+        ea[s] = fast_exp(l0);
+        ea[DP + s] = h0;
+        ea[2 * DP + s] = fast_exp(-l0);
+        ea[3 * DP + s] = l0;
+        ea[4 * DP + s] = fast_exp(l1);
+        ea[5 * DP + s] = h1;
+        ea[6 * DP + s] = fast_exp(-l1);
+        ea[7 * DP + s] = l1;
+    }
+    // element t of a layer's middle part (b1 and the hidden layers after the first): offset in the layer's blob, -1 = zero
+    __device__ static __forceinline__ int mid_src(int d_a, int t) {
+        const int m0 = d_a * HP;   // b1 | [WhT | bh] ...
+        if (!DIST || t < HP) return m0 + t;
+        const int hl = (t - HP) / HL, e = (t - HP) % HL;
+        const int sw = m0 + HP + hl * (HP * HP + HP);   // WhT[in][out] | bh
+        const int u = e / HROW, r = e % HROW;
+        return r < HP ? sw + (u ^ unit_xor<HP>(r)) * HP + u : (r == HP ? sw + HP * HP + u : -1);
+    }
+
+    // All `nthreads` threads of the workgroup; blob layout: flow_device.hpp (W1T | b1 | [WhT | bh] | W3 | b3).
+    // The image is a permutation of a few KB that sit in L2, so building it costs global-load LATENCY, not bandwidth:
+    // the first version walked layers, middle parts and the elementwise-affine vectors in separate loops, i.e. 5-7
+    // dependent global round trips (~2 us of an 11 us one-tile launch at d = 64, 6-12 us at d = 256).  Here every
+    // thread first ISSUES the loads of everything it will store -- one slot row, one middle element, one slot of
+    // elementwise-affine parameters; addresses clamped instead of branching, so they form one basic block with one
+    // wait -- and then stores; whatever exceeds that (DP = 512, deep conditioners) follows in plain loops.
     __device__ static void stage(float* __restrict__ img, const NfmcRealNVP& f, int nthreads) {
-        const int d = f.d, d_a = d / 2, d_b = d - d_a, n_hl = f.n_hidden_layers;
+        const int d = f.d, d_a = d / 2, n_hl = f.n_hidden_layers;
         const int lf = layer_floats(n_hl);
         const int nmid = mid_floats(n_hl);                        // image
         const int bmid = HP + (n_hl - 1) * (HP * HP + HP);        // blob
-        for (int l = 0; l < f.n_coupling; ++l) {
-            const bool rev = (l & 1) == 0;
-            const float* W = f.weights + l * f.layer_stride;
-            const float* W3 = W + d_a * HP + bmid;
-            const float* b3 = W3 + 2 * d_b * HP;
-            float* o = img + l * lf;
-            float* o3 = o + ROWS * HP + nmid;
-            for (int s = threadIdx.x; s < DP; s += nthreads) {
-                const int c = coord_of<CPL, LPC>(s % LPC, s / LPC);
-                const int j = rev ? d - 1 - c : c;
-                const bool src = c < d && j < d_a, tgt = c < d && j >= d_a;
-                const float* w1 = W + (src ? j : 0) * HP;
-                const int tt = tgt ? j - d_a : 0;
-                const float* wa = W3 + tt * HP;
-                const float* wb = W3 + (d_b + tt) * HP;
-                const int ub = (s % LPC) % HP;                       // the slot's lane class
-                float r1[HP], r3[RS];
-#pragma unroll
-                for (int k = 0; k < HP; ++k) {
-                    const int kk = DIST ? (ub ^ unit_xor<HP>(k)) : k;
-                    r1[k] = src ? w1[k] : 0.f;
-                    r3[2 * k] = tgt ? wa[kk] : 0.f;
-                    r3[2 * k + 1] = tgt ? wb[kk] : 0.f;
-                }
-                r3[2 * HP] = tgt ? b3[tt] : 0.f;
-                r3[2 * HP + 1] = tgt ? b3[d_b + tt] : 0.f;
-                r3[2 * HP + 2] = tgt ? 1.f : 0.f;
-                r3[2 * HP + 3] = 0.f;
-                // EXACT: registers [0, CPL/2) are the first half of the coordinates; row within the half's block
-                const int sh = EXACT ? (s >= DP / 2 ? s - DP / 2 : s) : s;
-                if (!EXACT || src) {
-#pragma unroll
-                    for (int k = 0; k < HP; k += 4)
-                        *reinterpret_cast<float4*>(o + sh * HP + k) = make_float4(r1[k], r1[k + 1], r1[k + 2], r1[k + 3]);
-                }
-                if (!EXACT || tgt) {
-#pragma unroll
-                    for (int k = 0; k < RS; k += 4)
-                        *reinterpret_cast<float4*>(o3 + sh * RS + k) = make_float4(r3[k], r3[k + 1], r3[k + 2], r3[k + 3]);
-                }
-            }
-            if constexpr (DIST) {
-                for (int t = threadIdx.x; t < HP; t += nthreads) o[ROWS * HP + t] = W[d_a * HP + t];
-                for (int hl = 1; hl < n_hl; ++hl) {
-                    const float* sw = W + d_a * HP + HP + (hl - 1) * (HP * HP + HP);   // WhT[in][out] | bh
-                    float* dw = o + ROWS * HP + HP + (hl - 1) * HL;
-                    for (int t = threadIdx.x; t < HL; t += nthreads) {
-                        const int u = t / HROW, r = t % HROW;
-                        dw[t] = r < HP ? sw[(u ^ unit_xor<HP>(r)) * HP + u] : (r == HP ? sw[HP * HP + u] : 0.f);
-                    }
-                }
-            } else {
-                for (int t = threadIdx.x; t < nmid; t += nthreads) o[ROWS * HP + t] = W[d_a * HP + t];
-            }
-        }
-        float* ea = img + f.n_coupling * lf;
+        const int t = threadIdx.x;
+        const int nA = f.n_coupling * DP, nB = f.n_coupling * nmid;
         const bool revl = (f.n_coupling & 1) != 0;
-        for (int s = threadIdx.x; s < DP; s += nthreads) {
+        // ---- loads
+        const int a0 = t < nA ? t : 0;
+        const SlotRows ra = load_slot(f, a0 / DP, a0 % DP, bmid);
+        const int b0 = t < nB ? t : 0;
+        const int mo = mid_src(d_a, b0 % nmid);
+        const float mv = f.weights[(b0 / nmid) * (int)f.layer_stride + (mo < 0 ? 0 : mo)];
+        const int s0 = t < DP ? t : 0;
+        const int p0 = coord_of<CPL, LPC>(s0 % LPC, s0 / LPC);
+        const bool ok0 = p0 < d;
+        const int pc = ok0 ? p0 : 0, cc = revl ? d - 1 - pc : pc;   // logical latent coordinate held at position p
+        const float ls0 = f.ea0_log_scale[pc], sh0 = f.ea0_shift[pc], ls1 = f.ea1_log_scale[cc], sh1 = f.ea1_shift[cc];
+        // ---- stores
+        if (t < nA) store_slot(img, ra, a0 / DP, a0 % DP, lf, nmid);
+        if (t < nB) img[(b0 / nmid) * lf + ROWS * HP + b0 % nmid] = mo < 0 ? 0.f : mv;
+        float* ea = img + f.n_coupling * lf;
+        if (t < DP) {
+            store_ea(ea, s0, ok0 ? ls0 : 0.f, ok0 ? sh0 : 0.f, ok0 ? ls1 : 0.f, ok0 ? sh1 : 0.f);
+        }
+        // ---- the rest (more than one slot row / one middle element / one slot per thread: d > 128 or deep conditioners)
+        for (int a = t + nthreads; a < nA; a += nthreads) store_slot(img, load_slot(f, a / DP, a % DP, bmid), a / DP, a % DP, lf, nmid);
+        for (int b = t + nthreads; b < nB; b += nthreads) {
+            const int q = mid_src(d_a, b % nmid);
+            img[(b / nmid) * lf + ROWS * HP + b % nmid] = q < 0 ? 0.f : f.weights[(b / nmid) * (int)f.layer_stride + q];
+        }
+        for (int s = t + nthreads; s < DP; s += nthreads) {
             const int p = coord_of<CPL, LPC>(s % LPC, s / LPC);
             const bool ok = p < d;
-            const int c = revl ? d - 1 - p : p;  // logical latent coordinate held at position p
-            ea[s] = ok ? f.ea0_log_scale[p] : 0.f;
-            ea[DP + s] = ok ? f.ea0_shift[p] : 0.f;
-            ea[2 * DP + s] = ok ? f.ea1_log_scale[c] : 0.f;
-            ea[3 * DP + s] = ok ? f.ea1_shift[c] : 0.f;
+            const int c = revl ? d - 1 - p : p;
+            store_ea(ea, s, ok ? f.ea0_log_scale[p] : 0.f, ok ? f.ea0_shift[p] : 0.f, ok ? f.ea1_log_scale[c] : 0.f,
+                     ok ? f.ea1_shift[c] : 0.f);
         }
     }
 };
@@ -171,7 +221,7 @@ struct FlowB {
     static_assert(!EXACT || CPL >= 8, "EXACT needs whole register quads per half");
     const float* img;  // LDS
     int n_hl, n_coupling, lf, g;
-    float m, log1m;
+    float m, log1m, ea_ls;
 
     __device__ __forceinline__ void init(const float* lds_img, const NfmcRealNVP& f, int g_) {
         img = lds_img;
@@ -181,6 +231,11 @@ struct FlowB {
         m = f.min_scale;
         log1m = __logf(1.f - f.min_scale);
         g = g_;
+        // this lane's share of the (state-independent) log-determinant of the two ElementwiseAffine layers
+        const float* ea = img + n_coupling * lf + g;
+        ea_ls = 0.f;
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) ea_ls += ea[3 * DP + i * LPC] + ea[7 * DP + i * LPC];
     }
 
     // Make the image pointer opaque to the optimiser.  The weights are loop-invariant across the chain tiles of
@@ -286,43 +341,29 @@ struct FlowB {
         }
     }
 
-    // x -> z (z left in physical positions); returns this lane's share of logdet_forward
+    // x -> z (z left in physical positions); returns this lane's share of logdet_forward.  The ElementwiseAffine
+    // planes of the image carry e^ls and e^-ls (no transcendental per coordinate) and the lane's share of sum(ls) is a
+    // constant of the flow (ea_ls, summed once in init()).
     __device__ __forceinline__ float forward(float (&x)[CPL]) const {
         const float* ea = img + n_coupling * lf + g;
-        float ld = 0.f;
+        float ld = ea_ls;
 #pragma unroll
-        for (int i = 0; i < CPL; ++i) {
-            const float ls = ea[i * LPC];
-            x[i] = fmaf(fast_exp(ls), x[i], ea[DP + i * LPC]);
-            ld += ls;
-        }
+        for (int i = 0; i < CPL; ++i) x[i] = fmaf(ea[i * LPC], x[i], ea[DP + i * LPC]);
         for (int l = 0; l < n_coupling; ++l) ld += coupling<false>(x, l);
 #pragma unroll
-        for (int i = 0; i < CPL; ++i) {
-            const float ls = ea[2 * DP + i * LPC];
-            x[i] = fmaf(fast_exp(ls), x[i], ea[3 * DP + i * LPC]);
-            ld += ls;
-        }
+        for (int i = 0; i < CPL; ++i) x[i] = fmaf(ea[4 * DP + i * LPC], x[i], ea[5 * DP + i * LPC]);
         return ld;
     }
 
     // z (physical positions) -> x; returns this lane's share of logdet_inverse
     __device__ __forceinline__ float inverse(float (&x)[CPL]) const {
         const float* ea = img + n_coupling * lf + g;
-        float ld = 0.f;
+        float ld = -ea_ls;
 #pragma unroll
-        for (int i = 0; i < CPL; ++i) {
-            const float ls = ea[2 * DP + i * LPC];
-            x[i] = (x[i] - ea[3 * DP + i * LPC]) * fast_exp(-ls);
-            ld -= ls;
-        }
+        for (int i = 0; i < CPL; ++i) x[i] = (x[i] - ea[5 * DP + i * LPC]) * ea[6 * DP + i * LPC];
         for (int l = n_coupling - 1; l >= 0; --l) ld += coupling<true>(x, l);
 #pragma unroll
-        for (int i = 0; i < CPL; ++i) {
-            const float ls = ea[i * LPC];
-            x[i] = (x[i] - ea[DP + i * LPC]) * fast_exp(-ls);
-            ld -= ls;
-        }
+        for (int i = 0; i < CPL; ++i) x[i] = (x[i] - ea[DP + i * LPC]) * ea[2 * DP + i * LPC];
         return ld;
     }
 };

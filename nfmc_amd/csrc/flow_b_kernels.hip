@@ -6,7 +6,10 @@
 
 namespace nfmc {
 
-template <int CPL, int LPC, int HP, template <int, int, bool> class Pot, bool FAST>
+// DIAG = false is the production instantiation: no replayed noise, no sample store, no mask / log-ratio outputs --
+// the branches on those pointers (and the scalar registers that carry them through the tile loop: the DIAG kernel
+// spills SGPRs into VGPR lanes there) are compiled out.  The host picks it when all of those arguments are NULL.
+template <int CPL, int LPC, int HP, template <int, int, bool> class Pot, bool FAST, bool DIAG>
 #ifndef NFMC_FLOWB_WPE
 #define NFMC_FLOWB_WPE 1
 #endif
@@ -65,7 +68,7 @@ __global__ void __launch_bounds__(kBlock, NFMC_FLOWB_WPE) flow_mh_b_kernel(NfmcF
         }
         for (int s = 0; s < a.n_steps; ++s) {
             float xp[CPL];
-            draw_latent<CPL, LPC, FAST>(xp, a.rng.replay_normals ? a.rng.replay_normals + (int64_t)s * n * d : nullptr, a.rng.seed,
+            draw_latent<CPL, LPC, FAST>(xp, (DIAG && a.rng.replay_normals) ? a.rng.replay_normals + (int64_t)s * n * d : nullptr, a.rng.seed,
                                   a.rng.step0 + (uint32_t)s, gchain, row, n, d, g, revl);  // flow.sample: jump.py:205 / imh.py:221
             float part = 0.f;
 #pragma unroll
@@ -83,7 +86,7 @@ __global__ void __launch_bounds__(kBlock, NFMC_FLOWB_WPE) flow_mh_b_kernel(NfmcF
             bool accept = true;
             if (a.adjusted) {
                 float u;
-                if (a.rng.replay_uniforms) {
+                if (DIAG && a.rng.replay_uniforms) {
                     u = active ? a.rng.replay_uniforms[(int64_t)s * n + row] : 0.5f;
                 } else {
                     const uint4 r = philox4x32_10(gchain, a.rng.step0 + (uint32_t)s, 0u, kTagJump, (uint32_t)a.rng.seed,
@@ -104,8 +107,8 @@ __global__ void __launch_bounds__(kBlock, NFMC_FLOWB_WPE) flow_mh_b_kernel(NfmcF
                 sx[i] += x[i];
                 sxx[i] = fmaf(x[i], x[i], sxx[i]);
             }
-            if (a.samples) store_row<CPL, LPC, FAST>(a.samples + (int64_t)s * n * d, row, d, g, active, x);
-            if (g == 0 && active) {
+            if (DIAG && a.samples) store_row<CPL, LPC, FAST>(a.samples + (int64_t)s * n * d, row, d, g, active, x);
+            if (DIAG && g == 0 && active) {
                 if (a.masks_out) a.masks_out[(int64_t)s * n + row] = accept ? 1 : 0;
                 if (a.log_ratio_out) a.log_ratio_out[(int64_t)s * n + row] = lr;
             }
@@ -131,7 +134,9 @@ static int launch_b(const NfmcFlowMhArgs& a, bool fast, int64_t tiles, int grid,
                                                                                        a.flow.n_coupling) * sizeof(float); \
         if (lds > 120 * 1024) return NFMC_EUNSUPPORTED;                                                         \
         if (dry) return 0;                                                                                      \
-        auto kern = flow_mh_b_kernel<CPL, LPC, HP, POT, F>;                                                     \
+        const bool diag = !F || a.rng.replay_normals || a.rng.replay_uniforms || a.samples || a.masks_out ||    \
+                          a.log_ratio_out;                                                                      \
+        auto kern = diag ? flow_mh_b_kernel<CPL, LPC, HP, POT, F, true> : flow_mh_b_kernel<CPL, LPC, HP, POT, F, (F ? false : true)>; \
         if (lds > 48 * 1024) {                                                                                  \
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,   \
                                                (int)lds);                                                       \
@@ -173,8 +178,11 @@ int flow_mh_b_launch(const NfmcFlowMhArgs& a, hipStream_t st, int* grid_out, int
                       (((uintptr_t)a.x) & 15u) == 0 && (!a.samples || (((uintptr_t)a.samples) & 15u) == 0);
     const int cpw = kWave / c.lpc;
     const int64_t tiles = (a.n + (int64_t)kWavesPerBlock * cpw - 1) / ((int64_t)kWavesPerBlock * cpw);
-    int gcap = 512;  // ~2 resident workgroups per CU: the weight image is staged once per workgroup, so fewer,
-                     // longer-lived workgroups amortise it (C3 jump: 51 us per outer step next to the sampler at 512, 61 us at 2048)
+    // Persistent workgroups: the weight image is staged once per workgroup and every wave pays a fixed prologue /
+    // statistics epilogue, so fewer, longer-lived workgroups amortise both, while more of them hide the latency of a
+    // transition's dependent chain.  Measured (rocprofv3, tools/ab_jump.sh): C3 jump (65536 x 64) 26.1 / 23.1 / 25.4 us
+    // at 512 / 1024 / 2048 workgroups; C5 jump (32768 x 256, image 35 KB) 61.6 / 65.6 / 73.9 us.
+    int gcap = dp <= 128 ? 1024 : 512;
     if (const char* e = getenv("NFMC_FLOWB_GRID")) gcap = atoi(e) > 0 ? atoi(e) : gcap;
     const int grid = (int)(tiles < gcap ? tiles : gcap);
     if (a.stats.sum_x && a.stats.scratch_bytes < (int64_t)grid * (2 * dp + kStatTail) * (int64_t)sizeof(double))
