@@ -351,6 +351,8 @@ class Sampler:
         self.target = target
         self.kernel = kernel
         self.params = params
+        self.fuse = 'auto'    # 'auto': a plain callable target that potentials.recognize() reproduces as a quadratic
+                              # is evaluated in closed form inside the kernels; False / 'never': always call it
         self.seed = None      # native-stream seed; None: drawn from torch's global RNG per sample() call
         self.shard = None     # dist.Shard when the chains are split over GPUs
         self.replay = None    # (normals, uniforms) to replay instead of the native streams (parity tests)

@@ -7,11 +7,13 @@ The reference's own potential objects live in the absent third-party package `po
 `Funnel` is the build's C4 potential.
 
 `recognize(target, event_shape)` lets plain Python callables such as the README's
-`lambda x: torch.sum(x**2, dim=1)` take the fused path: it probes the callable on a few points,
-fits U = sum_j a_j (x_j - b_j)^2 + c and accepts it only if the fit reproduces the callable (and its
-autograd gradient) on fresh points at several scales to 1e-5 relative.
+`lambda x: torch.sum(x**2, dim=1)` take the fused path: it probes the callable, fits
+U = sum_j a_j (x_j - b_j)^2 + c and accepts it only if the fit reproduces the callable (and its autograd
+gradient) on fresh points at radii from 0.1 to 100 and around the run's own x0 to 1e-5 relative.  It is an
+inference from finitely many probes (see its docstring); `fuse='never'` turns it off.
 """
 import ctypes as C
+import logging
 import math
 from typing import Optional, Sequence, Tuple, Union
 
@@ -111,8 +113,21 @@ class Funnel(Potential):
         return hip.NfmcPotential(hip.POT_FUNNEL, 0, None, None, self.scale, 0.0)
 
 
-def recognize(target, event_shape, rtol: float = 1e-5) -> Optional[Potential]:
-    """Return a QuadraticPotential equal to `target`, or None.  Never guesses: any probe mismatch -> None."""
+_log = logging.getLogger('nfmc_amd')
+_announced = set()
+
+
+def recognize(target, event_shape, rtol: float = 1e-5, x_scale: float = None) -> Optional[Potential]:
+    """A QuadraticPotential that reproduces the plain callable `target` on every probe below, or None.
+
+    This is an inference from finitely many evaluations, not a proof: a callable that is quadratic on all probed
+    points and something else elsewhere (walls or modes beyond the probed radii), or one that changes between calls,
+    would be sampled as the fitted Gaussian.  The probes therefore cover, besides the unit directions used for the
+    fit, random points at radii 0.1 ... 100 per coordinate AND at 1x / 3x / 10x the largest |x0| of the run
+    (`x_scale`), a repeated evaluation (stateful / stochastic targets differ), and the autograd gradient; any mismatch,
+    non-finite value or exception -> None (the sampler then takes the split path, where an exception of the target
+    surfaces unchanged).  The first time a callable is rerouted one line is logged on the `nfmc_amd` logger.  Opt out
+    with `sample(..., fuse='never')` / `sampler.fuse = False`, or pass a `Potential` to be explicit."""
     if isinstance(target, Potential):
         return target
     d = int(math.prod(event_shape))
@@ -133,12 +148,17 @@ def recognize(target, event_shape, rtol: float = 1e-5) -> Optional[Potential]:
             const = c0 - (a * b * b).sum()
             if not torch.isfinite(a).all() or not torch.isfinite(b).all() or (a < 0).any():
                 return None
-            for scale in (0.1, 1.0, 7.0):
+            scales = [0.1, 1.0, 7.0, 30.0, 100.0]
+            if x_scale is not None and math.isfinite(x_scale) and x_scale > 0:
+                scales += [x_scale, 3.0 * x_scale, 10.0 * x_scale]
+            for scale in scales:
                 x = scale * torch.randn(8, *event_shape, generator=g, dtype=torch.float64)
                 want = target(x).reshape(-1).double()
                 got = (a * (x.reshape(8, -1) - b) ** 2).sum(-1) + const
                 if not torch.allclose(got, want, rtol=rtol, atol=rtol * (1 + want.abs().max())):
                     return None
+            if not torch.equal(target(x).reshape(-1).double(), want):   # same input, same answer
+                return None
         # gradient check through autograd (catches targets that detach / are piecewise)
         with torch.enable_grad():
             x = torch.randn(4, *event_shape, generator=g, dtype=torch.float64).requires_grad_(True)
@@ -152,4 +172,10 @@ def recognize(target, event_shape, rtol: float = 1e-5) -> Optional[Potential]:
     def simplify(v):
         return float(v[0]) if bool((v == v[0]).all()) else v.float()
 
+    key = getattr(target, '__qualname__', None) or type(target).__name__
+    if key not in _announced:
+        _announced.add(key)
+        _log.warning('nfmc_amd: target %r reproduces U(x) = sum_j a_j (x_j - b_j)^2 + c on every probe (radii up to %.3g); '
+                     'it is evaluated in closed form inside the HIP kernels.  Pass fuse="never" to sample() to keep '
+                     'calling the Python callable.', key, max(scales))
     return QuadraticPotential(tuple(event_shape), simplify(a), simplify(b))

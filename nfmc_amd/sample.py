@@ -125,7 +125,13 @@ def sample(target: Union[callable, Potential],
            sampling_time_limit_seconds: Union[float, int] = None,
            warmup_time_limit_seconds: Union[float, int] = None,
            **kwargs) -> MCMCOutput:
-    """nfmc/sample.py:243-314."""
+    """nfmc/sample.py:243-314.  Keywords beyond the reference's (all optional):
+      seed   native Philox stream seed (default: drawn from torch's global generator)
+      shard  nfmc_amd.dist.Shard when the chains are split over GPUs
+      fuse   'auto' (default): a plain callable `target` that probing reproduces exactly as
+             U = sum_j a_j (x_j - b_j)^2 + c (potentials.recognize: an inference from finitely many evaluations,
+             logged once) is evaluated in closed form inside the HIP kernels; 'never' / False: always call the Python
+             callable (U and grad U by torch autograd on the GPU, the reference's recipe)."""
     if flow == 'None':
         flow = None
     if flow is not None and not isinstance(flow, str):
@@ -138,6 +144,7 @@ def sample(target: Union[callable, Potential],
         event_shape = tuple(x0.shape[1:])   # (the reference fails on `*None` here)
     seed = kwargs.pop('seed', None)
     shard = kwargs.pop('shard', None)
+    fuse = kwargs.pop('fuse', 'auto')
     if 'param_kwargs' not in kwargs:
         kwargs['param_kwargs'] = {}
     kwargs['param_kwargs'] = {**kwargs['param_kwargs'],
@@ -145,6 +152,7 @@ def sample(target: Union[callable, Potential],
     sampler = create_sampler(target=target, event_shape=event_shape, flow=flow, strategy=strategy, **kwargs)
     sampler.seed = seed
     sampler.shard = shard
+    sampler.fuse = fuse
     if x0 is None:
         x0 = torch.randn(size=(n_chains, *event_shape))  # drawn after flow construction, sample.py:304-305
     if warmup:

@@ -10,13 +10,18 @@ from .. import hip
 from ..potentials import Potential, recognize
 
 
-def resolve_target(target, event_shape, fuse='auto') -> Optional[Potential]:
-    """A closed-form descriptor for `target`, or None (-> split path: torch autograd for U, grad U)."""
+def resolve_target(target, event_shape, fuse='auto', x0=None) -> Optional[Potential]:
+    """A closed-form descriptor for `target`, or None (-> split path: torch autograd for U, grad U).
+    fuse: 'auto' (default) probes plain callables (potentials.recognize; `x0` sets the radii the probes must also
+    cover); False / 'never' keeps every plain callable on the split path."""
     if isinstance(target, Potential):
         return target
     if fuse in (False, 'never'):
         return None
-    return recognize(target, event_shape)
+    x_scale = None
+    if x0 is not None and x0.numel() > 0:
+        x_scale = float(x0.detach().abs().max())
+    return recognize(target, event_shape, x_scale=x_scale)
 
 
 class Replay:
@@ -32,6 +37,15 @@ class Replay:
             self.uniforms = torch.as_tensor(uniforms, dtype=torch.float32).to(device).contiguous()
         self.i_n = 0
         self.i_u = 0
+
+    def take_uniforms(self, k=1):
+        """The uniforms of k transitions alone.  The split path draws them only once every target call of the step
+        has returned, like the reference (langevin.py:106, hmc.py:112, jump.py:225): a step whose target raised never
+        consumes its uniforms."""
+        un = self.uniforms[self.i_u:self.i_u + k]
+        assert un.shape[0] == k, 'replay uniforms exhausted'
+        self.i_u += k
+        return un
 
     def take(self, k, with_uniforms=True):
         nz = self.normals[self.i_n:self.i_n + k]

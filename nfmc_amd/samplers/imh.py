@@ -78,7 +78,7 @@ class FixedIMH(AbstractIMH):
         out = MCMCOutput(event_shape, store_samples=self.params.store_samples)
         flow = self.kernel.flow
         T = int(self.params.n_iterations)
-        pot = resolve_target(self.target, event_shape)
+        pot = resolve_target(self.target, event_shape, self.fuse, run.x)
         fused = pot is not None and flow_is_native(flow)
         buf = torch.empty(T, n, d, dtype=torch.float32, device=run.dev) if (self.params.store_samples and T > 0) else None
         logq = torch.empty(n, dtype=torch.float32, device=run.dev)
@@ -194,7 +194,7 @@ class AdaptiveIMH(AbstractIMH):
         out = MCMCOutput(event_shape, store_samples=True)
         flow = self.kernel.flow
         T = int(self.params.n_iterations)
-        pot = resolve_target(self.target, event_shape)
+        pot = resolve_target(self.target, event_shape, self.fuse, run.x)
         fused = pot is not None and flow_is_native(flow)
         host = HostDraws(run.shard, *(self.host_draws or (None, None)))
         buf = torch.empty(max(T, 1), n, d, dtype=torch.float32, device=run.dev)

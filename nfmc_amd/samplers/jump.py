@@ -20,7 +20,7 @@ from ..flows import Flow, RealNVP
 from ..tuning import train_val_split
 from ..util import metropolis_acceptance_log_ratio
 from .common import Run, chunks, resolve_target
-from .mcmc import HMC, MALA, MH, UHMC, ULA
+from .mcmc import HMC, MALA, MH, UHMC, ULA, TargetFailure, _guarded
 
 
 @dataclass
@@ -185,11 +185,11 @@ def split_flow_mh(run: Run, flow, target, event_shape, step, adjusted, stats_str
         if flow_is_native(flow) or isinstance(flow, Flow):   # this package's flow: the run's own noise streams
             rng = hip.make_rng(run.seed, run.chain_offset, step)
             if run.replay is not None:
-                nz, un = run.replay.take(1, with_uniforms=adjusted)
+                nz, _ = run.replay.take(1, with_uniforms=False)
                 x_prime, ld = flow.bijection.inverse(nz[0].reshape(n, *event_shape))
                 zz = nz[0]
                 f_xp = (-0.5 * (zz * zz).sum(-1) - 0.5 * d * 1.8378770664093453) - ld
-                unif = un[0].contiguous() if un is not None else None
+                unif = None   # taken below, once the target calls have returned (jump.py:225)
             else:
                 x_prime, f_xp = flow.sample(n, return_log_prob=True, rng=rng)
                 unif = None
@@ -200,12 +200,21 @@ def split_flow_mh(run: Run, flow, target, event_shape, step, adjusted, stats_str
         f_xp = f_xp.detach().to(run.dev, torch.float32).contiguous()
         lr = None
         f_x = None
+        target_calls = 0
         if adjusted:
-            u_x = target(run.x.reshape(n, *event_shape)).reshape(-1)
-            u_xp = target(x_prime.reshape(n, *event_shape)).reshape(-1)
-            f_x = logq if logq is not None else flow.log_prob(run.x.reshape(n, *event_shape))
-            f_x = f_x.detach().to(run.dev, torch.float32).contiguous()
-            lr = metropolis_acceptance_log_ratio(-u_x, -u_xp, f_x, f_xp).float().contiguous()
+            # jump.py:210-227 / imh.py:222-237: a ValueError from the target or from flow.log_prob rejects every chain
+            # (no divergence is counted for a jump); the two target calls are booked once both have returned
+            try:
+                u_x = _guarded(target, run.x.reshape(n, *event_shape)).reshape(-1)
+                u_xp = _guarded(target, x_prime.reshape(n, *event_shape)).reshape(-1)
+                target_calls = 2 * n
+                f_x = logq if logq is not None else _guarded(flow.log_prob, run.x.reshape(n, *event_shape))
+                f_x = f_x.detach().to(run.dev, torch.float32).contiguous()
+                lr = metropolis_acceptance_log_ratio(-u_x, -u_xp, f_x, f_xp).float().contiguous()
+                if run.replay is not None and (flow_is_native(flow) or isinstance(flow, Flow)):
+                    unif = run.replay.take_uniforms(1)[0].contiguous()
+            except TargetFailure:
+                lr = torch.full((n,), -math.inf, dtype=torch.float32, device=run.dev)
     st = hip.NfmcSelectArgs()
     st.x, st.x_prime, st.n, st.d = hip.ptr(run.x), hip.ptr(x_prime), n, d
     st.log_ratio = hip.ptr(lr) if lr is not None else None
@@ -220,6 +229,7 @@ def split_flow_mh(run: Run, flow, target, event_shape, step, adjusted, stats_str
     st.stats = stats_struct
     st.mask_out = None
     hip.check(hip.lib().nfmc_mh_accept_select_f32(C.byref(st), hip.stream()), 'nfmc_mh_accept_select_f32')
+    return target_calls
 
 
 class JumpNFMC(Sampler):
@@ -274,11 +284,15 @@ class JumpNFMC(Sampler):
         out = JumpNFMCOutput(event_shape, store_samples=self.params.store_samples)
         flow = self.kernel.flow
         T, K = int(self.params.n_iterations), int(inner.params.n_iterations)
-        pot = resolve_target(self.target, event_shape, getattr(inner, 'fuse', 'auto'))
+        off = (False, 'never')
+        pot = resolve_target(self.target, event_shape,
+                             'never' if (self.fuse in off or getattr(inner, 'fuse', 'auto') in off) else 'auto', run.x)
         fused = pot is not None and flow_is_native(flow)
         tail_ok = (self.fuse_jump_tail and fused and flow_fits_jump_tail(flow) and not self.params.fit_nf
                    and isinstance(inner, (MALA, ULA, HMC, UHMC)))
         inner._cur_run = run
+        inner._n_divergences = 0
+        jump_target_calls = 0
 
         buf = torch.empty(T * (K + 1), n, d, dtype=torch.float32, device=run.dev) if self.params.store_samples else None
         fit_buf = torch.empty(K, n, d, dtype=torch.float32, device=run.dev) if (self.params.fit_nf and buf is None) else None
@@ -331,13 +345,14 @@ class JumpNFMC(Sampler):
             # ---- the jump (jump.py:205-243)
             jview = buf[base + K:base + K + 1] if buf is not None else None
             if tail_done:
-                pass
+                jump_target_calls += 2 * n if self.params.adjusted_jumps else 0
             elif fused:
                 launch_flow_mh(run, flow, pot, logq, 1, base + K, False, self.params.adjusted_jumps,
                                run.stats.struct(defer=True, attempted=n, jump=True), jview)
+                jump_target_calls += 2 * n if self.params.adjusted_jumps else 0
             else:
-                split_flow_mh(run, flow, self.target, event_shape, base + K, self.params.adjusted_jumps,
-                              run.stats.struct(jump=True))
+                jump_target_calls += split_flow_mh(run, flow, self.target, event_shape, base + K,
+                                                   self.params.adjusted_jumps, run.stats.struct(jump=True))
                 if jview is not None:
                     jview[0].copy_(run.x)
             done = i + 1
@@ -351,8 +366,9 @@ class JumpNFMC(Sampler):
         calls, grads = inner._counts(n, K * done)
         st = out.statistics
         st.update_counters(n_accepted_trajectories=int(cnt[hip.CNT_ACCEPTED]),
-                           n_attempted_trajectories=int(cnt[hip.CNT_ATTEMPTED]), n_divergences=0,
-                           n_target_calls=calls + (2 * n * done if self.params.adjusted_jumps else 0),
+                           n_attempted_trajectories=int(cnt[hip.CNT_ATTEMPTED]),
+                           n_divergences=inner._n_divergences,      # jump.py:183: the inner sampler's failed steps
+                           n_target_calls=calls + jump_target_calls,
                            n_target_gradient_calls=grads,
                            n_accepted_jumps=int(jc[hip.CNT_ACCEPTED]), n_attempted_jumps=n * done)
         st.n_nonfinite_log_ratios = int(cnt[hip.CNT_NONFINITE]) + int(jc[hip.CNT_NONFINITE])

@@ -89,6 +89,22 @@ class HMCParameters(MetropolisParameters):
     pass
 
 
+class TargetFailure(Exception):
+    """The target raised ValueError: the reference's failure channel (langevin.py:111-114, hmc.py:117-120,
+    mh.py:63-66): every chain rejects this step and the step counts as ONE divergence."""
+
+
+def _guarded(fn, *args):
+    """Call into user code (`target`, autograd through it).  A ValueError from there becomes TargetFailure; the
+    library's own argument errors (hip.NfmcArgumentError, also a ValueError) are never swallowed."""
+    try:
+        return fn(*args)
+    except hip.NfmcArgumentError:
+        raise
+    except ValueError as e:
+        raise TargetFailure(str(e)) from e
+
+
 def _value_and_grad(target, x, event_shape):
     """U(x), grad U(x) by autograd on the GPU (the reference's recipe, langevin.py:66-70)."""
     with torch.enable_grad():
@@ -99,7 +115,6 @@ def _value_and_grad(target, x, event_shape):
 
 
 class MCMCSampler(Sampler):
-    fuse = 'auto'  # 'auto': probe plain callables for a closed form (potentials.recognize); False: never
 
     def __init__(self, event_shape, target, kernel: MCMCKernel, params: MCMCParameters,
                  data_transform=lambda v: v):
@@ -146,9 +161,10 @@ class MCMCSampler(Sampler):
         out = MCMCOutput(event_shape, store_samples=self.params.store_samples)
         out.statistics.data_transform = self.data_transform
         K = int(self.params.n_iterations)
-        pot = resolve_target(self.target, event_shape, self.fuse)
+        pot = resolve_target(self.target, event_shape, self.fuse, run.x)
         buf = torch.empty(K, n, d, dtype=torch.float32, device=run.dev) if (self.params.store_samples and K > 0) else None
         run.stats.zero_()
+        self._n_divergences = 0
         t0 = time.time()
         done = 0
         label = f'{self.name} (tuning)' if self.params.tuning else self.name
@@ -175,7 +191,8 @@ class MCMCSampler(Sampler):
         run.sync()
         sum_x, sum_x2, cnt, _jc = run.stats.host_totals()
         calls, grads = self._counts(n, done)
-        out.statistics.update_counters(n_target_calls=calls, n_target_gradient_calls=grads, n_divergences=0,
+        out.statistics.update_counters(n_target_calls=calls, n_target_gradient_calls=grads,
+                                       n_divergences=self._n_divergences,
                                        n_accepted_trajectories=int(cnt[hip.CNT_ACCEPTED]),
                                        n_attempted_trajectories=int(cnt[hip.CNT_ATTEMPTED]))
         out.statistics.n_nonfinite_log_ratios = int(cnt[hip.CNT_NONFINITE])
@@ -193,11 +210,21 @@ class MCMCSampler(Sampler):
             run.shard.merge_statistics(out.statistics)
         return out
 
+    def _rejected_step(self, xf, n_calls, n_grads):
+        """What propose() returns when the target raised ValueError: x' = x, nobody accepts (log ratio -inf, also for
+        unadjusted kernels, whose select would otherwise accept everything), one divergence; the call counters are the
+        reference's, which books them after its try block whatever happened inside."""
+        n = xf.shape[0]
+        self._last_log_ratio = torch.full((n,), -math.inf, dtype=torch.float32, device=xf.device)
+        self._last_uniforms = None
+        return xf, torch.zeros(n, dtype=torch.bool, device=xf.device), n_calls, n_grads, 1
+
     # ---- one transition through the propose() seam (arbitrary targets)
     def _split_step(self, run: Run, step, sample_view):
         n, d = run.n, run.d
         self._cur_run, self._cur_step = run, step
         x_prime, mask_or_lr, n_calls, n_grads, n_divs = self.propose(run.x)
+        self._n_divergences = getattr(self, '_n_divergences', 0) + int(n_divs)
         st = hip.NfmcSelectArgs()
         st.x, st.x_prime, st.n, st.d = hip.ptr(run.x), hip.ptr(x_prime), n, d
         st.n_carry = 0
@@ -300,20 +327,30 @@ class Langevin(MetropolisSampler):
         h = float(self.kernel.step_size)
         imd = imd_tensor(self.kernel, dev)
         lib = hip.lib()
-        u, g = _value_and_grad(self.target, xf, self.event_shape)
-        x_prime = torch.empty_like(xf)
         nz = un = None
-        if run is not None and run.replay is not None:
-            nz, un = run.replay.take(1, with_uniforms=self.params.adjustment)
+        if run is not None and run.replay is not None:   # the noise is drawn before the first target call (langevin.py:63)
+            nz, _ = run.replay.take(1, with_uniforms=False)
+        per = 2 * n if self.params.adjustment else n     # langevin.py:116-120
+        try:
+            u, g = _guarded(_value_and_grad, self.target, xf, self.event_shape)
+        except TargetFailure:
+            return self._rejected_step(xf, per, per)
+        x_prime = torch.empty_like(xf)
         rng = hip.make_rng(seed, off, step, nz, None)
         hip.check(lib.nfmc_langevin_propose_f32(hip.ptr(xf), hip.ptr(g), hip.ptr(imd), h, n, d, C.byref(rng),
                                                 hip.ptr(x_prime), hip.stream()), 'nfmc_langevin_propose_f32')
         n_calls = n_grads = n
         self._last_log_ratio = None
-        self._last_uniforms = un[0].contiguous() if un is not None else None
+        self._last_uniforms = None
         mask = torch.ones(n, dtype=torch.bool, device=dev)
         if self.params.adjustment:
-            up, gp = _value_and_grad(self.target, x_prime, self.event_shape)
+            try:
+                up, gp = _guarded(_value_and_grad, self.target, x_prime, self.event_shape)
+            except TargetFailure:
+                return self._rejected_step(xf, per, per)
+            if nz is not None:
+                un = run.replay.take_uniforms(1)              # drawn after the second target call (langevin.py:106)
+                self._last_uniforms = un[0].contiguous()
             lr = torch.empty(n, dtype=torch.float32, device=dev)
             hip.check(lib.nfmc_langevin_log_ratio_f32(hip.ptr(xf), hip.ptr(x_prime), hip.ptr(u), hip.ptr(up),
                                                       hip.ptr(g), hip.ptr(gp), hip.ptr(imd), h, n, d, hip.ptr(lr),
@@ -388,9 +425,9 @@ class MH(Langevin):
         step = getattr(self, '_cur_step', 0)
         seed = run.seed if run is not None else (self.seed or 0)
         off = run.chain_offset if run is not None else 0
-        un = None
-        if run is not None and run.replay is not None:
-            nz, un = run.replay.take(1, with_uniforms=self.params.adjustment)
+        replayed = run is not None and run.replay is not None
+        if replayed:
+            nz, _ = run.replay.take(1, with_uniforms=False)
             noise = nz[0]
         else:
             noise = torch.empty(n, d, dtype=torch.float32, device=dev)
@@ -399,14 +436,19 @@ class MH(Langevin):
                       'nfmc_philox_normals_f32')
         x_prime = (xf + noise * self.kernel.inv_mass_diag.to(dev, torch.float32)[None]).contiguous()
         self._last_log_ratio = None
-        self._last_uniforms = un[0].contiguous() if un is not None else None
+        self._last_uniforms = None
         mask = torch.ones(n, dtype=torch.bool, device=dev)
         n_calls = 0
         if self.params.adjustment:
-            with torch.no_grad():
-                lr = (self.target(xf.reshape(n, *self.event_shape)).reshape(-1)
-                      - self.target(x_prime.reshape(n, *self.event_shape)).reshape(-1))
+            try:
+                with torch.no_grad():
+                    lr = (_guarded(self.target, xf.reshape(n, *self.event_shape)).reshape(-1)
+                          - _guarded(self.target, x_prime.reshape(n, *self.event_shape)).reshape(-1))
+            except TargetFailure:
+                return self._rejected_step(xf, 2 * n, 0)      # mh.py:63-71
             self._last_log_ratio = lr.float().contiguous()
+            if replayed:
+                self._last_uniforms = run.replay.take_uniforms(1)[0].contiguous()   # mh.py:59, after both target calls
             n_calls = 2 * n
             if run is None:
                 unif = torch.empty(n, dtype=torch.float32, device=dev)
@@ -473,9 +515,9 @@ class HMC(MetropolisSampler):
         h = float(self.kernel.step_size)
         m = self.kernel.inv_mass_diag.to(dev, torch.float32)
         lib = hip.lib()
-        nz = un = None
-        if run is not None and run.replay is not None:
-            nz, un = run.replay.take(1, with_uniforms=self.params.adjustment)
+        replayed = run is not None and run.replay is not None
+        if replayed:
+            nz, _ = run.replay.take(1, with_uniforms=False)
             noise = nz[0]
         else:
             noise = torch.empty(n, d, dtype=torch.float32, device=dev)
@@ -485,21 +527,30 @@ class HMC(MetropolisSampler):
         p = noise * (1 / m.sqrt())
         p0 = p
         q = xf
-        for _ in range(self.kernel.n_leapfrog_steps):
-            p = p - h / 2 * _value_and_grad(self.target, q, self.event_shape)[1]
-            q = q + h * (p * m)
-            p = p - h / 2 * _value_and_grad(self.target, q, self.event_shape)[1]
         L = self.kernel.n_leapfrog_steps
-        n_grads = 2 * L * n
+        n_grads = 2 * L * n                                   # hmc.py:122-125
+        n_calls = n_grads + (2 * n if self.params.adjustment else 0)
+        try:
+            for _ in range(L):
+                p = p - h / 2 * _guarded(_value_and_grad, self.target, q, self.event_shape)[1]
+                q = q + h * (p * m)
+                p = p - h / 2 * _guarded(_value_and_grad, self.target, q, self.event_shape)[1]
+        except TargetFailure:
+            return self._rejected_step(xf, n_calls, n_grads)  # hmc.py:117-120
         n_calls = n_grads
         self._last_log_ratio = None
-        self._last_uniforms = un[0].contiguous() if un is not None else None
+        self._last_uniforms = None
         mask = torch.ones(n, dtype=torch.bool, device=dev)
         if self.params.adjustment:
-            with torch.no_grad():
-                h0 = self.target(xf.reshape(n, *self.event_shape)).reshape(-1) + 0.5 * (p0 ** 2 * m).sum(-1)
-                h1 = self.target(q.reshape(n, *self.event_shape)).reshape(-1) + 0.5 * (p ** 2 * m).sum(-1)
+            try:
+                with torch.no_grad():
+                    h0 = _guarded(self.target, xf.reshape(n, *self.event_shape)).reshape(-1) + 0.5 * (p0 ** 2 * m).sum(-1)
+                    h1 = _guarded(self.target, q.reshape(n, *self.event_shape)).reshape(-1) + 0.5 * (p ** 2 * m).sum(-1)
+            except TargetFailure:
+                return self._rejected_step(xf, n_grads + 2 * n, n_grads)
             self._last_log_ratio = (h0 - h1).float().contiguous()
+            if replayed:
+                self._last_uniforms = run.replay.take_uniforms(1)[0].contiguous()   # hmc.py:112, after both target calls
             n_calls += 2 * n
             if run is None:
                 unif = torch.empty(n, dtype=torch.float32, device=dev)

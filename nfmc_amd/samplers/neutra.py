@@ -100,7 +100,7 @@ class NeuTra(Sampler):
     def _closed_form(self):
         """The target as a closed-form potential descriptor (None: an arbitrary callable, differentiated by autograd)."""
         if getattr(self, '_pot_cache', None) is None or self._pot_cache[0] is not self.target:
-            self._pot_cache = (self.target, resolve_target(self.target, self.event_shape))
+            self._pot_cache = (self.target, resolve_target(self.target, self.event_shape, self.fuse))
         return self._pot_cache[1]
 
     def _potential_grad(self, z):
@@ -140,7 +140,7 @@ class NeuTra(Sampler):
         inner.params.store_samples = self.params.store_samples
         run = Run(self, x0)
         n, d, event_shape = run.n, run.d, run.event_shape
-        pot = resolve_target(self.target, event_shape)
+        pot = resolve_target(self.target, event_shape, self.fuse)
         def split():
             # NeuTraMH / arbitrary targets / shapes without a fused kernel: the inner sampler's split path on the
             # adjusted target (neutra.py:116-127)

@@ -129,6 +129,7 @@ class Trace:
     n_accepted_jumps: int = 0
     n_attempted_jumps: int = 0
     n_refits: int = 0
+    n_divergences: int = 0
     moments: Optional[Moments] = None
     last: Optional[torch.Tensor] = None
 
@@ -226,14 +227,25 @@ def mcmc_sample(x0, target, kind, n_iterations, step_size, inv_mass_diag=None, n
     tr = Trace(moments=Moments.for_event((d,)))
     for it in range(n_iterations):
         step = step0 + it
+        # The reference's failure channel (langevin.py:111-114, hmc.py:117-120, mh.py:63-66): a ValueError raised by
+        # the target inside propose() rejects every chain for this step and counts ONE divergence; the call counters
+        # are booked after the try block, whatever happened inside it.  The step's normals were drawn before the first
+        # target call, its uniforms are only drawn once every target call has returned.
+        try:
+            if kind == 'langevin':
+                x_prime, mask, lr, lu = langevin_propose(x, target, step_size, inv_mass_diag, adjustment, noise, step)
+            elif kind == 'mh':
+                x_prime, mask, lr, lu = mh_propose(x, target, inv_mass_diag, adjustment, noise, step)
+            else:
+                x_prime, mask, lr, lu = hmc_propose(x, target, step_size, inv_mass_diag, n_leapfrog, adjustment, noise, step)
+        except ValueError:
+            x_prime, mask, lr, lu = x, torch.zeros(n, dtype=torch.bool), None, None
+            tr.n_divergences += 1
         if kind == 'langevin':
-            x_prime, mask, lr, lu = langevin_propose(x, target, step_size, inv_mass_diag, adjustment, noise, step)
             calls = grads = n * (2 if adjustment else 1)                         # langevin.py:116-120
         elif kind == 'mh':
-            x_prime, mask, lr, lu = mh_propose(x, target, inv_mass_diag, adjustment, noise, step)
             calls, grads = (2 * n if adjustment else 0), 0                       # mh.py:67-71
         else:
-            x_prime, mask, lr, lu = hmc_propose(x, target, step_size, inv_mass_diag, n_leapfrog, adjustment, noise, step)
             grads = 2 * n_leapfrog * n                                           # hmc.py:122-125
             calls = grads + (2 * n if adjustment else 0)
         x = x.detach().clone()
@@ -274,6 +286,7 @@ def jump_sample(x0, target, flow, inner_kind, n_outer, n_inner, step_size, inv_m
         tr.n_attempted += inner.n_attempted
         tr.n_target_calls += inner.n_target_calls
         tr.n_target_gradient_calls += inner.n_target_gradient_calls
+        tr.n_divergences += inner.n_divergences                                  # jump.py:183
         tr.masks += inner.masks
         tr.log_ratios += inner.log_ratios
         tr.moments.update(inner.stacked())                                       # :188
@@ -287,16 +300,19 @@ def jump_sample(x0, target, flow, inner_kind, n_outer, n_inner, step_size, inv_m
         x_prime = x_prime.reshape(n, -1)
         x = inner.last                                                            # :209
         if adjusted_jumps:
-            u_x = target(x)                                                       # :212
-            u_xp = target(x_prime)                                                # :213
-            tr.n_target_calls += 2 * n
-            with torch.no_grad():
-                f_x = flow.log_prob(x.reshape(n, *event))                         # :218
-            log_alpha = (-u_xp) - (-u_x) + f_x - f_x_prime                        # :219-224, util.py:392
-            log_u = noise.uniform(n, jstep, philox.TAG_JUMP).log()                # :225
-            mask = log_u < log_alpha
-            tr.log_ratios.append(log_alpha.detach())
-            tr.uniforms.append(log_u)
+            try:                                                                  # :210-227
+                u_x = target(x)                                                   # :212
+                u_xp = target(x_prime)                                            # :213
+                tr.n_target_calls += 2 * n
+                with torch.no_grad():
+                    f_x = flow.log_prob(x.reshape(n, *event))                     # :218
+                log_alpha = (-u_xp) - (-u_x) + f_x - f_x_prime                    # :219-224, util.py:392
+                log_u = noise.uniform(n, jstep, philox.TAG_JUMP).log()            # :225
+                mask = log_u < log_alpha
+                tr.log_ratios.append(log_alpha.detach())
+                tr.uniforms.append(log_u)
+            except ValueError:                                                    # :226-227: reject all, no divergence
+                mask = torch.zeros(n, dtype=torch.bool)
         else:
             mask = torch.ones(n, dtype=torch.bool)
         x = x.clone()

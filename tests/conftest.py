@@ -45,6 +45,20 @@ def golden_flow(fx, d, n_layers=2, n_hidden=None, cond_layers=2):
     return f
 
 
+class FailingTarget:
+    """A target that raises ValueError on its `fail_calls`-th calls (1-based): the driver of the reference's failure
+    channel in the *_fail_* fixtures (tests/golden/make_golden.py uses the same counting)."""
+
+    def __init__(self, base, fail_calls):
+        self.base, self.fail_calls, self.calls = base, set(int(c) for c in fail_calls), 0
+
+    def __call__(self, x):
+        self.calls += 1
+        if self.calls in self.fail_calls:
+            raise ValueError('target failed on call %d' % self.calls)
+        return self.base(x)
+
+
 @pytest.fixture
 def golden():
     return load_golden

@@ -173,6 +173,43 @@ def main():
     save('mala_funnel_d5', rec, x0=x0.numpy(), step_size=np.float64(kern.step_size),
          inv_mass_diag=kern.inv_mass_diag.numpy(), **out_arrays(out))
 
+    # ---------------------------------------------------------------- the failure channel: a target that raises
+    # ValueError on chosen calls (langevin.py:111-114, hmc.py:117-120, mh.py:63-66, jump.py:226-227)
+    class FailingTarget:
+        def __init__(self, base, fail_calls):
+            self.base, self.fail_calls, self.calls = base, set(fail_calls), 0
+
+        def __call__(self, x):
+            self.calls += 1
+            if self.calls in self.fail_calls:
+                raise ValueError('target failed on call %d' % self.calls)
+            return self.base(x)
+
+    from nfmc.algorithms.sampling.mcmc.mh import MH as _MH, MHKernel as _MHKernel, MHParameters as _MHParameters
+    for name, kind, d, n, k, fails in [('mala_fail_d5', 'mala', 5, 12, 6, (4, 9)), ('hmc_fail_d5', 'hmc', 5, 8, 4, (5,)),
+                                       ('mh_fail_d5', 'mh', 5, 12, 5, (3,)), ('ula_fail_d5', 'ula', 5, 8, 4, (2,))]:
+        torch.manual_seed(41)
+        x0 = torch.randn(n, d)
+        tgt = FailingTarget(sumsq, fails)
+        extra = {}
+        if kind in ('mala', 'ula'):
+            kern = LangevinKernel(event_size=d)
+            s = (MALA if kind == 'mala' else ULA)((d,), tgt, kern, LangevinParameters(n_iterations=k))
+            extra['step_size'] = np.float64(kern.step_size)
+        elif kind == 'hmc':
+            kern = HMCKernel(event_size=d, n_leapfrog_steps=2, step_size=0.1)
+            s = HMC((d,), tgt, kern, HMCParameters(n_iterations=k))
+            extra.update(step_size=np.float64(0.1), n_leapfrog=np.int64(2))
+        else:
+            kern = _MHKernel(event_size=d)
+            kern.inv_mass_diag = torch.linspace(0.2, 0.5, d)
+            s = _MH((d,), tgt, kern, _MHParameters(n_iterations=k))
+        with DrawRecorder() as rec:
+            out = s.sample(x0.clone(), show_progress=False)
+        assert out.statistics.n_divergences == len(fails), out.statistics.n_divergences
+        save(name, rec, x0=x0.numpy(), inv_mass_diag=kern.inv_mass_diag.numpy(), fail_calls=np.array(fails, dtype=np.int64),
+             **extra, **out_arrays(out))
+
     # ---------------------------------------------------------------- random-walk MH (f2)
     from nfmc.algorithms.sampling.mcmc.mh import MH, RandomWalk, MHKernel, MHParameters
     from nfmc.algorithms.sampling.nfmc.jump import JumpMH
@@ -219,6 +256,22 @@ def main():
     # normals: per outer iteration K inner (n,d) then one latent (n,d); uniforms: K inner + 1 jump
     save('jump_mala_d6', rec, x0=x0.numpy(), step_size=np.float64(ik.step_size), n_outer=np.int64(T),
          n_inner=np.int64(K), **flow_arrays(flow), **out_arrays(out, jump=True))
+
+    # jump with a failing target: call 5 is an inner MALA call of outer iteration 0 (a divergence; the step makes no second call), call 7 the jump's
+    # second target call of outer iteration 0 (all chains rejected, no divergence, its 2n calls not booked)
+    d, n, T, K = 6, 10, 2, 3
+    flow = make_flow(d, 28, target_std=0.7)
+    torch.manual_seed(42)
+    x0 = torch.randn(n, d)
+    ik = LangevinKernel(event_size=d)
+    tgt = FailingTarget(sumsq, (5, 7))
+    s = JumpMALA((d,), tgt, NFMCKernel((d,), flow=flow), JumpNFMCParameters(n_iterations=T),
+                 ik, LangevinParameters(n_iterations=K))
+    with DrawRecorder() as rec:
+        out = s.sample(x0.clone(), show_progress=False)
+    assert out.statistics.n_divergences == 1
+    save('jump_mala_fail_d6', rec, x0=x0.numpy(), step_size=np.float64(ik.step_size), n_outer=np.int64(T),
+         n_inner=np.int64(K), fail_calls=np.array((5, 7), dtype=np.int64), **flow_arrays(flow), **out_arrays(out, jump=True))
 
     d, n, T, K, L = 8, 10, 2, 2, 3
     flow = make_flow(d, 22, n_layers=3, ck={'n_hidden': 5, 'n_layers': 3}, target_std=0.7)

@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, golden_flow
+from conftest import load_golden, golden_flow, FailingTarget
 
 pytestmark = pytest.mark.gpu
 
@@ -145,6 +145,67 @@ def test_hmc_golden_python_callable_split_path(dev):
     s.replay = _noise(fx)
     out = s.sample(torch.from_numpy(fx['x0']), show_progress=False)
     _check_out(out, fx)
+
+
+@pytest.mark.parametrize('name,cls', [('mala_fail_d5', 'MALA'), ('ula_fail_d5', 'ULA'), ('hmc_fail_d5', 'HMC'), ('mh_fail_d5', 'MH')])
+def test_target_failure_channel_golden(dev, name, cls):
+    """The reference's only error channel on the propose() seam (langevin.py:111-114, hmc.py:117-120, mh.py:63-66): a
+    ValueError raised by the target rejects every chain for that step, counts one divergence, and the run goes on.
+    Fixtures recorded from the reference with a target that raises on chosen calls."""
+    from nfmc_amd.samplers import mcmc
+    fx = load_golden(name)
+    d = fx['x0'].shape[1]
+    k = fx['exp/samples'].shape[0]
+    target = FailingTarget(lambda x: torch.sum(x ** 2, dim=-1), fx['fail_calls'])
+    imd = torch.from_numpy(fx['inv_mass_diag'])
+    if cls in ('MALA', 'ULA'):
+        s = getattr(mcmc, cls)((d,), target, mcmc.LangevinKernel(event_size=d, step_size=float(fx['step_size']), inv_mass_diag=imd),
+                               mcmc.LangevinParameters(n_iterations=k))
+    elif cls == 'HMC':
+        s = mcmc.HMC((d,), target, mcmc.HMCKernel(event_size=d, step_size=float(fx['step_size']),
+                                                   n_leapfrog_steps=int(fx['n_leapfrog']), inv_mass_diag=imd),
+                     mcmc.HMCParameters(n_iterations=k))
+    else:
+        s = mcmc.MH((d,), target, mcmc.MHKernel(event_size=d, inv_mass_diag=imd), mcmc.MHParameters(n_iterations=k))
+    s.fuse = False          # probing would consume the target's call counter (and a failing target is not a quadratic)
+    s.replay = _noise(fx)
+    out = s.sample(torch.from_numpy(fx['x0']), show_progress=False)
+    _check_out(out, fx)
+    assert out.statistics.n_divergences == len(fx['fail_calls'])
+
+
+def test_jump_with_failing_target_golden(dev):
+    """jump.py:183 (the inner sampler's divergences are carried into the jump statistics) and :226-227 (a jump whose
+    target call raises rejects every chain, counts no divergence and books no target calls)."""
+    from nfmc_amd.samplers import jump, mcmc
+    from nfmc_amd.containers import NFMCKernel
+    fx = load_golden('jump_mala_fail_d6')
+    d = fx['x0'].shape[1]
+    target = FailingTarget(lambda x: torch.sum(x ** 2, dim=-1), fx['fail_calls'])
+    s = jump.JumpMALA((d,), target, NFMCKernel((d,), flow=_amd_flow(fx, d)),
+                      jump.JumpNFMCParameters(n_iterations=int(fx['n_outer'])),
+                      mcmc.LangevinKernel(event_size=d, step_size=float(fx['step_size'])),
+                      mcmc.LangevinParameters(n_iterations=int(fx['n_inner'])))
+    s.fuse = False
+    s.replay = _noise(fx)
+    out = s.sample(torch.from_numpy(fx['x0']), show_progress=False)
+    _check_out(out, fx, jump=True)
+    assert out.statistics.n_divergences == 1
+
+
+def test_library_argument_errors_are_not_swallowed_by_the_failure_channel(dev):
+    """NfmcArgumentError subclasses ValueError (the reference's error type) but must never be mistaken for a failing
+    target: a sampler handed a bad shape still raises."""
+    from nfmc_amd import hip
+    from nfmc_amd.samplers import mcmc
+    assert issubclass(hip.NfmcArgumentError, ValueError)
+
+    def bad_target(x):
+        raise hip.NfmcArgumentError('library error inside user code', hip.EINVAL)
+    s = mcmc.MALA((4,), bad_target, None, mcmc.LangevinParameters(n_iterations=2))
+    s.fuse = False
+    with pytest.raises(hip.NfmcArgumentError):
+        s.sample(torch.randn(8, 4), show_progress=False)
 
 
 # ------------------------------------------------------------------------------------------ golden: flow samplers

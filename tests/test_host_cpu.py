@@ -216,9 +216,38 @@ def test_potential_recognition():
     assert recognize(lambda x: torch.sum(x ** 4, dim=1), (5,)) is None
     assert recognize(lambda x: torch.sum(x.abs(), dim=1), (5,)) is None
     assert recognize(opot.funnel(3.0), (6,)) is None
+    # quadratic near the origin, something else far out (a wall at |x| = 25): the far probes catch it
+    assert recognize(lambda x: torch.sum(x ** 2, dim=1) + 1e3 * (x.abs().amax(dim=1) > 25).float(), (5,)) is None
+    # ... and one whose other regime starts only at the scale of the run's own x0
+    wall = lambda x: torch.sum(x ** 2, dim=1) * (1 + (x.abs().amax(dim=1) > 2000).float())
+    assert recognize(wall, (5,)) is not None and recognize(wall, (5,), x_scale=800.0) is None
+    # stateful / stochastic targets differ between two evaluations of the same points
+    calls = []
+    def drifting(x):
+        calls.append(1)
+        return torch.sum(x ** 2, dim=1) * (1 + 1e-3 * len(calls))
+    assert recognize(drifting, (5,)) is None
+    assert recognize(lambda x: torch.sum(x ** 2, dim=1) + 1e-3 * torch.rand(x.shape[0], dtype=x.dtype), (5,)) is None
     x = torch.randn(7, 6)
     np.testing.assert_allclose(Funnel((6,), 3.0)(x).numpy(), opot.funnel(3.0)(x).numpy(), rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(SumOfSquares((6,))(x).numpy(), opot.sum_squares(x).numpy(), rtol=1e-6)
+
+
+def test_fuse_never_keeps_the_callable_and_rerouting_is_logged(caplog):
+    import logging
+    from nfmc_amd import potentials
+    from nfmc_amd.samplers.common import resolve_target
+    f = lambda x: torch.sum(x ** 2, dim=1)
+    assert resolve_target(f, (4,), 'never') is None and resolve_target(f, (4,), False) is None
+    potentials._announced.clear()
+    with caplog.at_level(logging.WARNING, logger='nfmc_amd'):
+        assert resolve_target(f, (4,), 'auto', x0=torch.randn(10, 4)) is not None
+        assert resolve_target(f, (4,), 'auto') is not None
+    msgs = [r.getMessage() for r in caplog.records if 'closed form' in r.getMessage()]
+    assert len(msgs) == 1 and 'fuse="never"' in msgs[0]      # logged once
+    import inspect
+    from nfmc_amd import sample
+    assert "fuse" in inspect.getdoc(sample)
 
 
 GLOO_WORKER = r'''

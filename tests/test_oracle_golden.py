@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, golden_flow
+from conftest import load_golden, golden_flow, FailingTarget
 from oracle import samplers as osamp
 from oracle import potentials as opot
 from oracle import philox
@@ -58,6 +58,32 @@ def test_random_walk_mh(name, adjust):
     tr = osamp.mcmc_sample(torch.from_numpy(fx['x0']), opot.sum_squares, 'mh', fx['exp/samples'].shape[0], 0.01,
                            torch.from_numpy(fx['inv_mass_diag']), adjustment=adjust, noise=_noise(fx))
     _check(tr, fx)
+
+
+@pytest.mark.parametrize('name,kind,adjust', [('mala_fail_d5', 'langevin', True), ('ula_fail_d5', 'langevin', False),
+                                              ('hmc_fail_d5', 'hmc', True), ('mh_fail_d5', 'mh', True)])
+def test_target_failure_rejects_the_step_and_counts_a_divergence(name, kind, adjust):
+    """langevin.py:111-114, hmc.py:117-120, mh.py:63-66: ValueError from the target -> x' = x, nobody accepts,
+    n_divergences += 1, the step's uniforms are never drawn; the run continues."""
+    fx = load_golden(name)
+    target = FailingTarget(opot.sum_squares, fx['fail_calls'])
+    tr = osamp.mcmc_sample(torch.from_numpy(fx['x0']), target, kind, fx['exp/samples'].shape[0],
+                           float(fx['step_size']) if 'step_size' in fx else 0.01, torch.from_numpy(fx['inv_mass_diag']),
+                           n_leapfrog=int(fx['n_leapfrog']) if 'n_leapfrog' in fx else 20, adjustment=adjust,
+                           noise=_noise(fx))
+    _check(tr, fx)
+    assert tr.n_divergences == int(fx['exp/counters'][2]) == len(fx['fail_calls'])
+
+
+def test_jump_with_failing_target():
+    """jump.py:183 (inner divergences are carried over) and :226-227 (a failing jump rejects, books no calls)."""
+    fx = load_golden('jump_mala_fail_d6')
+    flow = golden_flow(fx, 6)
+    target = FailingTarget(opot.sum_squares, fx['fail_calls'])
+    tr = osamp.jump_sample(torch.from_numpy(fx['x0']), target, flow, 'langevin', int(fx['n_outer']),
+                           int(fx['n_inner']), float(fx['step_size']), noise=_noise(fx))
+    _check(tr, fx, jump=True)
+    assert tr.n_divergences == int(fx['exp/counters'][2]) == 1
 
 
 def test_jump_mala():
