@@ -30,7 +30,7 @@ extern "C" {
 
 typedef void* nfmc_stream_t; /* hipStream_t */
 
-#define NFMC_ABI_VERSION 1
+#define NFMC_ABI_VERSION 2
 
 enum {
     NFMC_OK = 0,
@@ -129,9 +129,24 @@ int64_t nfmc_realnvp_layer_floats(int32_t d, int32_t n_hidden, int32_t n_hidden_
 /* the same for any coupling kind (n_bins as in NfmcRealNVP; 0 = affine) */
 int64_t nfmc_coupling_layer_floats(int32_t d, int32_t n_hidden, int32_t n_hidden_layers, int32_t n_bins);
 
+/* ---- Kept states.  Replaces `MCMCSamples.add` (nfmc/algorithms/sampling/base.py:234-263): the state after a
+ * transition is kept iff the transition's global index is a multiple of `thinning`, and only the newest `max_samples`
+ * kept states survive.  Both decisions are made BEFORE the launch, so a kernel writes only rows that will still be
+ * there at the end, into a store of `ring_rows` rows of n*d floats that is never larger than max_samples rows
+ * (the reference slices its host-side list after the fact).  The store is a ring: the j-th kept state of a run goes to
+ * row j mod ring_rows; the caller reads it back in order from the oldest surviving row. */
+typedef struct {
+    float* base;        /* NULL: keep nothing */
+    int32_t stride;     /* thinning: every stride-th transition is kept (>= 1) */
+    int32_t countdown;  /* transitions of THIS call to skip before its first kept one: (-seen) mod stride, where seen =
+                           transitions offered to the store so far */
+    int32_t ring_rows;  /* rows of the store (>= 1); kept rows wrap around */
+    int32_t row;        /* ring row of this call's first kept transition: ceil(seen / stride) mod ring_rows */
+} NfmcSampleStore;
+
 /* Optional tail of a sampler call: after the n_steps inner transitions, ONE flow-proposal Metropolis jump
  * (jump.py:205-243: flow.sample, flow.log_prob, 2 target calls, log u < log alpha, masked update) on the
- * same registers, as transition rng.step0 + n_steps.  With a tail, `samples` holds n_steps + 1 rows and the
+ * same registers, as transition rng.step0 + n_steps.  With a tail, `samples` is offered n_steps + 1 states and the
  * moments include the post-jump state.  Narrow conditioners only (n_hidden <= 8, d <= 512); otherwise the
  * call returns NFMC_EUNSUPPORTED and the caller issues nfmc_flow_mh_steps_f32 separately. */
 typedef struct {
@@ -161,7 +176,7 @@ typedef struct {
     NfmcPotential pot;
     NfmcRng rng;
     NfmcStats stats;
-    float* samples;             /* NULL or (n_steps, n, d): state after every step (MCMCSamples.add) */
+    NfmcSampleStore samples;    /* state after every step, thinned / windowed as described above (MCMCSamples.add) */
     uint8_t* masks_out;         /* NULL or (n_steps, n) accept masks (tests / split path) */
     float* log_ratio_out;       /* NULL or (n_steps, n) */
     const NfmcJumpTail* jump;   /* NULL or a jump to run after the inner transitions (host pointer) */
@@ -183,7 +198,7 @@ typedef struct {
     NfmcPotential pot;
     NfmcRng rng;
     NfmcStats stats;
-    float* samples;
+    NfmcSampleStore samples;
     uint8_t* masks_out;
     float* log_ratio_out;
     const NfmcJumpTail* jump;   /* as in NfmcMalaArgs */
@@ -216,7 +231,7 @@ typedef struct {
     NfmcPotential pot;
     NfmcRng rng;              /* replay_normals are the latents z (n_steps, n, d) */
     NfmcStats stats;          /* counters use the ACCEPTED/ATTEMPTED words */
-    float* samples;
+    NfmcSampleStore samples;
     uint8_t* masks_out;
     float* log_ratio_out;
 } NfmcFlowMhArgs;
@@ -258,7 +273,7 @@ typedef struct {
     NfmcPotential pot;
     NfmcRng rng;
     NfmcStats stats;          /* moments of the latent z (reference quirk) */
-    float* samples;
+    NfmcSampleStore samples;
     uint8_t* masks_out;
     float* log_ratio_out;
     float* scratch;           /* matrix-core path (n_hidden > 32) only: >= nfmc_neutra_scratch_bytes(...) bytes */

@@ -55,6 +55,11 @@ class MCMCParameters:
     n_warmup_iterations: int = 100
     tuning: bool = False          # True while warmup adapts the kernel
     store_samples: bool = True
+    # MCMCSamples.thinning / .max_samples (base.py:222-224), which the reference's samplers never set (their output object
+    # is built inside sample()); here they are parameters, applied on the device before every launch
+    thinning: int = 1
+    max_samples: Optional[int] = None
+    spill_to_host: bool = False   # start the device-to-host copy of the kept states at the end of sample(), asynchronously
 
     def __post_init__(self):
         return None
@@ -229,6 +234,64 @@ class MCMCStatistics:
 
 
 # ------------------------------------------------------------------------------------------------ kept states
+class DeviceSampleStore:
+    """The device slab behind `NfmcSampleStore` (include/nfmc_hip.h): `MCMCSamples.add`'s thinning and `max_samples`
+    window (base.py:249-263) decided BEFORE each launch, so the kernels write only states that are still kept at the end
+    and the slab never has more than min(ceil(total / thinning), max_samples) rows -- the reference appends every
+    state to a host list and slices it afterwards.  Row j mod rows holds the j-th kept state (a ring)."""
+
+    def __init__(self, n, d, device, total, thinning=1, max_samples=None):
+        self.n, self.d = int(n), int(d)
+        self.thinning = max(1, int(thinning))
+        kept_total = -(-int(total) // self.thinning)
+        self.rows = kept_total if not max_samples else min(kept_total, int(max_samples))
+        self.buf = torch.empty(self.rows, self.n, self.d, dtype=torch.float32, device=device) if self.rows > 0 else None
+        self.seen = 0   # transitions offered so far
+
+    @property
+    def n_kept(self):
+        """Kept states that survive: min(#kept so far, rows)."""
+        return min(-(-self.seen // self.thinning), self.rows)
+
+    def plan(self, k):
+        """(stride, countdown, ring_rows, row) of NfmcSampleStore for a launch that offers the next k transitions
+        (advances the store): countdown = transitions to skip before the launch's first kept one, row = its ring row."""
+        t = self.thinning
+        desc = (t, (-self.seen) % t, max(self.rows, 1), (-(-self.seen // t)) % max(self.rows, 1))
+        self.seen += int(k)
+        return desc
+
+    def struct(self, k):
+        """The NfmcSampleStore itself (device pointer + plan)."""
+        from . import hip
+        stride, countdown, rows, row = self.plan(k)
+        if self.buf is None:
+            return hip.dense_store(None)
+        return hip.NfmcSampleStore(hip.ptr(self.buf), stride, countdown, rows, row)
+
+    def add_dense(self, x):
+        """Offer (k, n, d) states that already sit in a dense device tensor (host-driven paths)."""
+        k = int(x.shape[0])
+        if self.buf is not None and k > 0:
+            t = self.thinning
+            idx = torch.arange(self.seen, self.seen + k)
+            keep = idx[idx % t == 0][-self.rows:]           # more kept than rows: only the newest `rows` survive
+            if keep.numel():
+                rows = ((keep // t) % self.rows).to(x.device)
+                self.buf.index_copy_(0, rows, x.reshape(k, self.n, self.d)[(keep - self.seen).to(x.device)])
+        self.seen += k
+
+    def ordered(self):
+        """(n_kept, n, d) in chronological order (a view when the ring has not wrapped)."""
+        if self.buf is None:
+            return torch.empty(0, self.n, self.d)
+        kept = -(-self.seen // self.thinning)
+        if kept <= self.rows:
+            return self.buf[:kept]
+        start = kept % self.rows                           # oldest surviving row
+        return self.buf if start == 0 else torch.cat([self.buf[start:], self.buf[:start]])
+
+
 class MCMCSamples:
     """States kept from a run, `(n_kept, n_chains, *event_shape)`."""
 
@@ -240,6 +303,7 @@ class MCMCSamples:
         self.reset()
 
     def reset(self):
+        self._host = None                       # host copy of the kept states (spill / as_tensor)
         self._slabs: List[torch.Tensor] = []   # device tensors (k, n_chains, *event), in order
         self.n_samples = 0                      # rows kept
         self.seen_samples = 0                   # rows offered (thinning counts these)
@@ -269,6 +333,18 @@ class MCMCSamples:
             newest = self.as_device_tensor()[-self.max_samples:]
             self._slabs, self.n_samples = [newest], len(newest)
 
+    def adopt_store(self, store: DeviceSampleStore, spill: bool = False):
+        """Take over what the kernels kept (thinning and window already applied on the device); `spill` starts the
+        asynchronous copy to pinned host memory right away."""
+        kept = store.ordered()
+        self.seen_samples += store.seen
+        self.thinning = store.thinning
+        self._slabs = [kept.reshape(kept.shape[0], kept.shape[1], *self.event_shape)] if kept.shape[0] else []
+        self.n_samples = int(kept.shape[0])
+        self._host = None
+        if spill:
+            self.spill()
+
     def as_device_tensor(self) -> torch.Tensor:
         if len(self._slabs) > 1:
             self._slabs = [torch.cat(self._slabs, dim=0)]
@@ -279,8 +355,31 @@ class MCMCSamples:
             return torch.empty((0, 0) + self.event_shape)
         return self.last_sample.new_empty((0,) + tuple(self.last_sample.shape))
 
+    def spill(self):
+        """Start copying the kept states to pinned host memory on a side stream and return at once (the asynchronous
+        spill of SURVEY 8f3); `as_tensor()` waits for it.  A no-op for host-resident or empty stores."""
+        dev_t = self.as_device_tensor()
+        if not dev_t.is_cuda or dev_t.numel() == 0 or getattr(self, '_host', None) is not None:
+            return
+        stream = torch.cuda.Stream(device=dev_t.device)
+        stream.wait_stream(torch.cuda.current_stream(dev_t.device))     # after the kernels that wrote the slab
+        host = torch.empty(dev_t.shape, dtype=dev_t.dtype, pin_memory=True)
+        with torch.cuda.stream(stream):
+            host.copy_(dev_t, non_blocking=True)
+        self._host, self._host_stream, self._host_src = host, stream, dev_t
+
     def as_tensor(self) -> torch.Tensor:
-        return self.as_device_tensor().cpu()
+        """The kept states on the host.  Copied once: later reads return the same host tensor until states are added."""
+        dev_t = self.as_device_tensor()
+        if not dev_t.is_cuda:
+            return dev_t
+        if getattr(self, '_host', None) is None or self._host_src is not dev_t:
+            self._host = None
+            self.spill()
+            if getattr(self, '_host', None) is None:      # empty store
+                return dev_t.cpu()
+        self._host_stream.synchronize()
+        return self._host
 
     def __getitem__(self, index):
         if index in (-1, self.n_samples - 1):
@@ -320,6 +419,12 @@ class MCMCOutput:
     @property
     def samples_device(self) -> Optional[torch.Tensor]:
         return self._kept(True)
+
+    def spill(self):
+        """Begin the asynchronous device-to-host copy of the kept states (see MCMCSamples.spill)."""
+        if self.store_samples:
+            self.running_samples.spill()
+        return self
 
     def resample(self, n: int) -> torch.Tensor:
         """n draws with replacement from all kept (step, chain) states."""

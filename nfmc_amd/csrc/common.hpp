@@ -325,6 +325,38 @@ __device__ __forceinline__ void store_row(float* __restrict__ base, int64_t row,
 }
 
 // ------------------------------------------------------------------------------------------------
+// Kept states (NfmcSampleStore): which transitions of a launch are kept, and in which ring row, is wave-uniform
+// bookkeeping on scalars -- a countdown to the next kept transition and the row it goes to, advanced without divisions.
+struct StoreCursor {
+    float* base;
+    int stride, countdown, ring, row;
+    __device__ __forceinline__ explicit StoreCursor(const NfmcSampleStore& s)
+        : base(s.base), stride(s.stride), countdown(s.countdown), ring(s.ring_rows), row(s.row) {}
+    // the store row (pointer to its n*d floats) the CURRENT transition is kept in, or nullptr; advances to the next one
+    __device__ __forceinline__ float* next(int64_t nd) {
+        if (!base) return nullptr;
+        if (countdown > 0) {
+            --countdown;
+            return nullptr;
+        }
+        float* p = base + (int64_t)row * nd;
+        row = row + 1 == ring ? 0 : row + 1;
+        countdown = stride - 1;
+        return p;
+    }
+};
+// the same for transition t of the call, out of order (the data-parallel IMH replay writes runs of equal states)
+__device__ __forceinline__ float* store_row_of(const NfmcSampleStore& s, int t, int64_t nd) {
+    const int k = t - s.countdown;
+    if (!s.base || k < 0 || k % s.stride != 0) return nullptr;
+    return s.base + (int64_t)((s.row + k / s.stride) % s.ring_rows) * nd;
+}
+inline bool store_ok(const NfmcSampleStore& s) {
+    return !s.base || (s.stride >= 1 && s.countdown >= 0 && s.countdown < s.stride && s.ring_rows >= 1 && s.row >= 0 &&
+                       s.row < s.ring_rows);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Deterministic statistics.  Each lane carries fp32 partial sums over the <= 512 steps of one call;
 // they are widened to fp64, reduced over the chains of the wave by shuffles, over the waves of the
 // workgroup through LDS, written to the workgroup's slot of the scratch slab, and a second tiny

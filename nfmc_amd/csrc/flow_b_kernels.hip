@@ -66,6 +66,7 @@ __global__ void __launch_bounds__(kBlock, NFMC_FLOWB_WPE) flow_mh_b_kernel(NfmcF
             for (int i = 0; i < CPL; ++i) part = fmaf(-0.5f * w[i], w[i], part);
             f_x = group_allreduce<LPC>(part) + base_c;
         }
+        StoreCursor keep(a.samples);
         for (int s = 0; s < a.n_steps; ++s) {
             float xp[CPL];
             draw_latent<CPL, LPC, FAST>(xp, (DIAG && a.rng.replay_normals) ? a.rng.replay_normals + (int64_t)s * n * d : nullptr, a.rng.seed,
@@ -107,7 +108,9 @@ __global__ void __launch_bounds__(kBlock, NFMC_FLOWB_WPE) flow_mh_b_kernel(NfmcF
                 sx[i] += x[i];
                 sxx[i] = fmaf(x[i], x[i], sxx[i]);
             }
-            if (DIAG && a.samples) store_row<CPL, LPC, FAST>(a.samples + (int64_t)s * n * d, row, d, g, active, x);
+            if constexpr (DIAG) {
+                if (float* kept = keep.next(n * d)) store_row<CPL, LPC, FAST>(kept, row, d, g, active, x);
+            }
             if (DIAG && g == 0 && active) {
                 if (a.masks_out) a.masks_out[(int64_t)s * n + row] = accept ? 1 : 0;
                 if (a.log_ratio_out) a.log_ratio_out[(int64_t)s * n + row] = lr;
@@ -134,7 +137,7 @@ static int launch_b(const NfmcFlowMhArgs& a, bool fast, int64_t tiles, int grid,
                                                                                        a.flow.n_coupling) * sizeof(float); \
         if (lds > 120 * 1024) return NFMC_EUNSUPPORTED;                                                         \
         if (dry) return 0;                                                                                      \
-        const bool diag = !F || a.rng.replay_normals || a.rng.replay_uniforms || a.samples || a.masks_out ||    \
+        const bool diag = !F || a.rng.replay_normals || a.rng.replay_uniforms || a.samples.base || a.masks_out ||    \
                           a.log_ratio_out;                                                                      \
         auto kern = diag ? flow_mh_b_kernel<CPL, LPC, HP, POT, F, true> : flow_mh_b_kernel<CPL, LPC, HP, POT, F, (F ? false : true)>; \
         if (lds > 48 * 1024) {                                                                                  \
@@ -175,7 +178,7 @@ int flow_mh_b_launch(const NfmcFlowMhArgs& a, hipStream_t st, int* grid_out, int
     if (!c.cpl) return NFMC_EUNSUPPORTED;
     const int dp = c.cpl * c.lpc;
     const bool fast = d == dp && (d % 4) == 0 && a.pot.a == nullptr && a.pot.b == nullptr &&
-                      (((uintptr_t)a.x) & 15u) == 0 && (!a.samples || (((uintptr_t)a.samples) & 15u) == 0);
+                      (((uintptr_t)a.x) & 15u) == 0 && (!a.samples.base || (((uintptr_t)a.samples.base) & 15u) == 0);
     const int cpw = kWave / c.lpc;
     const int64_t tiles = (a.n + (int64_t)kWavesPerBlock * cpw - 1) / ((int64_t)kWavesPerBlock * cpw);
     // Persistent workgroups: the weight image is staged once per workgroup and every wave pays a fixed prologue /

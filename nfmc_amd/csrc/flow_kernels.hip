@@ -152,6 +152,7 @@ __global__ void __launch_bounds__(kFlowBlock) flow_mh_kernel(NfmcFlowMhArgs a, i
             for (int c = 0; c < d; ++c) ss = fmaf(pr[c], pr[c], ss);
             f_x = -0.5f * ss + base_c + ld;
         }
+        StoreCursor keep(a.samples);
         for (int s = 0; s < a.n_steps; ++s) {
             const float ss = draw_latent_row(pr, g, a.rng, row, n, s);       // flow.sample: jump.py:205 / imh.py:221
             const float ldi = flow_inverse_row<HP>(pr, f, g, hbuf);
@@ -200,7 +201,7 @@ __global__ void __launch_bounds__(kFlowBlock) flow_mh_kernel(NfmcFlowMhArgs a, i
                     }
                 }
             }
-            if (a.samples) tile_store(xt, stride, a.samples + (int64_t)s * n * d, r0, n, d);
+            if (float* kept = keep.next(n * (int64_t)d)) tile_store(xt, stride, kept, r0, n, d);
             __syncthreads();
         }
         tile_store(xt, stride, a.x, r0, n, d);
@@ -362,6 +363,7 @@ static int check_flow_mh(const NfmcFlowMhArgs& a) {
     if (a.pot.kind != NFMC_POT_QUADRATIC && a.pot.kind != NFMC_POT_FUNNEL) return NFMC_EUNSUPPORTED;
     if (a.stats.sum_x && (!a.stats.sum_x2 || !a.stats.counters || !a.stats.scratch)) return NFMC_EINVAL;
     if (a.adjusted && (a.rng.replay_normals != nullptr) != (a.rng.replay_uniforms != nullptr)) return NFMC_EINVAL;
+    if (!store_ok(a.samples)) return NFMC_EINVAL;
     return NFMC_OK;
 }
 
@@ -375,7 +377,7 @@ extern "C" int nfmc_flow_mh_supported_f32(const NfmcFlowMhArgs* args) {
     int grid = 0, dp = 0;
     rc = (getenv("NFMC_FLOW_TILE_PATH") || a.flow.n_bins != 0) ? NFMC_EUNSUPPORTED : flow_mh_b_launch(a, nullptr, &grid, &dp, true);
     if (rc != NFMC_EUNSUPPORTED) return rc;
-    if (use_mfma_flow(&a.flow) && al16(a.x) && al16(a.samples)) return NFMC_OK;
+    if (use_mfma_flow(&a.flow) && al16(a.x) && al16(a.samples.base)) return NFMC_OK;
     return flow_mh_tile_lds(a.flow) <= kMaxLdsBytes ? NFMC_OK : NFMC_EUNSUPPORTED;
 }
 
@@ -389,7 +391,7 @@ extern "C" int nfmc_flow_mh_steps_f32(const NfmcFlowMhArgs* args, nfmc_stream_t 
     hipStream_t st = (hipStream_t)stream;
     int grid = 0;
     rc = (getenv("NFMC_FLOW_TILE_PATH") || a.flow.n_bins != 0) ? NFMC_EUNSUPPORTED : flow_mh_b_launch(a, st, &grid, &dp, false);
-    if (rc == NFMC_EUNSUPPORTED && use_mfma_flow(&a.flow) && al16(a.x) && al16(a.samples)) {
+    if (rc == NFMC_EUNSUPPORTED && use_mfma_flow(&a.flow) && al16(a.x) && al16(a.samples.base)) {
         // wide conditioners at d = 64 / 128 (16-byte aligned rows): matrix cores
         rc = nfmc_flow_mh_steps_mfma_f32(a, stream, &grid, &dp);
         if (rc) return rc;

@@ -149,6 +149,7 @@ __global__ void __launch_bounds__(kMfmaBlock, 2) flow_mh_mfma_kernel(NfmcFlowMhA
             const float ld = chain_sum(flow_forward_sweep_c<TD, TH, NHL>(w, f, wp, col, half));
             f_x = -0.5f * sum_squares_c<TD>(w) + base_c + ld;
         }
+        StoreCursor keep(a.samples);
         for (int s = 0; s < a.n_steps; ++s) {
             // per-step opaque copies of the row index (cf. neutra_mfma.hip: addresses must not live through the GEMMs)
             int64_t row = row_t, rrow = rrow_t;
@@ -182,12 +183,13 @@ __global__ void __launch_bounds__(kMfmaBlock, 2) flow_mh_mfma_kernel(NfmcFlowMhA
                 u_x = u_xp;
                 if (half == 0) n_acc++;
             }
+            float* kept = keep.next(n * (int64_t)d);
             if (active) {
                 if (half == 0) {
                     if (a.masks_out) a.masks_out[(int64_t)s * n + row] = accept ? 1 : 0;
                     if (a.log_ratio_out) a.log_ratio_out[(int64_t)s * n + row] = lr;
                 }
-                if (a.samples) store_ctiles<TD>(x, a.samples + (int64_t)s * n * d, row, d, half, false);
+                if (kept) store_ctiles<TD>(x, kept, row, d, half, false);
             }
             if (a.stats.sum_x) {  // K7: sums over the 16 chains of the wave, kept per wave in LDS
 #pragma unroll

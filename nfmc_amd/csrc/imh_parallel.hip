@@ -239,11 +239,13 @@ __global__ void __launch_bounds__(kBlock) imh_replay_kernel(NfmcFlowMhArgs a, Im
                     sxx[q] = fmaf(cf * xs[q], xs[q], sxx[q]);
                 }
                 if (!initial) {
-                    if (a.samples)
-                        for (int t = s; t < s + c; ++t) store_row<CPL, LPC, FAST>(a.samples + (int64_t)t * n * d, i, d, g, true, xs);
+                    if (a.samples.base)
+                        for (int t = s; t < s + c; ++t)
+                            if (float* kept = store_row_of(a.samples, t, n * (int64_t)d)) store_row<CPL, LPC, FAST>(kept, i, d, g, true, xs);
                     if (w.last[i] == s) store_row<CPL, LPC, FAST>(a.x, i, d, g, true, xs);
-                } else if (a.samples) {
-                    for (int t = 0; t < c; ++t) store_row<CPL, LPC, FAST>(a.samples + (int64_t)t * n * d, i, d, g, true, xs);
+                } else if (a.samples.base) {
+                    for (int t = 0; t < c; ++t)
+                        if (float* kept = store_row_of(a.samples, t, n * (int64_t)d)) store_row<CPL, LPC, FAST>(kept, i, d, g, true, xs);
                 }
             }
             for (int t = 0; t < CPW && todo; ++t) todo &= todo - 1ull;   // CPW rows done
@@ -289,7 +291,7 @@ static int launch_imh(const NfmcFlowMhArgs& a, const ImhWork& w, hipStream_t st,
     }
     const int d = a.flow.d;
     const bool fast = d == dp && (d % 4) == 0 && a.pot.a == nullptr && a.pot.b == nullptr && (((uintptr_t)a.x) & 15u) == 0 &&
-                      (((uintptr_t)w.x0) & 15u) == 0 && (!a.samples || (((uintptr_t)a.samples) & 15u) == 0);
+                      (((uintptr_t)w.x0) & 15u) == 0 && (!a.samples.base || (((uintptr_t)a.samples.base) & 15u) == 0);
     if (a.pot.kind == NFMC_POT_FUNNEL) NFMC_LI(FunnelPot, false)
     else if (fast) NFMC_LI(QuadraticPot, true)
     else NFMC_LI(QuadraticPot, false)
@@ -326,7 +328,7 @@ static int imh_parallel_run(const NfmcFlowMhArgs* args, void* work, int64_t work
     if (!args) return NFMC_EINVAL;
     NfmcFlowMhArgs a = *args;
     const NfmcRealNVP& f = a.flow;
-    if (!a.x || !a.logq || a.n <= 0 || a.n_steps <= 0 || !a.adjusted) return NFMC_EINVAL;
+    if (!a.x || !a.logq || a.n <= 0 || a.n_steps <= 0 || !a.adjusted || !store_ok(a.samples)) return NFMC_EINVAL;
     if (!f.ea0_log_scale || !f.ea0_shift || !f.ea1_log_scale || !f.ea1_shift || (f.n_coupling > 0 && !f.weights)) return NFMC_EINVAL;
     if (f.d < 2 || f.d > 512 || a.n_steps > NFMC_IMH_PARALLEL_MAX_STEPS) return NFMC_ESHAPE;
     if (f.n_hidden <= 0 || f.n_hidden > 8 || f.n_hidden_layers <= 0 || f.n_bins != 0) return NFMC_EUNSUPPORTED;

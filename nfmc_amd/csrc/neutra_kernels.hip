@@ -237,6 +237,7 @@ __global__ void __launch_bounds__(kNeutraBlock) neutra_hmc_kernel(NfmcNeutraHmcA
         __syncthreads();
         float u_cur = adjusted_potential_grad_row<HP>(zr, wr, gr, f, g, a.pot);  // U~(z), grad at the current state
         uint4 ur = make_uint4(0, 0, 0, 0);
+        StoreCursor keep(a.samples);
         for (int s = 0; s < a.n_steps; ++s) {
             // momentum p = eps / sqrt(m)  (hmc.py:100); tile columns are latent positions: logical c <-> col latent_col(c)
             float kin0 = 0.f;
@@ -338,7 +339,7 @@ __global__ void __launch_bounds__(kNeutraBlock) neutra_hmc_kernel(NfmcNeutraHmcA
                     }
                 }
             }
-            if (a.samples) tile_store(zt, stride, a.samples + (int64_t)s * n * d, r0, n, d, rev);
+            if (float* kept = keep.next(n * (int64_t)d)) tile_store(zt, stride, kept, r0, n, d, rev);
             __syncthreads();
         }
     }
@@ -439,6 +440,7 @@ extern "C" int nfmc_neutra_hmc_steps_f32(const NfmcNeutraHmcArgs* args, nfmc_str
         if (a.pot.kind != NFMC_POT_QUADRATIC && a.pot.kind != NFMC_POT_FUNNEL) return NFMC_EUNSUPPORTED;
         if (a.stats.sum_x && (!a.stats.sum_x2 || !a.stats.counters || !a.stats.scratch)) return NFMC_EINVAL;
         if (a.adjust && (a.rng.replay_normals != nullptr) != (a.rng.replay_uniforms != nullptr)) return NFMC_EINVAL;
+        if (!store_ok(a.samples)) return NFMC_EINVAL;
         return nfmc_neutra_hmc_steps_mfma_f32(&a, a.scratch, a.scratch_bytes, stream);
     }
     int rc = check_flow_neutra(&a.flow);
@@ -448,6 +450,7 @@ extern "C" int nfmc_neutra_hmc_steps_f32(const NfmcNeutraHmcArgs* args, nfmc_str
     if (a.pot.kind != NFMC_POT_QUADRATIC && a.pot.kind != NFMC_POT_FUNNEL) return NFMC_EUNSUPPORTED;
     if (a.stats.sum_x && (!a.stats.sum_x2 || !a.stats.counters || !a.stats.scratch)) return NFMC_EINVAL;
     if (a.adjust && (a.rng.replay_normals != nullptr) != (a.rng.replay_uniforms != nullptr)) return NFMC_EINVAL;
+    if (!store_ok(a.samples)) return NFMC_EINVAL;
     const int d = a.flow.d;
     const int dp = padded_d(d);
     const int64_t tiles = (a.n + 63) / 64;

@@ -222,6 +222,7 @@ struct LeapArgs {
     NfmcNeutraHmcArgs a;
     float *p, *gz, *uz, *h0;  // scratch: momentum; gradient and U~ at the current state; H0
     int step;                  // transition index within this call
+    float* sample_row;         // store row this transition is kept in (NfmcSampleStore walked on the host), or NULL
 };
 
 // mass / momentum helpers in C layout: tile position pos <-> logical latent coordinate (rev ? d-1-pos : pos)
@@ -373,7 +374,7 @@ __global__ void __launch_bounds__(kMfmaBlock, 2) neutra_leapfrog_mfma_kernel(Lea
                 if (a.masks_out) a.masks_out[(int64_t)s * n + row] = accept ? 1 : 0;
                 if (a.log_ratio_out) a.log_ratio_out[(int64_t)s * n + row] = lr;
             }
-            if (a.samples) store_ctiles<TD>(zc, a.samples + (int64_t)s * n * d, row, d, half, rev);
+            if (A.sample_row) store_ctiles<TD>(zc, A.sample_row, row, d, half, rev);
         }
         if (a.stats.sum_x) {  // sums over the 16 chains of the wave (lanes of one lane group), kept per wave in LDS
 #pragma unroll
@@ -452,8 +453,19 @@ static int run_hmc(const NfmcNeutraHmcArgs& a, float* scratch, hipStream_t st) {
     auto kern = neutra_leapfrog_mfma_kernel<TD, TH, NHL>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMfmaLdsBytes);
     if (e != hipSuccess) return (int)e;
+    int countdown = a.samples.countdown, srow = a.samples.row;   // one launch per transition: the store cursor runs here
     for (int s = 0; s < a.n_steps; ++s) {
         A.step = s;
+        A.sample_row = nullptr;
+        if (a.samples.base) {
+            if (countdown > 0) {
+                --countdown;
+            } else {
+                A.sample_row = a.samples.base + (int64_t)srow * n * d;
+                srow = srow + 1 == a.samples.ring_rows ? 0 : srow + 1;
+                countdown = a.samples.stride - 1;
+            }
+        }
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kMfmaBlock), kMfmaLdsBytes, st, A, tiles, dp);
         if (a.stats.sum_x) {
             hipLaunchKernelGGL(stats_finish_kernel<true>, dim3(stats_finish_grid(dp)), dim3(kFinishBlock), 0, st,

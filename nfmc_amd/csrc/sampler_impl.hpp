@@ -214,6 +214,7 @@ __global__ void __launch_bounds__(kBlock, NFMC_WPE) mala_kernel(NfmcMalaArgs a, 
         float x[CPL];
         load_row<CPL, LPC, FAST>(a.x, row, d, g, active, x);
         AcceptUniform au;
+        StoreCursor keep(a.samples);
         float sq = 0.f, sq_prop = 0.f;   // FAST quadratic: this lane's share of |x|^2 (current state / proposal)
         if constexpr (Pot<CPL, LPC, FAST>::kQuadratic && FAST) {
 #pragma unroll
@@ -284,7 +285,7 @@ __global__ void __launch_bounds__(kBlock, NFMC_WPE) mala_kernel(NfmcMalaArgs a, 
                 sx[i] += x[i];
                 sxx[i] = fmaf(x[i], x[i], sxx[i]);
             }
-            if (a.samples) store_row<CPL, LPC, FAST>(a.samples + (int64_t)s * n * d, row, d, g, active, x);
+            if (float* kept = keep.next(n * d)) store_row<CPL, LPC, FAST>(kept, row, d, g, active, x);
             if (g == 0 && active) {
                 if (a.masks_out) a.masks_out[(int64_t)s * n + row] = accept ? 1 : 0;
                 if (a.log_ratio_out) a.log_ratio_out[(int64_t)s * n + row] = lr;
@@ -303,7 +304,7 @@ __global__ void __launch_bounds__(kBlock, NFMC_WPE) mala_kernel(NfmcMalaArgs a, 
                 sx[i] += x[i];
                 sxx[i] = fmaf(x[i], x[i], sxx[i]);
             }
-            if (a.samples) store_row<CPL, LPC, FAST>(a.samples + (int64_t)a.n_steps * n * d, row, d, g, active, x);
+            if (float* kept = keep.next(n * d)) store_row<CPL, LPC, FAST>(kept, row, d, g, active, x);
             if (g == 0 && active) {
                 if (jd.mask_out) jd.mask_out[row] = acc ? 1 : 0;
                 if (jd.log_ratio_out) jd.log_ratio_out[row] = lr;
@@ -353,6 +354,7 @@ __global__ void __launch_bounds__(kBlock, NFMC_WPE) hmc_kernel(NfmcHmcArgs a, in
         float x[CPL];
         load_row<CPL, LPC, FAST>(a.x, row, d, g, active, x);
         AcceptUniform au;
+        StoreCursor keep(a.samples);
 
         for (int s = 0; s < a.n_steps; ++s) {
             float p[CPL], q[CPL];
@@ -412,7 +414,7 @@ __global__ void __launch_bounds__(kBlock, NFMC_WPE) hmc_kernel(NfmcHmcArgs a, in
                 sx[i] += x[i];
                 sxx[i] = fmaf(x[i], x[i], sxx[i]);
             }
-            if (a.samples) store_row<CPL, LPC, FAST>(a.samples + (int64_t)s * n * d, row, d, g, active, x);
+            if (float* kept = keep.next(n * d)) store_row<CPL, LPC, FAST>(kept, row, d, g, active, x);
             if (g == 0 && active) {
                 if (a.masks_out) a.masks_out[(int64_t)s * n + row] = accept ? 1 : 0;
                 if (a.log_ratio_out) a.log_ratio_out[(int64_t)s * n + row] = lr;
@@ -431,7 +433,7 @@ __global__ void __launch_bounds__(kBlock, NFMC_WPE) hmc_kernel(NfmcHmcArgs a, in
                 sx[i] += x[i];
                 sxx[i] = fmaf(x[i], x[i], sxx[i]);
             }
-            if (a.samples) store_row<CPL, LPC, FAST>(a.samples + (int64_t)a.n_steps * n * d, row, d, g, active, x);
+            if (float* kept = keep.next(n * d)) store_row<CPL, LPC, FAST>(kept, row, d, g, active, x);
             if (g == 0 && active) {
                 if (jd.mask_out) jd.mask_out[row] = acc ? 1 : 0;
                 if (jd.log_ratio_out) jd.log_ratio_out[row] = lr;

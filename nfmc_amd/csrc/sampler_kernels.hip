@@ -42,6 +42,7 @@ static int check_common(const Args* a) {
     if (!(a->step_size > 0.f)) return NFMC_EINVAL;
     if (a->pot.kind != NFMC_POT_QUADRATIC && a->pot.kind != NFMC_POT_FUNNEL) return NFMC_EUNSUPPORTED;
     if (((uintptr_t)a->x & 3u) != 0) return NFMC_EALIGN;
+    if (!store_ok(a->samples)) return NFMC_EINVAL;
     if ((a->rng.replay_normals == nullptr) != (a->rng.replay_uniforms == nullptr) && (a->adjust & 1)) return NFMC_EINVAL;
     if (a->stats.sum_x && (!a->stats.sum_x2 || !a->stats.counters || !a->stats.scratch)) return NFMC_EINVAL;
     if (a->jump) {
@@ -62,7 +63,7 @@ static bool fast_path(const Args* a, const Cfg& c) {
     // the FAST kernels assume a scalar potential with b = 0 (the carried |x|^2 of the Langevin ratio)
     return a->d == c.cpl * c.lpc && a->inv_mass_diag == nullptr && a->pot.a == nullptr && a->pot.b == nullptr &&
            (a->pot.kind != NFMC_POT_QUADRATIC || a->pot.b_scalar == 0.f) && aligned16(a->x) &&
-           (!a->samples || aligned16(a->samples));
+           (!a->samples.base || aligned16(a->samples.base));
 }
 
 static JumpDev jump_dev(const NfmcJumpTail* j) {

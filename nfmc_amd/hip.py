@@ -45,6 +45,10 @@ class NfmcRealNVP(C.Structure):
                 ('weights', c_fp), ('layer_stride', C.c_int64), ('spline_bound', C.c_float), ('reserved', C.c_int32)]
 
 
+class NfmcSampleStore(C.Structure):
+    _fields_ = [('base', c_fp), ('stride', C.c_int32), ('countdown', C.c_int32), ('ring_rows', C.c_int32), ('row', C.c_int32)]
+
+
 class NfmcJumpTail(C.Structure):
     _fields_ = [('flow', NfmcRealNVP), ('adjusted', C.c_int32), ('reserved', C.c_int32), ('counters', c_fp),
                 ('replay_latent', c_fp), ('replay_uniform', c_fp), ('mask_out', c_fp), ('log_ratio_out', c_fp)]
@@ -54,20 +58,20 @@ class NfmcMalaArgs(C.Structure):
     _fields_ = [('x', c_fp), ('n', C.c_int64), ('d', C.c_int32), ('n_steps', C.c_int32),
                 ('step_size', C.c_float), ('adjust', C.c_int32), ('inv_mass_diag', c_fp),
                 ('pot', NfmcPotential), ('rng', NfmcRng), ('stats', NfmcStats),
-                ('samples', c_fp), ('masks_out', c_fp), ('log_ratio_out', c_fp), ('jump', C.POINTER(NfmcJumpTail))]
+                ('samples', NfmcSampleStore), ('masks_out', c_fp), ('log_ratio_out', c_fp), ('jump', C.POINTER(NfmcJumpTail))]
 
 
 class NfmcHmcArgs(C.Structure):
     _fields_ = [('x', c_fp), ('n', C.c_int64), ('d', C.c_int32), ('n_steps', C.c_int32),
                 ('step_size', C.c_float), ('n_leapfrog', C.c_int32), ('adjust', C.c_int32), ('reserved', C.c_int32),
                 ('inv_mass_diag', c_fp), ('pot', NfmcPotential), ('rng', NfmcRng), ('stats', NfmcStats),
-                ('samples', c_fp), ('masks_out', c_fp), ('log_ratio_out', c_fp), ('jump', C.POINTER(NfmcJumpTail))]
+                ('samples', NfmcSampleStore), ('masks_out', c_fp), ('log_ratio_out', c_fp), ('jump', C.POINTER(NfmcJumpTail))]
 
 
 class NfmcFlowMhArgs(C.Structure):
     _fields_ = [('x', c_fp), ('logq', c_fp), ('n', C.c_int64), ('n_steps', C.c_int32), ('logq_cached', C.c_int32),
                 ('adjusted', C.c_int32), ('reserved', C.c_int32), ('flow', NfmcRealNVP), ('pot', NfmcPotential),
-                ('rng', NfmcRng), ('stats', NfmcStats), ('samples', c_fp), ('masks_out', c_fp),
+                ('rng', NfmcRng), ('stats', NfmcStats), ('samples', NfmcSampleStore), ('masks_out', c_fp),
                 ('log_ratio_out', c_fp)]
 
 
@@ -75,7 +79,7 @@ class NfmcNeutraHmcArgs(C.Structure):
     _fields_ = [('z', c_fp), ('n', C.c_int64), ('n_steps', C.c_int32), ('n_leapfrog', C.c_int32),
                 ('step_size', C.c_float), ('adjust', C.c_int32), ('inv_mass_diag', c_fp),
                 ('flow', NfmcRealNVP), ('pot', NfmcPotential), ('rng', NfmcRng), ('stats', NfmcStats),
-                ('samples', c_fp), ('masks_out', c_fp), ('log_ratio_out', c_fp), ('scratch', c_fp),
+                ('samples', NfmcSampleStore), ('masks_out', c_fp), ('log_ratio_out', c_fp), ('scratch', c_fp),
                 ('scratch_bytes', C.c_int64)]
 
 
@@ -292,6 +296,26 @@ class DeviceStats:
     def zero_(self):
         self.fold()
         self._buf.zero_()
+
+
+def dense_store(t):
+    """NfmcSampleStore that keeps every transition of one call in the rows of `t` (k, n, d), in order (None: nothing)."""
+    if t is None:
+        return NfmcSampleStore(None, 1, 0, 1, 0)
+    return NfmcSampleStore(ptr(t), 1, 0, int(t.shape[0]), 0)
+
+
+def store_struct(samples, k):
+    """NfmcSampleStore for a call that offers k transitions: `samples` is None (keep nothing), a
+    containers.DeviceSampleStore (thinning / bounded window decided here, before the launch), or a dense (k, n, d)
+    device tensor (every transition kept, in order)."""
+    if samples is None:
+        return dense_store(None)
+    if hasattr(samples, 'struct'):
+        return samples.struct(k)
+    if int(samples.shape[0]) != int(k):
+        raise ValueError('dense sample view has %d rows for %d transitions' % (samples.shape[0], k))
+    return dense_store(samples)
 
 
 def null_stats():

@@ -157,7 +157,7 @@ def sample(target: Union[callable, Potential],
         x0 = torch.randn(size=(n_chains, *event_shape))  # drawn after flow construction, sample.py:304-305
     if warmup:
         warmup_output = sampler.warmup(x0=x0, show_progress=show_progress, time_limit_seconds=warmup_time_limit_seconds)
-        if warmup_output.samples is not None:
+        if warmup_output.store_samples:       # (not `.samples`: that would copy the whole store to the host)
             flat = warmup_output.samples_device.flatten(0, 1)
             x0 = flat[torch.randperm(len(flat), device=flat.device)][:x0.shape[0]]
         else:

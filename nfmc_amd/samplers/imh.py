@@ -11,7 +11,7 @@ import torch
 from tqdm import tqdm
 
 from .. import hip
-from ..containers import MCMCOutput, NFMCKernel, NFMCParameters, Sampler
+from ..containers import DeviceSampleStore, MCMCOutput, NFMCKernel, NFMCParameters, Sampler
 from .common import Run, chunks, resolve_target
 from .jump import (flow_is_native, flow_mh_supported, imh_parallel_ok, launch_flow_mh, launch_imh_parallel,
                    split_flow_mh)
@@ -75,12 +75,14 @@ class FixedIMH(AbstractIMH):
         """imh.py:200-255 on the device."""
         run = Run(self, x0)
         n, d, event_shape = run.n, run.d, run.event_shape
-        out = MCMCOutput(event_shape, store_samples=self.params.store_samples)
+        out = MCMCOutput(event_shape, store_samples=self.params.store_samples,
+                         max_samples=getattr(self.params, 'max_samples', None))
         flow = self.kernel.flow
         T = int(self.params.n_iterations)
         pot = resolve_target(self.target, event_shape, self.fuse, run.x)
         fused = pot is not None and flow_is_native(flow)
-        buf = torch.empty(T, n, d, dtype=torch.float32, device=run.dev) if (self.params.store_samples and T > 0) else None
+        store = DeviceSampleStore(n, d, run.dev, T, getattr(self.params, 'thinning', 1),
+                                  getattr(self.params, 'max_samples', None)) if (self.params.store_samples and T > 0) else None
         logq = torch.empty(n, dtype=torch.float32, device=run.dev)
         fused = fused and flow_mh_supported(run, flow, pot, logq)
         t0 = time.time()
@@ -98,17 +100,16 @@ class FixedIMH(AbstractIMH):
             if fused and parallel and unlimited:
                 # all proposals of the chunk at once: as many steps as 2^26 work items (1 GiB of work arrays) allow
                 k = min(T - done, hip.IMH_PARALLEL_MAX_STEPS, max(16, (1 << 26) // max(n, 1)))
-            view = buf[done:done + k] if buf is not None else None
             if fused and parallel:
                 launch_imh_parallel(run, flow, pot, logq, k, done, done > 0,
-                                    run.stats.struct(defer=True, attempted=n * k), view)
+                                    run.stats.struct(defer=True, attempted=n * k), store)
             elif fused:
                 launch_flow_mh(run, flow, pot, logq, k, done, done > 0, True,
-                               run.stats.struct(defer=True, attempted=n * k), view)
+                               run.stats.struct(defer=True, attempted=n * k), store)
             else:
                 split_flow_mh(run, flow, self.target, event_shape, done, True, run.stats.struct(), logq=logq)
-                if view is not None:
-                    view[0].copy_(run.x)
+                if store is not None:
+                    store.add_dense(run.x[None])
             done += k
             bar.update(k)
         bar.close()
@@ -119,8 +120,8 @@ class FixedIMH(AbstractIMH):
                            n_attempted_trajectories=int(cnt[hip.CNT_ATTEMPTED]))
         st.n_nonfinite_log_ratios = int(cnt[hip.CNT_NONFINITE])
         st.absorb_device_sums(sum_x.reshape(event_shape), sum_x2.reshape(event_shape), n * done)
-        if buf is not None and done > 0:
-            out.running_samples.add(buf[:done].reshape(done, n, *event_shape))
+        if store is not None:
+            out.running_samples.adopt_store(store, getattr(self.params, 'spill_to_host', False))
         out.running_samples.last_sample = run.x.reshape(n, *event_shape).clone()
         st.update_elapsed_time(time.time() - t0)
         out.kernel = self.kernel

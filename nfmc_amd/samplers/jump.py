@@ -15,7 +15,8 @@ import torch
 from tqdm import tqdm
 
 from .. import hip
-from ..containers import MCMCKernel, MCMCOutput, MCMCParameters, MCMCStatistics, NFMCKernel, NFMCParameters, Sampler
+from ..containers import (DeviceSampleStore, MCMCKernel, MCMCOutput, MCMCParameters, MCMCStatistics, NFMCKernel,
+                          NFMCParameters, Sampler)
 from ..flows import Flow, RealNVP
 from ..tuning import train_val_split
 from ..util import metropolis_acceptance_log_ratio
@@ -112,7 +113,7 @@ def launch_flow_mh(run: Run, flow, pot, logq, k, step0, cached, adjusted, stats_
     a.pot = pot.descriptor(run.dev)
     a.rng = run.rng(step0, k, adjusted=adjusted)
     a.stats = stats_struct
-    a.samples = hip.ptr(samples) if samples is not None else None
+    a.samples = hip.store_struct(samples, k)
     a.masks_out = hip.ptr(masks_out, torch.uint8) if masks_out is not None else None
     a.log_ratio_out = hip.ptr(log_ratio_out) if log_ratio_out is not None else None
     with run.timed('flow_mh_steps'):
@@ -165,7 +166,7 @@ def launch_imh_parallel(run: Run, flow, pot, logq, k, step0, cached, stats_struc
     a.pot = pot.descriptor(run.dev)
     a.rng = run.rng(step0, k, adjusted=True)
     a.stats = stats_struct
-    a.samples = hip.ptr(samples) if samples is not None else None
+    a.samples = hip.store_struct(samples, k)
     a.masks_out = hip.ptr(masks_out, torch.uint8) if masks_out is not None else None
     a.log_ratio_out = hip.ptr(log_ratio_out) if log_ratio_out is not None else None
     nbytes = int(hip.lib().nfmc_imh_parallel_work_bytes(run.n, run.d, k))
@@ -281,7 +282,8 @@ class JumpNFMC(Sampler):
             raise ValueError("Inner sampler in jump HMC must store samples")
         run = Run(self, x0)
         n, d, event_shape = run.n, run.d, run.event_shape
-        out = JumpNFMCOutput(event_shape, store_samples=self.params.store_samples)
+        out = JumpNFMCOutput(event_shape, store_samples=self.params.store_samples,
+                             max_samples=getattr(self.params, 'max_samples', None))
         flow = self.kernel.flow
         T, K = int(self.params.n_iterations), int(inner.params.n_iterations)
         off = (False, 'never')
@@ -294,8 +296,11 @@ class JumpNFMC(Sampler):
         inner._n_divergences = 0
         jump_target_calls = 0
 
-        buf = torch.empty(T * (K + 1), n, d, dtype=torch.float32, device=run.dev) if self.params.store_samples else None
-        fit_buf = torch.empty(K, n, d, dtype=torch.float32, device=run.dev) if (self.params.fit_nf and buf is None) else None
+        # kept states of the whole run, T * (K + 1) offered: thinning / max_samples applied on the device (f3).  With
+        # fit_nf the inner states of one outer iteration are also needed as a dense block for the refit (fit_buf).
+        store = DeviceSampleStore(n, d, run.dev, T * (K + 1), getattr(self.params, 'thinning', 1),
+                                  getattr(self.params, 'max_samples', None)) if (self.params.store_samples and T > 0) else None
+        fit_buf = torch.empty(K, n, d, dtype=torch.float32, device=run.dev) if self.params.fit_nf else None
         logq = torch.empty(n, dtype=torch.float32, device=run.dev)
         if fused and not flow_mh_supported(run, flow, pot, logq, self.params.adjusted_jumps):
             fused = tail_ok = False   # the jump through the flow's own kernels (split_flow_mh)
@@ -307,7 +312,7 @@ class JumpNFMC(Sampler):
             if run.time_is_up(t0, time_limit_seconds):
                 break
             base = i * (K + 1)
-            inner_view = buf[base:base + K] if buf is not None else fit_buf
+            dense = fit_buf is not None   # inner states into the refit block (offered to the store afterwards), else straight into the store
             # ---- K inner transitions (jump.py:178); when the flow is narrow the jump rides at the end of
             # the last inner launch, on the same registers (NfmcJumpTail)
             tail_done = False
@@ -317,10 +322,7 @@ class JumpNFMC(Sampler):
                     tail = None
                     if last and tail_ok:
                         tail = make_jump_tail(run, flow, self.params.adjusted_jumps)
-                    if tail is not None:  # k inner rows + the jump row, contiguous in the store
-                        view = buf[base + off:base + off + k + 1] if buf is not None else None
-                    else:
-                        view = inner_view[off:off + k] if inner_view is not None else None
+                    view = fit_buf[off:off + k] if dense else store
                     if tail is not None and run.replay is not None:
                         # replay order: K inner fields, then the jump's latent + uniform
                         rng_inner = run.rng(base + off, k, adjusted=inner.params.adjustment)
@@ -334,27 +336,28 @@ class JumpNFMC(Sampler):
                     tail_done = tail is not None
             else:
                 for off in range(K):
-                    inner._split_step(run, base + off, inner_view[off:off + 1] if inner_view is not None else None)
+                    inner._split_step(run, base + off, fit_buf[off:off + 1] if dense else store)
+            if dense and store is not None:
+                store.add_dense(fit_buf)
             # ---- optional refit on this iteration's inner samples (jump.py:193-201)
             if self.params.fit_nf and i >= self.params.n_jumps_before_training:
-                x_train, x_val = train_val_split(inner_view.reshape(K, n, *event_shape),
+                x_train, x_val = train_val_split(fit_buf.reshape(K, n, *event_shape),
                                                  train_pct=self.params.train_pct,
                                                  max_train_size=self.params.max_train_size,
                                                  max_val_size=self.params.max_val_size, shard=self.shard)
                 flow.fit(x_train=x_train, x_val=x_val, **self.params.flow_fit_kwargs)
             # ---- the jump (jump.py:205-243)
-            jview = buf[base + K:base + K + 1] if buf is not None else None
             if tail_done:
                 jump_target_calls += 2 * n if self.params.adjusted_jumps else 0
             elif fused:
                 launch_flow_mh(run, flow, pot, logq, 1, base + K, False, self.params.adjusted_jumps,
-                               run.stats.struct(defer=True, attempted=n, jump=True), jview)
+                               run.stats.struct(defer=True, attempted=n, jump=True), store)
                 jump_target_calls += 2 * n if self.params.adjusted_jumps else 0
             else:
                 jump_target_calls += split_flow_mh(run, flow, self.target, event_shape, base + K,
                                                    self.params.adjusted_jumps, run.stats.struct(jump=True))
-                if jview is not None:
-                    jview[0].copy_(run.x)
+                if store is not None:
+                    store.add_dense(run.x[None])
             done = i + 1
             if show_progress:
                 run.sync()
@@ -373,8 +376,8 @@ class JumpNFMC(Sampler):
                            n_accepted_jumps=int(jc[hip.CNT_ACCEPTED]), n_attempted_jumps=n * done)
         st.n_nonfinite_log_ratios = int(cnt[hip.CNT_NONFINITE]) + int(jc[hip.CNT_NONFINITE])
         st.absorb_device_sums(sum_x.reshape(event_shape), sum_x2.reshape(event_shape), n * done * (K + 1))
-        if buf is not None and done > 0:
-            out.running_samples.add(buf[:done * (K + 1)].reshape(done * (K + 1), n, *event_shape))
+        if store is not None:
+            out.running_samples.adopt_store(store, getattr(self.params, 'spill_to_host', False))
         out.running_samples.last_sample = run.x.reshape(n, *event_shape).clone()
         st.update_elapsed_time(time.time() - t0)
         out.kernel = self.kernel

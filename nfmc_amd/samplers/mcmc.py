@@ -17,7 +17,7 @@ import torch
 from tqdm import tqdm
 
 from .. import hip
-from ..containers import MCMCKernel, MCMCOutput, MCMCParameters, Sampler
+from ..containers import DeviceSampleStore, MCMCKernel, MCMCOutput, MCMCParameters, Sampler
 from ..tuning import DualAveraging, DualAveragingParams
 from .common import Run, chunks, imd_tensor, resolve_target
 
@@ -158,11 +158,14 @@ class MCMCSampler(Sampler):
         step0 = 0
         n, d = run.n, run.d
         event_shape = run.event_shape
-        out = MCMCOutput(event_shape, store_samples=self.params.store_samples)
+        out = MCMCOutput(event_shape, store_samples=self.params.store_samples,
+                         max_samples=getattr(self.params, 'max_samples', None))
         out.statistics.data_transform = self.data_transform
         K = int(self.params.n_iterations)
         pot = resolve_target(self.target, event_shape, self.fuse, run.x)
-        buf = torch.empty(K, n, d, dtype=torch.float32, device=run.dev) if (self.params.store_samples and K > 0) else None
+        # kept states: thinning / max_samples window applied on the device, slab bounded by max_samples (f3)
+        store = DeviceSampleStore(n, d, run.dev, K, getattr(self.params, 'thinning', 1),
+                                  getattr(self.params, 'max_samples', None)) if (self.params.store_samples and K > 0) else None
         run.stats.zero_()
         self._n_divergences = 0
         t0 = time.time()
@@ -175,13 +178,12 @@ class MCMCSampler(Sampler):
             if run.time_is_up(t0, time_limit_seconds):
                 break
             k = min(limit, K - done)
-            view = buf[done:done + k] if buf is not None else None
             if pot is not None:
                 mask_buf = torch.empty(k, n, dtype=torch.uint8, device=run.dev) if self.params.tuning else None
-                self._launch(run, pot, k, step0 + done, view, masks_out=mask_buf)
+                self._launch(run, pot, k, step0 + done, store, masks_out=mask_buf)
                 mask = mask_buf[-1].bool() if mask_buf is not None else None
             else:
-                mask = self._split_step(run, step0 + done, view)
+                mask = self._split_step(run, step0 + done, store)
             if self.params.tuning:
                 with torch.no_grad():
                     self.update_kernel({'x': run.x.reshape(n, *event_shape), 'mask': mask})
@@ -199,8 +201,8 @@ class MCMCSampler(Sampler):
         out.statistics.absorb_device_sums(sum_x.reshape(event_shape), sum_x2.reshape(event_shape),
                                           n * done)
         rs = out.running_samples
-        if buf is not None and done > 0:
-            rs.add(buf[:done].reshape(done, n, *event_shape))
+        if store is not None:
+            rs.adopt_store(store, getattr(self.params, 'spill_to_host', False))
         rs.last_sample = run.x.reshape(n, *event_shape).clone()
         out.statistics.update_elapsed_time(time.time() - t0)
         out.kernel = self.kernel
@@ -239,7 +241,10 @@ class MCMCSampler(Sampler):
         st.mask_out = hip.ptr(mask, torch.uint8)
         hip.check(hip.lib().nfmc_mh_accept_select_f32(C.byref(st), hip.stream()), 'nfmc_mh_accept_select_f32')
         if sample_view is not None:
-            sample_view[0].copy_(run.x)
+            if hasattr(sample_view, 'add_dense'):
+                sample_view.add_dense(run.x[None])
+            else:
+                sample_view[0].copy_(run.x)
         return mask.bool()
 
 
@@ -305,7 +310,7 @@ class Langevin(MetropolisSampler):
         # `rng`: an NfmcRng prepared by the caller (replay bookkeeping of fused jump tails)
         a.rng = rng if rng is not None else run.rng(step0, k, adjusted=self.params.adjustment)
         a.stats = run.stats.struct(defer=True, attempted=run.n * k, jump_attempted=run.n if jump is not None else 0)
-        a.samples = hip.ptr(samples) if samples is not None else None
+        a.samples = hip.store_struct(samples, k + (1 if jump is not None else 0))
         a.masks_out = hip.ptr(masks_out, torch.uint8) if masks_out is not None else None
         a.log_ratio_out = hip.ptr(log_ratio_out) if log_ratio_out is not None else None
         a.jump = C.pointer(jump) if jump is not None else None
@@ -495,7 +500,7 @@ class HMC(MetropolisSampler):
         # `rng`: an NfmcRng prepared by the caller (replay bookkeeping of fused jump tails)
         a.rng = rng if rng is not None else run.rng(step0, k, adjusted=self.params.adjustment)
         a.stats = run.stats.struct(defer=True, attempted=run.n * k, jump_attempted=run.n if jump is not None else 0)
-        a.samples = hip.ptr(samples) if samples is not None else None
+        a.samples = hip.store_struct(samples, k + (1 if jump is not None else 0))
         a.masks_out = hip.ptr(masks_out, torch.uint8) if masks_out is not None else None
         a.log_ratio_out = hip.ptr(log_ratio_out) if log_ratio_out is not None else None
         a.jump = C.pointer(jump) if jump is not None else None

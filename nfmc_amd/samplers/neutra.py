@@ -17,7 +17,7 @@ import torch
 from tqdm import tqdm
 
 from .. import hip
-from ..containers import MCMCOutput, NFMCKernel, NFMCParameters, Sampler
+from ..containers import DeviceSampleStore, MCMCOutput, NFMCKernel, NFMCParameters, Sampler
 from .common import Run, chunks, imd_tensor, resolve_target
 from .mcmc import (HMC, MH, HMCKernel, HMCParameters, MHKernel, MHParameters, MetropolisKernel, MetropolisParameters,
                    MetropolisSampler)
@@ -138,6 +138,8 @@ class NeuTra(Sampler):
         inner.params.n_iterations = self.params.n_iterations
         inner.params.sampling_mode()
         inner.params.store_samples = self.params.store_samples
+        inner.params.thinning = getattr(self.params, 'thinning', 1)
+        inner.params.max_samples = getattr(self.params, 'max_samples', None)
         run = Run(self, x0)
         n, d, event_shape = run.n, run.d, run.event_shape
         pot = resolve_target(self.target, event_shape, self.fuse)
@@ -151,9 +153,11 @@ class NeuTra(Sampler):
 
         if not isinstance(inner, HMC) or pot is None or getattr(self.kernel.flow.bijection, 'n_bins', 0):
             return split()
-        out = MCMCOutput(event_shape, store_samples=self.params.store_samples)
+        out = MCMCOutput(event_shape, store_samples=self.params.store_samples,
+                         max_samples=getattr(self.params, 'max_samples', None))
         T = int(self.params.n_iterations)
-        buf = torch.empty(T, n, d, dtype=torch.float32, device=run.dev) if (self.params.store_samples and T > 0) else None
+        store = DeviceSampleStore(n, d, run.dev, T, getattr(self.params, 'thinning', 1),
+                                  getattr(self.params, 'max_samples', None)) if (self.params.store_samples and T > 0) else None
         st_flow, _keep = self.kernel.flow.bijection.packed(run.dev, self._min_hidden())
         imd = imd_tensor(inner.kernel, run.dev)
         bij = self.kernel.flow.bijection
@@ -177,7 +181,8 @@ class NeuTra(Sampler):
             a.pot = pot.descriptor(run.dev)
             a.rng = run.rng(done, k, adjusted=inner.params.adjustment)
             a.stats = run.stats.struct()
-            a.samples = hip.ptr(buf[done:done + k]) if buf is not None else None
+            seen_before = store.seen if store is not None else 0
+            a.samples = hip.store_struct(store, k)
             a.scratch, a.scratch_bytes = hip.ptr(scratch), sbytes
             try:
                 with run.timed('neutra_hmc_steps'):
@@ -186,6 +191,8 @@ class NeuTra(Sampler):
                 if done == 0 and e.no_kernel:   # validation precedes every launch: nothing has run yet
                     bar.close()
                     return split()
+                if store is not None:
+                    store.seen = seen_before
                 raise
             done += k
             bar.update(k)
@@ -199,8 +206,8 @@ class NeuTra(Sampler):
                            n_attempted_trajectories=int(cnt[hip.CNT_ATTEMPTED]))
         st.n_nonfinite_log_ratios = int(cnt[hip.CNT_NONFINITE])
         st.absorb_device_sums(sum_x.reshape(event_shape), sum_x2.reshape(event_shape), n * done)
-        if buf is not None and done > 0:
-            out.running_samples.add(buf[:done].reshape(done, n, *event_shape))
+        if store is not None:
+            out.running_samples.adopt_store(store, getattr(self.params, 'spill_to_host', False))
         out.running_samples.last_sample = run.x.reshape(n, *event_shape).clone()
         st.update_elapsed_time(time.time() - t0)
         out.kernel = inner.kernel

@@ -259,3 +259,91 @@ def test_C5_jump_hmc_32768x256_shard_properties(dev):
     assert lo4 <= lo and hi <= hi4
     c = run(sh4)
     assert torch.equal(c.running_samples.last_sample[lo - lo4:hi - lo4], a.running_samples.last_sample)
+
+
+# ================================================================================================ f3: kept states
+def _reference_window(dense, thinning, max_samples):
+    """MCMCSamples.add, one state at a time (nfmc/algorithms/sampling/base.py:249-263)."""
+    idx = [i for i in range(dense.shape[0]) if i % thinning == 0]
+    if max_samples:
+        idx = idx[-max_samples:]
+    return dense[idx]
+
+
+@pytest.mark.parametrize('strategy', ['mala', 'hmc', 'mh', 'imh', 'imh_seq', 'jump_mala', 'jump_hmc', 'jump_mala_tail',
+                                      'neutra_hmc', 'neutra_hmc_wide', 'jump_mala_wide', 'mala_callable'])
+@pytest.mark.parametrize('thinning,max_samples', [(3, None), (1, 5), (4, 3), (7, 100)])
+def test_thinning_and_max_samples_are_applied_on_the_device(dev, strategy, thinning, max_samples, monkeypatch):
+    """f3 (sampling/base.py:249-263): with `thinning` / `max_samples` the kernels write only the states that survive, into
+    a device slab of at most max_samples rows; the result equals the dense run (same seed) cut by the reference's rule,
+    bit for bit, on every kernel family: register samplers (+ fused jump tail), register / tile / matrix-core flow-MH,
+    data-parallel and sequential IMH, VALU and matrix-core NeuTra, and the split path of a plain callable."""
+    from nfmc_amd import sample
+    from nfmc_amd.containers import DeviceSampleStore
+    from nfmc_amd.potentials import SumOfSquares
+    from nfmc_amd.samplers import jump
+    d, n, T = 64, 70, 23
+    kw = dict(show_progress=False, seed=5, n_chains=n)
+    target = SumOfSquares((d,))
+    base = strategy
+    if strategy == 'imh_seq':
+        monkeypatch.setenv('NFMC_IMH_PARALLEL', '0')
+        base = 'imh'
+    if strategy.startswith('jump_mala') or strategy == 'jump_hmc':
+        T = 5
+        kw['inner_param_kwargs'] = {'n_iterations': 4}
+        base = 'jump_hmc' if strategy == 'jump_hmc' else 'jump_mala'
+        if strategy == 'jump_hmc':
+            kw['inner_kernel_kwargs'] = {'n_leapfrog_steps': 3, 'step_size': 0.05}
+        monkeypatch.setattr(jump.JumpNFMC, 'fuse_jump_tail', strategy == 'jump_mala_tail')
+        if strategy == 'jump_mala_wide':
+            kw['flow_kwargs'] = {'conditioner_kwargs': {'n_hidden': 64, 'n_layers': 1}}    # matrix-core flow-MH
+    if strategy.startswith('neutra_hmc'):
+        base, T = 'neutra_hmc', 9
+        kw['inner_kernel_kwargs'] = {'n_leapfrog_steps': 2, 'step_size': 0.02}
+        kw['flow_kwargs'] = {'conditioner_kwargs': {'n_hidden': 64 if strategy.endswith('wide') else 8, 'n_layers': 1}}
+        if not strategy.endswith('wide'):
+            monkeypatch.setenv('NFMC_NEUTRA_VALU', '1')
+    if strategy in ('hmc',):
+        kw['kernel_kwargs'] = {'n_leapfrog_steps': 3, 'step_size': 0.05}
+    if strategy == 'mala_callable':
+        base, target, kw['fuse'] = 'mala', (lambda x: torch.sum(x ** 2, dim=-1)), 'never'
+        kw['event_shape'] = (d,)
+    x0 = torch.randn(n, d, generator=torch.Generator().manual_seed(4)) * 0.7
+
+    def run(pk):
+        torch.manual_seed(2)   # flow weights
+        return sample(target, strategy=base, x0=x0, n_iterations=T, param_kwargs=pk, **kw)
+
+    dense = run({}).samples
+    rows = []
+    orig = DeviceSampleStore.__init__
+
+    def spy(self, *a, **k):
+        orig(self, *a, **k)
+        rows.append(self.rows)
+    monkeypatch.setattr(DeviceSampleStore, '__init__', spy)
+    out = run({'thinning': thinning, 'max_samples': max_samples})
+    want = _reference_window(dense, thinning, max_samples)
+    assert out.samples.shape == want.shape, (out.samples.shape, want.shape)
+    assert torch.equal(out.samples, want)
+    assert out.running_samples.n_samples == want.shape[0] and out.running_samples.seen_samples == dense.shape[0]
+    assert rows and rows[-1] == want.shape[0] and (max_samples is None or rows[-1] <= max_samples)   # bounded slab
+    assert torch.equal(out.running_samples.last_sample.cpu(), dense[-1])
+
+
+def test_async_host_spill_of_the_kept_states(dev):
+    """the kept states go to pinned host memory by an asynchronous copy started at the end of sample()
+    (`spill_to_host=True`); `.samples` waits for it and later reads return the same host tensor (no second copy)."""
+    from nfmc_amd import sample
+    from nfmc_amd.potentials import SumOfSquares
+    d, n, T = 64, 4096, 40
+    x0 = torch.randn(n, d, generator=torch.Generator().manual_seed(4)) * 0.7
+    a = sample(SumOfSquares((d,)), strategy='mala', x0=x0, n_iterations=T, show_progress=False, seed=3)
+    b = sample(SumOfSquares((d,)), strategy='mala', x0=x0, n_iterations=T, show_progress=False, seed=3,
+               param_kwargs={'spill_to_host': True, 'thinning': 2})
+    hb = b.samples
+    assert hb.is_pinned() and not hb.is_cuda and hb.shape == (T // 2, n, d)
+    assert torch.equal(hb, a.samples[::2])
+    assert b.samples is hb                                     # cached: one device-to-host copy per store
+    assert torch.equal(b.samples_device.cpu(), hb)

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(handle, name), f'{name} declared in include/nfmc_hip.h but not exported'
     assert declared == {s[0] for s in hip.SYMBOLS}, 'hip.SYMBOLS and the header disagree'
     lim = hip.limits()
-    assert lim.abi_version == 1 and lim.max_d_sampler >= 256 and lim.max_steps_per_call == hip.MAX_STEPS_PER_CALL
+    assert lim.abi_version == 2 and lim.max_d_sampler >= 256 and lim.max_steps_per_call == hip.MAX_STEPS_PER_CALL
     assert hip.lib().nfmc_error_string(-5).decode().startswith('statistics scratch')
     assert hip.lib().nfmc_stats_scratch_bytes(64) > 0 and hip.lib().nfmc_stats_scratch_bytes(5000) == 0
     assert hip.lib().nfmc_realnvp_padded_hidden(5) == 8 and hip.lib().nfmc_realnvp_padded_hidden(100) == 128
@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_sizes_match_the_header():
     """Compile a tiny C program against include/nfmc_hip.h and compare sizeof() with the ctypes mirrors."""
     from nfmc_amd import hip
-    names = ['NfmcPotential', 'NfmcRng', 'NfmcStats', 'NfmcJumpTail', 'NfmcMalaArgs', 'NfmcHmcArgs', 'NfmcRealNVP', 'NfmcFlowMhArgs',
+    names = ['NfmcPotential', 'NfmcRng', 'NfmcStats', 'NfmcSampleStore', 'NfmcJumpTail', 'NfmcMalaArgs', 'NfmcHmcArgs', 'NfmcRealNVP', 'NfmcFlowMhArgs',
              'NfmcNeutraHmcArgs', 'NfmcSelectArgs', 'NfmcLimits']
     src = '#include <stdio.h>\n#include "nfmc_hip.h"\nint main(){' + ''.join(
         f'printf("%zu\\n", sizeof({n}));' for n in names) + 'return 0;}'
@@ -579,3 +579,51 @@ def test_bench_launcher_starts_one_process_per_gpu():
     # under a launcher that already set WORLD_SIZE (torchrun) the same file is one rank and spawns nothing
     src = open(os.path.join(ROOT, 'bench.py')).read()
     assert "'WORLD_SIZE' not in os.environ and args.gpus > 1" in src
+
+
+def test_device_sample_store_plans_exactly_the_reference_rows():
+    """DeviceSampleStore decides BEFORE every launch which transitions are kept and in which ring row
+    (NfmcSampleStore: stride, countdown, ring_rows, row).  A Python model of the kernels' cursor (csrc/common.hpp
+    StoreCursor) fed those structs must leave exactly the rows the reference's step-by-step MCMCSamples.add keeps
+    (base.py:249-263: every `thinning`-th offered state by global index, the newest `max_samples`), for any launch
+    sizes, early stops, and mixes of kernel launches with host-side dense adds -- in at most max_samples rows."""
+    import random
+    from nfmc_amd.containers import DeviceSampleStore, MCMCSamples
+    rng = random.Random(1)
+    for trial in range(200):
+        thinning = rng.choice([1, 1, 2, 3, 7])
+        max_samples = rng.choice([None, None, 1, 2, 5, 16])
+        total = rng.choice([1, 2, 9, 40, 101])
+        offered = total if rng.random() > 0.3 else rng.randrange(0, total + 1)   # time limit: stop early
+        n, d = 2, 3
+        states = torch.arange(total * n * d, dtype=torch.float32).reshape(total, n, d) + 1
+        st = DeviceSampleStore(n, d, 'cpu', total, thinning, max_samples)
+        assert st.rows <= (max_samples or total) and st.rows <= -(-total // thinning)
+        done = 0
+        while done < offered:
+            k = min(rng.choice([1, 1, 3, 8, 512]), offered - done)
+            if rng.random() < 0.3:
+                st.add_dense(states[done:done + k])
+            else:
+                stride, countdown, ring_rows, row = st.plan(k)   # what a kernel launch of k transitions receives
+                assert 0 <= countdown < stride and 0 <= row < ring_rows
+                for s_ in range(k):                      # StoreCursor::next
+                    if countdown > 0:
+                        countdown -= 1
+                        continue
+                    st.buf[row] = states[done + s_]
+                    row = 0 if row + 1 == ring_rows else row + 1
+                    countdown = stride - 1
+            done += k
+        # the reference, one state at a time
+        idx = [i for i in range(offered) if i % thinning == 0]
+        if max_samples:
+            idx = idx[-max_samples:]
+        want = states[idx] if idx else torch.empty(0, n, d)
+        got = st.ordered()
+        assert got.shape == want.shape and torch.equal(got, want), (trial, thinning, max_samples, total, offered)
+        ms = MCMCSamples((d,), thinning=thinning, max_samples=max_samples)
+        ms.adopt_store(st)
+        assert ms.n_samples == len(idx) and ms.seen_samples == offered
+        if idx:
+            assert torch.equal(ms.as_tensor(), want)

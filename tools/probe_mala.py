@@ -23,7 +23,7 @@ def time_mala(n, d, K, cfg, reps=5, adjust=1, store=False):
     a.step_size, a.adjust = d ** (-1 / 3), adjust
     a.pot = pot.descriptor(dev)
     a.stats = st.struct()
-    a.samples = hip.ptr(samples) if store else None
+    a.samples = hip.dense_store(samples if store else None)
     ts = []
     for r in range(reps + 1):
         a.rng = hip.make_rng(1, 0, r * K)
