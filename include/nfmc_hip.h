@@ -144,6 +144,37 @@ typedef struct {
     int32_t row;        /* ring row of this call's first kept transition: ceil(seen / stride) mod ring_rows */
 } NfmcSampleStore;
 
+/* ---- Warmup tuning on the device.  Replaces `MetropolisSampler.update_kernel` + `DualAveraging.step`
+ * (nfmc/algorithms/sampling/mcmc/base.py:142-161, tuning.py:15-41): after the transitions of a call, the controller
+ *     m_j <- beta var_j + (1 - beta) m_j            var_j = unbiased variance of coordinate j over the call's states
+ *     err = target - accepted / attempted;  S += err;  log h_raw = anchor - S / (sqrt(t) gamma);
+ *     w = t^-kappa;  log h-bar <- w log h_raw + (1 - w) log h-bar;  t += 1;  h = exp(log h-bar)
+ * runs inside the statistics fold of the call (its last workgroup), on state that lives in device memory: the next call
+ * reads its step size and mass diagonal from there, so a warmup is a stream of launches without one host round trip.
+ * One transition per call reproduces the reference update for update; n_steps = K updates once per K transitions with
+ * the statistics pooled over them.  `state` words (fp64): */
+enum {
+    NFMC_TUNE_STEP_SIZE = 0,   /* h: read by the sampler kernel, rewritten by the controller */
+    NFMC_TUNE_LOG_SMOOTH = 1,  /* log h-bar */
+    NFMC_TUNE_ERROR_SUM = 2,   /* S */
+    NFMC_TUNE_ITERATION = 3,   /* t */
+    NFMC_TUNE_ANCHOR = 4,      /* log(10 h0) */
+    NFMC_TUNE_LOG_RAW = 5,     /* log h_raw (output) */
+    NFMC_TUNE_TARGET = 6,      /* target acceptance rate (0.651) */
+    NFMC_TUNE_KAPPA = 7,
+    NFMC_TUNE_GAMMA = 8,
+    NFMC_TUNE_IMD_ADJUSTMENT = 9, /* beta */
+    NFMC_TUNE_TICKET = 10,     /* internal: workgroup counter of the fold (zero between calls) */
+    NFMC_TUNE_WORDS = 12       /* followed by 2 * padded_d + 4 words of column totals: nfmc_tune_state_doubles(d) in all */
+};
+typedef struct {
+    double* state;             /* NULL: no tuning (step_size / inv_mass_diag of the call are used as given) */
+    float* inv_mass_diag;      /* (d,) device, updated in place when tune_inv_mass_diag; must be the call's inv_mass_diag */
+    int32_t tune_step_size;
+    int32_t tune_inv_mass_diag;
+} NfmcTune;
+int64_t nfmc_tune_state_doubles(int32_t d);
+
 /* Optional tail of a sampler call: after the n_steps inner transitions, ONE flow-proposal Metropolis jump
  * (jump.py:205-243: flow.sample, flow.log_prob, 2 target calls, log u < log alpha, masked update) on the
  * same registers, as transition rng.step0 + n_steps.  With a tail, `samples` is offered n_steps + 1 states and the
@@ -180,6 +211,7 @@ typedef struct {
     uint8_t* masks_out;         /* NULL or (n_steps, n) accept masks (tests / split path) */
     float* log_ratio_out;       /* NULL or (n_steps, n) */
     const NfmcJumpTail* jump;   /* NULL or a jump to run after the inner transitions (host pointer) */
+    NfmcTune tune;              /* device-side tuning (warmup); needs stats with defer = 0 and no jump tail */
 } NfmcMalaArgs;
 
 int nfmc_mala_steps_f32(const NfmcMalaArgs* args, nfmc_stream_t stream);
@@ -202,6 +234,7 @@ typedef struct {
     uint8_t* masks_out;
     float* log_ratio_out;
     const NfmcJumpTail* jump;   /* as in NfmcMalaArgs */
+    NfmcTune tune;              /* as in NfmcMalaArgs */
 } NfmcHmcArgs;
 
 int nfmc_hmc_steps_f32(const NfmcHmcArgs* args, nfmc_stream_t stream);

@@ -181,7 +181,10 @@ __global__ void __launch_bounds__(kBlock, NFMC_WPE) mala_kernel(NfmcMalaArgs a, 
     const int g = lane % LPC, cw = lane / LPC;
     const int d = a.d;
     const int64_t n = a.n;
-    const float h = a.step_size;
+    // warmup: the step size lives in device memory, where the controller of the previous call left it (NfmcTune)
+    const double h_dev = a.tune.state ? a.tune.state[NFMC_TUNE_STEP_SIZE] : 0.0;
+    const float h = a.tune.state ? (float)h_dev : a.step_size;
+    if (a.tune.state) sqrt2h = (float)sqrt(2.0 * h_dev);   // math.sqrt(2 * step_size) of the fp64 step, langevin.py:75
     const bool adjust = (a.adjust & 1) != 0, rw = (a.adjust & 2) != 0;
     const float inv4h = rw ? 0.f : 1.f / (4.f * h);
 
@@ -324,7 +327,7 @@ __global__ void __launch_bounds__(kBlock, NFMC_WPE) hmc_kernel(NfmcHmcArgs a, in
     const int g = lane % LPC, cw = lane / LPC;
     const int d = a.d;
     const int64_t n = a.n;
-    const float h = a.step_size, hh = a.step_size / 2;
+    const float h = a.tune.state ? (float)a.tune.state[NFMC_TUNE_STEP_SIZE] : a.step_size, hh = h / 2;
 
     MassCoef<CPL, LPC, FAST> mc;
     mc.init(h, 0.f, a.inv_mass_diag, g, d);

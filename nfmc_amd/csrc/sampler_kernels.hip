@@ -66,6 +66,83 @@ static bool fast_path(const Args* a, const Cfg& c) {
            (!a->samples.base || aligned16(a->samples.base));
 }
 
+// ------------------------------------------------------------------------------------------------
+// Warmup: statistics fold + tuning controller in one launch (NfmcTune).  The column totals of the call's per-workgroup
+// partials are folded into the run's accumulators exactly like stats_finish_kernel<true> does, and also left in the
+// tuning state; the workgroup that finishes last (a ticket counter, release / acquire through device-scope fences)
+// then runs the controller: mass-diagonal update over the coordinates, dual averaging of the step size on thread 0.
+__global__ void __launch_bounds__(kFinishBlock) tune_finish_kernel(double* __restrict__ scratch, int nblocks, int dp, int d,
+                                                                   NfmcStats st, NfmcTune tn, unsigned long long attempted) {
+    __shared__ double part[kFinishSlices][kFinishCols];
+    __shared__ bool last;
+    const int width = 2 * dp + kStatTail;
+    const int col = threadIdx.x % kFinishCols, slice = threadIdx.x / kFinishCols;
+    const int t = blockIdx.x * kFinishCols + col;
+    double* __restrict__ totals = tn.state + NFMC_TUNE_WORDS;
+    double p0 = 0.0;
+    if (t < width)
+        for (int b = slice; b < nblocks; b += kFinishSlices) p0 += take<true>(scratch + (size_t)b * width + t);
+    part[slice][col] = p0;
+    __syncthreads();
+    if (slice == 0 && t < width) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < kFinishSlices; ++k) s += part[k][col];
+        totals[t] = s;
+        if (t < dp) {
+            if (t < d) st.sum_x[t] += s;
+        } else if (t < 2 * dp) {
+            if (t - dp < d) st.sum_x2[t - dp] += s;
+        } else if (t == 2 * dp) {
+            st.counters[NFMC_CNT_ACCEPTED] += (unsigned long long)(s + 0.5);
+            st.counters[NFMC_CNT_ATTEMPTED] += attempted;
+        } else if (t == 2 * dp + 1) {
+            st.counters[NFMC_CNT_NONFINITE] += (unsigned long long)(s + 0.5);
+        }
+    }
+    __threadfence();
+    __syncthreads();
+    unsigned long long* ticket = reinterpret_cast<unsigned long long*>(tn.state + NFMC_TUNE_TICKET);
+    if (threadIdx.x == 0) last = atomicAdd(ticket, 1ull) == (unsigned long long)(gridDim.x - 1);
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    const double n_tot = (double)attempted;
+    if (tn.tune_inv_mass_diag && tn.inv_mass_diag && n_tot > 1.0) {   // mcmc/base.py:146-151
+        const double beta = tn.state[NFMC_TUNE_IMD_ADJUSTMENT];
+        for (int j = threadIdx.x; j < d; j += kFinishBlock) {
+            const double sx = totals[j], sxx = totals[dp + j];
+            const double var = (sxx - sx * sx / n_tot) / (n_tot - 1.0);           // torch.var: unbiased
+            tn.inv_mass_diag[j] = (float)(beta * var + (1.0 - beta) * (double)tn.inv_mass_diag[j]);
+        }
+    }
+    if (threadIdx.x == 0) {
+        if (tn.tune_step_size) {                                                   // mcmc/base.py:153-161, tuning.py:22-38
+            const double acc = totals[2 * dp];
+            const double err = tn.state[NFMC_TUNE_TARGET] - acc / n_tot;
+            const double S = tn.state[NFMC_TUNE_ERROR_SUM] + err;
+            const double it = tn.state[NFMC_TUNE_ITERATION];
+            const double log_raw = tn.state[NFMC_TUNE_ANCHOR] - S / (sqrt(it) * tn.state[NFMC_TUNE_GAMMA]);
+            const double w = pow(it, -tn.state[NFMC_TUNE_KAPPA]);
+            const double log_smooth = w * log_raw + (1.0 - w) * tn.state[NFMC_TUNE_LOG_SMOOTH];
+            tn.state[NFMC_TUNE_ERROR_SUM] = S;
+            tn.state[NFMC_TUNE_LOG_RAW] = log_raw;
+            tn.state[NFMC_TUNE_LOG_SMOOTH] = log_smooth;
+            tn.state[NFMC_TUNE_ITERATION] = it + 1.0;
+            tn.state[NFMC_TUNE_STEP_SIZE] = exp(log_smooth);
+        }
+        *ticket = 0ull;
+    }
+}
+
+template <class Args>
+static int check_tune(const Args& a) {
+    if (!a.tune.state) return NFMC_OK;
+    if (!a.stats.sum_x || a.stats.defer || a.jump) return NFMC_EINVAL;   // the controller rides on the per-call fold
+    if (a.tune.tune_inv_mass_diag && (!a.tune.inv_mass_diag || a.tune.inv_mass_diag != a.inv_mass_diag)) return NFMC_EINVAL;
+    return NFMC_OK;
+}
+
 static JumpDev jump_dev(const NfmcJumpTail* j) {
     JumpDev jd = {};
     if (j) {
@@ -88,6 +165,11 @@ extern "C" int64_t nfmc_stats_scratch_bytes(int32_t d) {
     return stats_scratch_doubles(padded_d(d)) * (int64_t)sizeof(double);
 }
 
+extern "C" int64_t nfmc_tune_state_doubles(int32_t d) {
+    if (d <= 0 || d > 1024) return 0;
+    return NFMC_TUNE_WORDS + 2 * padded_d(d) + kStatTail;
+}
+
 extern "C" int nfmc_mala_steps_f32(const NfmcMalaArgs* args, nfmc_stream_t stream) {
     int rc = check_common(args);
     if (rc) return rc;
@@ -104,6 +186,7 @@ extern "C" int nfmc_mala_steps_f32(const NfmcMalaArgs* args, nfmc_stream_t strea
     if (a.stats.sum_x && a.stats.scratch_bytes < (int64_t)grid * (2 * dp + kStatTail) * (int64_t)sizeof(double))
         return NFMC_ESCRATCH;
     if (check_defer(a.stats, dp, a.d)) return NFMC_EINVAL;
+    if ((rc = check_tune(a))) return rc;
     const float sqrt2h = (float)sqrt(2.0 * (double)a.step_size);  // math.sqrt(2*step_size), langevin.py:75
     const JumpDev jd = jump_dev(a.jump);
     unsigned long long* jc = a.jump ? a.jump->counters : nullptr;
@@ -113,7 +196,11 @@ extern "C" int nfmc_mala_steps_f32(const NfmcMalaArgs* args, nfmc_stream_t strea
                               : launch_mala_j8(a, jd, c, fast, tiles, grid, sqrt2h, st));
     if (rc) return rc;
     NFMC_HIP_CHECK_LAUNCH();
-    if (a.stats.sum_x && !a.stats.defer) {
+    if (a.tune.state) {
+        hipLaunchKernelGGL(tune_finish_kernel, dim3(stats_finish_grid(dp)), dim3(kFinishBlock), 0, st, a.stats.scratch, grid, dp,
+                           a.d, a.stats, a.tune, (unsigned long long)a.n * (unsigned long long)a.n_steps);
+        NFMC_HIP_CHECK_LAUNCH();
+    } else if (a.stats.sum_x && !a.stats.defer) {
         hipLaunchKernelGGL(stats_finish_kernel<true>, dim3(stats_finish_grid(dp)), dim3(kFinishBlock), 0, st, a.stats.scratch,
                            grid, dp, a.d, a.stats, (unsigned long long)a.n * (unsigned long long)a.n_steps, jc,
                            (unsigned long long)a.n);
@@ -139,6 +226,7 @@ extern "C" int nfmc_hmc_steps_f32(const NfmcHmcArgs* args, nfmc_stream_t stream)
     if (a.stats.sum_x && a.stats.scratch_bytes < (int64_t)grid * (2 * dp + kStatTail) * (int64_t)sizeof(double))
         return NFMC_ESCRATCH;
     if (check_defer(a.stats, dp, a.d)) return NFMC_EINVAL;
+    if ((rc = check_tune(a))) return rc;
     const JumpDev jd = jump_dev(a.jump);
     unsigned long long* jc = a.jump ? a.jump->counters : nullptr;
     a.jump = nullptr;
@@ -146,7 +234,11 @@ extern "C" int nfmc_hmc_steps_f32(const NfmcHmcArgs* args, nfmc_stream_t stream)
                   : (jhp == 4 ? launch_hmc_j4(a, jd, c, fast, tiles, grid, st) : launch_hmc_j8(a, jd, c, fast, tiles, grid, st));
     if (rc) return rc;
     NFMC_HIP_CHECK_LAUNCH();
-    if (a.stats.sum_x && !a.stats.defer) {
+    if (a.tune.state) {
+        hipLaunchKernelGGL(tune_finish_kernel, dim3(stats_finish_grid(dp)), dim3(kFinishBlock), 0, st, a.stats.scratch, grid, dp,
+                           a.d, a.stats, a.tune, (unsigned long long)a.n * (unsigned long long)a.n_steps);
+        NFMC_HIP_CHECK_LAUNCH();
+    } else if (a.stats.sum_x && !a.stats.defer) {
         hipLaunchKernelGGL(stats_finish_kernel<true>, dim3(stats_finish_grid(dp)), dim3(kFinishBlock), 0, st, a.stats.scratch,
                            grid, dp, a.d, a.stats, (unsigned long long)a.n * (unsigned long long)a.n_steps, jc,
                            (unsigned long long)a.n);

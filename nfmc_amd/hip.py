@@ -54,18 +54,28 @@ class NfmcJumpTail(C.Structure):
                 ('replay_latent', c_fp), ('replay_uniform', c_fp), ('mask_out', c_fp), ('log_ratio_out', c_fp)]
 
 
+class NfmcTune(C.Structure):
+    _fields_ = [('state', c_fp), ('inv_mass_diag', c_fp), ('tune_step_size', C.c_int32), ('tune_inv_mass_diag', C.c_int32)]
+
+
+TUNE_STEP_SIZE, TUNE_LOG_SMOOTH, TUNE_ERROR_SUM, TUNE_ITERATION, TUNE_ANCHOR, TUNE_LOG_RAW = 0, 1, 2, 3, 4, 5
+TUNE_TARGET, TUNE_KAPPA, TUNE_GAMMA, TUNE_IMD_ADJUSTMENT, TUNE_TICKET, TUNE_WORDS = 6, 7, 8, 9, 10, 12
+
+
 class NfmcMalaArgs(C.Structure):
     _fields_ = [('x', c_fp), ('n', C.c_int64), ('d', C.c_int32), ('n_steps', C.c_int32),
                 ('step_size', C.c_float), ('adjust', C.c_int32), ('inv_mass_diag', c_fp),
                 ('pot', NfmcPotential), ('rng', NfmcRng), ('stats', NfmcStats),
-                ('samples', NfmcSampleStore), ('masks_out', c_fp), ('log_ratio_out', c_fp), ('jump', C.POINTER(NfmcJumpTail))]
+                ('samples', NfmcSampleStore), ('masks_out', c_fp), ('log_ratio_out', c_fp), ('jump', C.POINTER(NfmcJumpTail)),
+                ('tune', NfmcTune)]
 
 
 class NfmcHmcArgs(C.Structure):
     _fields_ = [('x', c_fp), ('n', C.c_int64), ('d', C.c_int32), ('n_steps', C.c_int32),
                 ('step_size', C.c_float), ('n_leapfrog', C.c_int32), ('adjust', C.c_int32), ('reserved', C.c_int32),
                 ('inv_mass_diag', c_fp), ('pot', NfmcPotential), ('rng', NfmcRng), ('stats', NfmcStats),
-                ('samples', NfmcSampleStore), ('masks_out', c_fp), ('log_ratio_out', c_fp), ('jump', C.POINTER(NfmcJumpTail))]
+                ('samples', NfmcSampleStore), ('masks_out', c_fp), ('log_ratio_out', c_fp), ('jump', C.POINTER(NfmcJumpTail)),
+                ('tune', NfmcTune)]
 
 
 class NfmcFlowMhArgs(C.Structure):
@@ -98,6 +108,7 @@ class NfmcLimits(C.Structure):
 # every symbol include/nfmc_hip.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ('nfmc_stats_scratch_bytes', C.c_int64, [C.c_int32]),
+    ('nfmc_tune_state_doubles', C.c_int64, [C.c_int32]),
     ('nfmc_mala_steps_f32', C.c_int, [C.POINTER(NfmcMalaArgs), c_fp]),
     ('nfmc_hmc_steps_f32', C.c_int, [C.POINTER(NfmcHmcArgs), c_fp]),
     ('nfmc_realnvp_padded_hidden', C.c_int32, [C.c_int32]),

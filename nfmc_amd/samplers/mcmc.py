@@ -8,6 +8,7 @@ torch autograd on the GPU, proposal / log-ratio / accept-select / moments from t
 """
 import ctypes as C
 import math
+import os
 import time
 from copy import deepcopy
 from dataclasses import dataclass
@@ -51,6 +52,50 @@ class MetropolisParameters(MCMCParameters):
     tune_step_size: bool = True
     adjustment: bool = True
     imd_adjustment: float = 1e-3
+    # warmup on the device: transitions per controller update.  1 = the reference's schedule (mcmc/base.py:92-96: the
+    # kernel is updated after every transition); K > 1 updates once per K transitions with the acceptance rate and the
+    # per-coordinate variance pooled over them, K transitions per launch
+    tune_every: int = 1
+
+
+class DeviceTuning:
+    """Step size, mass diagonal and dual-averaging state in device memory for the length of a warmup (NfmcTune,
+    include/nfmc_hip.h): the controller (mcmc/base.py:142-161, tuning.py:15-41) runs inside each call's statistics fold
+    and the next call reads what it wrote, so the warmup loop never waits for the GPU."""
+
+    def __init__(self, sampler, run):
+        k, p, da = sampler.kernel, sampler.params, sampler.kernel.da
+        st = torch.zeros(int(hip.lib().nfmc_tune_state_doubles(run.d)), dtype=torch.float64)
+        st[hip.TUNE_STEP_SIZE] = float(k.step_size)
+        st[hip.TUNE_LOG_SMOOTH] = da.log_smooth
+        st[hip.TUNE_ERROR_SUM] = da.error_sum
+        st[hip.TUNE_ITERATION] = da.iteration
+        st[hip.TUNE_ANCHOR] = da.anchor
+        st[hip.TUNE_LOG_RAW] = da.log_raw if math.isfinite(da.log_raw) else 0.0
+        st[hip.TUNE_TARGET] = da.params.target_acceptance_rate
+        st[hip.TUNE_KAPPA] = da.params.kappa
+        st[hip.TUNE_GAMMA] = da.params.gamma
+        st[hip.TUNE_IMD_ADJUSTMENT] = p.imd_adjustment
+        self.state = st.to(run.dev)
+        self.imd = k.inv_mass_diag.detach().to(run.dev, torch.float32).contiguous().clone()
+        self.tune_step = bool(p.tune_step_size and p.adjustment)            # mcmc/base.py:153
+        self.tune_imd = bool(p.tune_inv_mass_diag and run.n > 1)            # mcmc/base.py:146
+        self.updates = 0
+
+    def struct(self):
+        self.updates += 1
+        return hip.NfmcTune(hip.ptr(self.state, torch.float64), hip.ptr(self.imd), int(self.tune_step), int(self.tune_imd))
+
+    def download(self, kernel):
+        """The tuned kernel back on the host (one copy, at the end of the warmup)."""
+        st = self.state.cpu()
+        if self.tune_imd:
+            kernel.inv_mass_diag = self.imd.cpu().to(kernel.inv_mass_diag.dtype)
+        if self.tune_step and self.updates:
+            da = kernel.da
+            da.log_smooth, da.error_sum = float(st[hip.TUNE_LOG_SMOOTH]), float(st[hip.TUNE_ERROR_SUM])
+            da.iteration, da.log_raw = int(round(float(st[hip.TUNE_ITERATION]))), float(st[hip.TUNE_LOG_RAW])
+            kernel.step_size = float(st[hip.TUNE_STEP_SIZE])
 
 
 @dataclass
@@ -132,7 +177,7 @@ class MCMCSampler(Sampler):
         raise NotImplementedError
 
     # ---- fused launch of k transitions; implemented by Langevin / HMC
-    def _launch(self, run: Run, pot, k, step0, samples, masks_out=None, log_ratio_out=None, jump=None, rng=None):
+    def _launch(self, run: Run, pot, k, step0, samples, masks_out=None, log_ratio_out=None, jump=None, rng=None, tune=None):
         raise NotImplementedError
 
     def _counts(self, n, k):
@@ -174,23 +219,34 @@ class MCMCSampler(Sampler):
         bar = tqdm(total=K, desc=label, disable=not show_progress)
         stepwise = self.params.tuning or pot is None
         limit = 1 if stepwise else (hip.MAX_STEPS_PER_CALL if time_limit_seconds is None and not show_progress else 32)
+        # warmup of a fused sampler on one GPU: kernel state and controller on the device, no host round trip per step
+        # (sharded chains keep the host controller: its statistics are all-reduced over the ranks every step)
+        tune = None
+        if (self.params.tuning and pot is not None and isinstance(self, MetropolisSampler)
+                and (run.shard is None or run.shard.world == 1) and os.environ.get('NFMC_TUNE_DEVICE', '1') != '0'):
+            tune = DeviceTuning(self, run)
+            limit = max(1, min(int(getattr(self.params, 'tune_every', 1)), hip.MAX_STEPS_PER_CALL))
         while done < K:
             if run.time_is_up(t0, time_limit_seconds):
                 break
             k = min(limit, K - done)
-            if pot is not None:
+            if tune is not None:
+                self._launch(run, pot, k, step0 + done, store, tune=tune)
+            elif pot is not None:
                 mask_buf = torch.empty(k, n, dtype=torch.uint8, device=run.dev) if self.params.tuning else None
                 self._launch(run, pot, k, step0 + done, store, masks_out=mask_buf)
                 mask = mask_buf[-1].bool() if mask_buf is not None else None
             else:
                 mask = self._split_step(run, step0 + done, store)
-            if self.params.tuning:
+            if self.params.tuning and tune is None:
                 with torch.no_grad():
                     self.update_kernel({'x': run.x.reshape(n, *event_shape), 'mask': mask})
             done += k
             bar.update(k)
         bar.close()
         run.sync()
+        if tune is not None:
+            tune.download(self.kernel)
         sum_x, sum_x2, cnt, _jc = run.stats.host_totals()
         calls, grads = self._counts(n, done)
         out.statistics.update_counters(n_target_calls=calls, n_target_gradient_calls=grads,
@@ -299,17 +355,21 @@ class Langevin(MetropolisSampler):
         per = 2 * n if self.params.adjustment else n  # langevin.py:116-120
         return per * k, per * k
 
-    def _launch(self, run, pot, k, step0, samples, masks_out=None, log_ratio_out=None, jump=None, rng=None):
+    def _launch(self, run, pot, k, step0, samples, masks_out=None, log_ratio_out=None, jump=None, rng=None, tune=None):
         a = hip.NfmcMalaArgs()
         a.x, a.n, a.d, a.n_steps = hip.ptr(run.x), run.n, run.d, k
         a.step_size = float(self.kernel.step_size)
         a.adjust = (1 if self.params.adjustment else 0) | (2 if getattr(self, 'random_walk', False) else 0)
-        imd = imd_tensor(self.kernel, run.dev)
+        imd = tune.imd if tune is not None else imd_tensor(self.kernel, run.dev)
         a.inv_mass_diag = hip.ptr(imd)
         a.pot = pot.descriptor(run.dev)
         # `rng`: an NfmcRng prepared by the caller (replay bookkeeping of fused jump tails)
         a.rng = rng if rng is not None else run.rng(step0, k, adjusted=self.params.adjustment)
-        a.stats = run.stats.struct(defer=True, attempted=run.n * k, jump_attempted=run.n if jump is not None else 0)
+        if tune is not None:   # the controller rides on the per-call statistics fold
+            a.stats = run.stats.struct()
+            a.tune = tune.struct()
+        else:
+            a.stats = run.stats.struct(defer=True, attempted=run.n * k, jump_attempted=run.n if jump is not None else 0)
         a.samples = hip.store_struct(samples, k + (1 if jump is not None else 0))
         a.masks_out = hip.ptr(masks_out, torch.uint8) if masks_out is not None else None
         a.log_ratio_out = hip.ptr(log_ratio_out) if log_ratio_out is not None else None
@@ -488,18 +548,22 @@ class HMC(MetropolisSampler):
         calls = grads + (2 * n if self.params.adjustment else 0)
         return calls * k, grads * k
 
-    def _launch(self, run, pot, k, step0, samples, masks_out=None, log_ratio_out=None, jump=None, rng=None):
+    def _launch(self, run, pot, k, step0, samples, masks_out=None, log_ratio_out=None, jump=None, rng=None, tune=None):
         a = hip.NfmcHmcArgs()
         a.x, a.n, a.d, a.n_steps = hip.ptr(run.x), run.n, run.d, k
         a.step_size = float(self.kernel.step_size)
         a.n_leapfrog = int(self.kernel.n_leapfrog_steps)
         a.adjust = 1 if self.params.adjustment else 0
-        imd = imd_tensor(self.kernel, run.dev)
+        imd = tune.imd if tune is not None else imd_tensor(self.kernel, run.dev)
         a.inv_mass_diag = hip.ptr(imd)
         a.pot = pot.descriptor(run.dev)
         # `rng`: an NfmcRng prepared by the caller (replay bookkeeping of fused jump tails)
         a.rng = rng if rng is not None else run.rng(step0, k, adjusted=self.params.adjustment)
-        a.stats = run.stats.struct(defer=True, attempted=run.n * k, jump_attempted=run.n if jump is not None else 0)
+        if tune is not None:   # the controller rides on the per-call statistics fold
+            a.stats = run.stats.struct()
+            a.tune = tune.struct()
+        else:
+            a.stats = run.stats.struct(defer=True, attempted=run.n * k, jump_attempted=run.n if jump is not None else 0)
         a.samples = hip.store_struct(samples, k + (1 if jump is not None else 0))
         a.masks_out = hip.ptr(masks_out, torch.uint8) if masks_out is not None else None
         a.log_ratio_out = hip.ptr(log_ratio_out) if log_ratio_out is not None else None

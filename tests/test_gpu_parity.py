@@ -724,6 +724,65 @@ def test_mala_warmup_tuning_golden(dev):
     assert s.params.tuning is False and s.params.n_iterations == 6
 
 
+@pytest.mark.parametrize('kind', ['mala', 'hmc', 'mh', 'mala_mass'])
+def test_device_tuning_equals_the_host_controller(dev, kind, monkeypatch):
+    """f1: the warmup controller on the device (NfmcTune: mass-diagonal EMA + dual averaging inside the statistics fold,
+    no host round trip per step) against the host-side `update_kernel` (mcmc/base.py:142-161, tuning.py:15-41) fed the
+    same transitions: tuned step size, mass diagonal, controller state, samples and counters."""
+    from nfmc_amd.samplers import mcmc
+    from nfmc_amd.potentials import DiagonalGaussian
+    d, n, k = 24, 500, 40
+    sig = torch.linspace(0.5, 2.0, d)
+    x0 = torch.randn(n, d, generator=torch.Generator().manual_seed(8)) * sig
+
+    def make():
+        pot = DiagonalGaussian((d,), 0.0, sig)
+        if kind.startswith('mala'):
+            kern = mcmc.LangevinKernel(event_size=d, inv_mass_diag=torch.linspace(0.8, 1.2, d) if kind == 'mala_mass' else None)
+            s = mcmc.MALA((d,), pot, kern, mcmc.LangevinParameters(n_iterations=5, n_warmup_iterations=k))
+        elif kind == 'hmc':
+            s = mcmc.HMC((d,), pot, mcmc.HMCKernel(event_size=d, n_leapfrog_steps=4, step_size=0.05),
+                         mcmc.HMCParameters(n_iterations=5, n_warmup_iterations=k))
+        else:
+            s = mcmc.MH((d,), pot, mcmc.MHKernel(event_size=d, inv_mass_diag=torch.full((d,), 0.3)),
+                        mcmc.MHParameters(n_iterations=5, n_warmup_iterations=k))
+        s.seed = 77
+        return s
+
+    a = make()
+    out_a = a.warmup(x0, show_progress=False)
+    monkeypatch.setenv('NFMC_TUNE_DEVICE', '0')
+    b = make()
+    out_b = b.warmup(x0, show_progress=False)
+    np.testing.assert_allclose(a.kernel.step_size, b.kernel.step_size, rtol=2e-5)
+    np.testing.assert_allclose(a.kernel.inv_mass_diag.numpy(), b.kernel.inv_mass_diag.numpy(), rtol=1e-5, atol=1e-7)
+    if kind != 'mh':
+        assert a.kernel.step_size != make().kernel.step_size            # the controller did move it
+        assert a.kernel.da.iteration == b.kernel.da.iteration == 10 + k
+        np.testing.assert_allclose(a.kernel.da.error_sum, b.kernel.da.error_sum, atol=1e-4)
+    same = ((out_a.samples - out_b.samples).abs().amax(dim=(0, 2)) < 1e-3).float().mean()
+    assert same > 0.95      # identical streams; a chain parts only through an accept test within rounding of a tie
+    assert abs(out_a.statistics.n_accepted_trajectories - out_b.statistics.n_accepted_trajectories) <= 0.01 * n * k
+
+
+def test_device_tuning_batched_controller(dev):
+    """`tune_every = K`: one controller update per K transitions (K transitions per launch), statistics pooled over
+    them; the tuned step size still lands where the per-transition schedule puts it for a well-conditioned target."""
+    from nfmc_amd.samplers import mcmc
+    from nfmc_amd.potentials import SumOfSquares
+    d, n = 64, 4096
+    x0 = torch.randn(n, d, generator=torch.Generator().manual_seed(9)) * 0.7071
+    tuned = {}
+    for every in (1, 10):
+        s = mcmc.MALA((d,), SumOfSquares((d,)), None, mcmc.LangevinParameters(n_warmup_iterations=300, tune_every=every))
+        s.seed = 5
+        out = s.warmup(x0, show_progress=False)
+        tuned[every] = s.kernel.step_size
+        assert out.statistics.n_attempted_trajectories == n * 300
+        assert s.kernel.da.iteration == 10 + 300 // every
+    assert 0.6 < tuned[10] / tuned[1] < 1.6, tuned
+
+
 @pytest.mark.parametrize('strategy', ['mala', 'hmc', 'imh', 'neutra_hmc'])
 def test_warmup_api(dev, strategy):
     """test/test_warmup.py: warmup with store_samples=False returns last_sample only."""

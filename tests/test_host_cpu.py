@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_sizes_match_the_header():
     """Compile a tiny C program against include/nfmc_hip.h and compare sizeof() with the ctypes mirrors."""
     from nfmc_amd import hip
-    names = ['NfmcPotential', 'NfmcRng', 'NfmcStats', 'NfmcSampleStore', 'NfmcJumpTail', 'NfmcMalaArgs', 'NfmcHmcArgs', 'NfmcRealNVP', 'NfmcFlowMhArgs',
+    names = ['NfmcPotential', 'NfmcRng', 'NfmcStats', 'NfmcSampleStore', 'NfmcTune', 'NfmcJumpTail', 'NfmcMalaArgs', 'NfmcHmcArgs', 'NfmcRealNVP', 'NfmcFlowMhArgs',
              'NfmcNeutraHmcArgs', 'NfmcSelectArgs', 'NfmcLimits']
     src = '#include <stdio.h>\n#include "nfmc_hip.h"\nint main(){' + ''.join(
         f'printf("%zu\\n", sizeof({n}));' for n in names) + 'return 0;}'
