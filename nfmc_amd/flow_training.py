@@ -122,15 +122,19 @@ def _train_device(flow):
 def _loop(flow, loss_fn, val_fn, n_epochs, lr, early_stopping, early_stopping_threshold, keep_best_weights,
           show_progress, time_limit_seconds, check_for_divergences=True):
     opt = torch.optim.AdamW(flow.parameters(), lr=lr)
-    best_loss, best_state, since_best = math.inf, None, 0
+    # the weights the flow came in with are the fallback "best": a fit whose every epoch is non-finite leaves them as
+    # they were instead of whatever the optimiser last wrote
+    best_loss, best_state, since_best = math.inf, (deepcopy(flow.state_dict()) if keep_best_weights else None), 0
     t0 = time.time()
     for epoch in range(int(n_epochs)):
         if time_limit_seconds is not None and time.time() - t0 >= time_limit_seconds:
             break
         opt.zero_grad()
         loss = loss_fn()
-        if check_for_divergences and not torch.isfinite(loss):
-            raise ValueError('flow training diverged (non-finite loss)')
+        if not torch.isfinite(loss):
+            if check_for_divergences:
+                raise ValueError('flow training diverged (non-finite loss)')
+            continue   # no backward / step on a non-finite loss: it would write NaN into every weight
         loss.backward()
         opt.step()
         with torch.no_grad():

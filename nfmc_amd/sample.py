@@ -4,8 +4,10 @@ plumbing (nfmc/sample.py:20-30, 243-314) for the strategies on this build's path
     mala, ula, hmc, uhmc, mh                              (inner samplers)
     imh / fixed_imh, jump_mala, jump_ula, jump_hmc, jump_uhmc, jump_mh, neutra_hmc, neutra_mh
 
-Other reference strategies (ess, nuts, adaptive_imh, jump_ess, tess, dlmc) are
-outside the path and raise ValueError naming what is supported.
+    adaptive_imh
+
+Other reference strategies (ess, nuts, jump_ess, tess, dlmc) are outside the path and raise
+ValueError naming what is supported.
 """
 from typing import Optional, Tuple, Union
 

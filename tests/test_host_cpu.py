@@ -627,3 +627,26 @@ def test_device_sample_store_plans_exactly_the_reference_rows():
         assert ms.n_samples == len(idx) and ms.seen_samples == offered
         if idx:
             assert torch.equal(ms.as_tensor(), want)
+
+
+def test_flow_fit_survives_non_finite_losses():
+    """variational_fit defaults to check_for_divergences=False: a non-finite loss must not reach backward()/step()
+    (it would poison every weight), and a fit whose every epoch is non-finite leaves the incoming weights in place."""
+    from nfmc_amd import flow_training as ft
+    from nfmc_amd.flows import Flow, RealNVP
+    torch.manual_seed(0)
+    f = Flow(RealNVP((4,)))
+    before = {k: v.clone() for k, v in f.state_dict().items()}
+    ft.variational_fit(f, lambda x: torch.full((x.shape[0],), float('nan')), n_epochs=3, n_samples=16)
+    after = f.state_dict()
+    assert all(torch.equal(before[k], after[k]) for k in before)
+    calls = []
+    def sometimes_nan(x):
+        calls.append(1)
+        lp = -0.5 * (x ** 2).sum(-1)
+        return lp * float('nan') if len(calls) == 2 else lp
+    ft.variational_fit(f, sometimes_nan, n_epochs=5, n_samples=64, lr=0.01)
+    assert all(torch.isfinite(v).all() for v in f.state_dict().values())
+    with pytest.raises(ValueError):
+        ft.variational_fit(f, lambda x: torch.full((x.shape[0],), float('nan')), n_epochs=2, n_samples=8,
+                           check_for_divergences=True)
