@@ -15,12 +15,15 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, 'csrc')
 INCLUDE = os.path.join(ROOT, 'include')
-OBJ = os.path.join(CSRC, 'build')
-LIB = os.path.join(HERE, 'libnfmc_hip.so')
+# NFMC_BUILD_VARIANT=name NFMC_EXTRA_FLAGS="-D..." builds an experimental variant next to the product library
+# (nfmc_amd/libnfmc_hip.<name>.so, objects in csrc/build_<name>/): A/B runs select it with NFMC_LIB
+VARIANT = os.environ.get('NFMC_BUILD_VARIANT', '')
+OBJ = os.path.join(CSRC, 'build' + ('_' + VARIANT if VARIANT else ''))
+LIB = os.path.join(HERE, 'libnfmc_hip%s.so' % ('.' + VARIANT if VARIANT else ''))
 
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-I' + INCLUDE, '-I' + CSRC,
-         '-Wno-unused-result']
+         '-Wno-unused-result'] + os.environ.get('NFMC_EXTRA_FLAGS', '').split()
 
 
 def sources():

@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(kMfmaBlock, 2) flow_mh_mfma_kernel(NfmcFlowMhA
     const bool rev = (f.n_coupling & 1) != 0;
     const int64_t n = a.n;
     const float base_c = -0.5f * (float)d * kLog2Pi;
-    double* red = reinterpret_cast<double*>(lds + 2 * kImgFloats + 2 * kVecFloats);  // [8 waves][2*d + 2]
+    double* red = reinterpret_cast<double*>(lds + kMfmaStatOffset);  // [8 waves][2*d + 2]
     WeightPipe wp{lds, 0};
     uint32_t n_acc = 0, n_bad = 0;
     for (int i = threadIdx.x; i < kMfmaWaves * (2 * d + 2); i += kMfmaBlock) red[i] = 0.0;

@@ -25,9 +25,28 @@ namespace nfmc {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-constexpr int kMfmaBlock = 512;      // 8 waves x 16 chains
-constexpr int kMfmaWaves = kMfmaBlock / 64;
-constexpr int kMfmaChains = 128;     // chains per workgroup
+// Workgroup shape (compile-time knobs, A/B'd on the GPU: tools/ab_c4.sh):
+//   NFMC_MFMA_WAVES   waves per workgroup, 16 chains each (8 -> 128 chains, 4 -> 64 chains)
+//   NFMC_MFMA_IMAGES  LDS weight images per workgroup: 2 = double-buffered pipeline, ONE barrier per GEMM and one
+//                     workgroup per CU; 1 = a single image, two barriers per GEMM, but TWO workgroups fit a CU (2 x ~77 KB
+//                     of LDS): their barriers are independent, so while one stages / waits the other's waves own the
+//                     matrix pipe -- the two waves of a SIMD are no longer in lock-step.
+#ifndef NFMC_MFMA_WAVES
+#define NFMC_MFMA_WAVES 8
+#endif
+#ifndef NFMC_MFMA_IMAGES
+#define NFMC_MFMA_IMAGES 2
+#endif
+#ifndef NFMC_STAGE_BATCH
+#define NFMC_STAGE_BATCH 4
+#endif
+#ifndef NFMC_EPI_VALU
+#define NFMC_EPI_VALU 4
+#endif
+constexpr int kMfmaWaves = NFMC_MFMA_WAVES;
+constexpr int kMfmaImages = NFMC_MFMA_IMAGES;
+constexpr int kMfmaBlock = 64 * kMfmaWaves;
+constexpr int kMfmaChains = 16 * kMfmaWaves;     // chains per workgroup
 
 struct MLayer {
     const float *W1, *W1T, *b1, *Wh, *WhT, *bh, *W3, *W3T, *b3;
@@ -62,30 +81,50 @@ __device__ __forceinline__ MLayer mfma_layer(const float* base, int d, int hp, i
 // inside blocks (a reversed coupling layer sees logical coordinate j at physical position d-1-j).
 // All extents are powers of two known at compile time, so the index arithmetic is shifts and masks (with
 // run-time extents each element cost several integer divisions: as much VALU time as the GEMM it fed).
-template <int K, int RBLK, int CBLK>
-__device__ __forceinline__ void stage_matrix(float* __restrict__ img, const float* __restrict__ W, int rows,
-                                             bool rev_rows, bool rev_cols) {
-    constexpr int ld = K + 4, k4 = K >> 2;
+template <int K, int RBLK, int CBLK, int ROWS>
+__device__ __forceinline__ void stage_matrix(float* __restrict__ img, const float* __restrict__ W, bool rev_rows,
+                                             bool rev_cols) {
+    constexpr int ld = K + 4, k4 = K >> 2, N = ROWS * k4;
     static_assert((K & (K - 1)) == 0 && (RBLK & (RBLK - 1)) == 0 && (CBLK & (CBLK - 1)) == 0, "power-of-two extents");
+    static_assert(N % kMfmaBlock == 0, "whole passes of the workgroup");
+    constexpr int IT = N / kMfmaBlock;            // 128-bit pieces per thread: 8 for a 128 x 128 matrix and 512 threads
+    constexpr int BATCH = IT < NFMC_STAGE_BATCH ? IT : NFMC_STAGE_BATCH;   // loads in flight per thread (4 registers each)
     // The copy addresses depend only on the thread index, so LICM would hoist the address arithmetic of EVERY
     // staging call of the kernel above the tile loop and keep hundreds of VGPRs live through all the GEMMs
     // (measured: ~2 KB of scratch per lane).  An opaque copy of the index pins the arithmetic to the call.
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
-    for (int idx = tid; idx < rows * k4; idx += kMfmaBlock) {
-        const int r = idx / k4, c = (idx % k4) << 2;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(W + (size_t)r * K + c);
-        const int rr = rev_rows ? (r / RBLK) * RBLK + (RBLK - 1 - (r % RBLK)) : r;
-        if (!rev_cols) {
-            *reinterpret_cast<f32x4*>(img + rr * ld + c) = v;
-        } else {
-            const int cc = (c / CBLK) * CBLK + (CBLK - 4 - (c % CBLK));
-            f32x4 w;
-            w[0] = v[3];
-            w[1] = v[2];
-            w[2] = v[1];
-            w[3] = v[0];
-            *reinterpret_cast<f32x4*>(img + rr * ld + cc) = w;
+#ifdef NFMC_X_NO_STAGE
+    if (tid >= 0) return;   // ablation: no global -> LDS copy (barriers stay)
+#endif
+    // The weights sit in L2, so a staging is latency, not bandwidth: as a plain loop every piece was load -> wait ->
+    // store (8 dependent L2 round trips per 128 x 128 operand, ~10k cycles in which both waves of every SIMD sat idle:
+    // the largest single loss of the first version, MFMA pipe busy 59 %).  Loads are issued BATCH at a time before
+    // the first store.
+#pragma unroll
+    for (int b0 = 0; b0 < IT; b0 += BATCH) {
+        f32x4 v[BATCH];
+#pragma unroll
+        for (int b = 0; b < BATCH; ++b) {
+            const int idx = tid + (b0 + b) * kMfmaBlock;
+            v[b] = *reinterpret_cast<const f32x4*>(W + (size_t)(idx / k4) * K + ((idx % k4) << 2));
+        }
+#pragma unroll
+        for (int b = 0; b < BATCH; ++b) {
+            const int idx = tid + (b0 + b) * kMfmaBlock;
+            const int r = idx / k4, c = (idx % k4) << 2;
+            const int rr = rev_rows ? (r / RBLK) * RBLK + (RBLK - 1 - (r % RBLK)) : r;
+            if (!rev_cols) {
+                *reinterpret_cast<f32x4*>(img + rr * ld + c) = v[b];
+            } else {
+                const int cc = (c / CBLK) * CBLK + (CBLK - 4 - (c % CBLK));
+                f32x4 w;
+                w[0] = v[b][3];
+                w[1] = v[b][2];
+                w[2] = v[b][1];
+                w[3] = v[b][0];
+                *reinterpret_cast<f32x4*>(img + rr * ld + cc) = w;
+            }
         }
     }
 }
@@ -120,6 +159,146 @@ __device__ __forceinline__ void gemm_tile(f32x4& acc, const float* __restrict__ 
 #ifdef NFMC_MFMA_FENCE_END
     __builtin_amdgcn_sched_barrier(0);
 #endif
+}
+
+// ---- a GEMM phase = NSTEP steps, each: read this lane's A fragments of one 16-row output block from the LDS image,
+// 4 * TK MFMAs into one accumulator quad, an elementwise epilogue.
+//   row(i)   LDS address of the A fragments of step i (this lane's row / column group)
+//   init(i)  set up the accumulator of step i        acc(i)  the accumulator (f32x4&)
+//   act(i)   the B operand tiles (f32x4[TK])          fin(i)  the elementwise epilogue of step i
+// Four orderings of the same work exist as compile-time variants; measured on one box at the C4 shape (d = 128,
+// H = 128 x 2, 65536 chains, L = 10; tools/ab_c4.sh; all bitwise equal in their results):
+//   default                  reads(i), MFMAs(i), epilogue(i)                                    3.53 ms per trajectory
+//   NFMC_MFMA_EPI            epilogue(i - 1) woven between the MFMAs of step i (sched_group_barrier)           3.54
+//   NFMC_MFMA_PREFETCH       reads(i + 1) issued before MFMAs(i) (two fragment sets, exact lgkmcnt waits)      3.60
+//   NFMC_MFMA_PAIRS          steps in pairs, MFMAs of two accumulators interleaved                             3.66
+// None beats the plain order: the ablations (tools/ab_c4_time.sh: -DNFMC_X_NO_MFMA / NO_LDS / NO_STAGE) show why --
+// without the fragment reads the kernel still takes 3.43 ms, without MFMAs and reads 0.87 ms, and a register-only MFMA
+// loop reaches 153-156 TFLOP/s with one dependent accumulator per wave (tools/ubench_mfma.hip): neither LDS latency
+// nor the accumulation chain is what idles the matrix pipe.  The 0.87 ms of weight staging, elementwise epilogues,
+// barriers and the leapfrog's global round trips (with ~300 scratch reloads per gradient around the GEMMs) run while
+// BOTH waves of every SIMD are outside their GEMMs, because the barriers keep the eight waves in lock-step.
+template <int TK>
+__device__ __forceinline__ void frag_load(f32x4 (&a)[TK], const float* __restrict__ arow) {
+#ifdef NFMC_X_NO_LDS
+#pragma unroll
+    for (int mk = 0; mk < TK; ++mk) asm volatile("" : "=v"(a[mk]));   // ablation: no LDS reads, operands are whatever is there
+    return;
+#endif
+#pragma unroll
+    for (int mk = 0; mk < TK; ++mk) a[mk] = *reinterpret_cast<const f32x4*>(arow + 16 * mk);
+}
+template <int TK, int NSTEP, class Row, class Init, class Acc, class Act, class Fin>
+__device__ __forceinline__ void gemm_phase(Row row, Init init, Acc acc, Act act, Fin fin) {
+    static_assert(NSTEP % 2 == 0, "steps come in pairs");
+#ifdef NFMC_MFMA_EPI
+    // One step at a time; the elementwise epilogue of step i - 1 (tanh, exp, rcp, ... of a finished tile) is woven
+    // between the MFMAs of step i: the accumulation chain of a tile is dependent (a new MFMA every 40 cycles at best,
+    // 8 of them occupying the issue port), so up to ~4 ordinary VALU instructions fit behind every MFMA for free.
+    // In plain order both waves of a SIMD run their epilogues at the same time (the barriers keep them in lock-step)
+    // with the matrix pipe idle: measured, all non-MFMA work of the kernel (0.87 ms of 3.5) was serialised with the MFMAs.
+#pragma unroll
+    for (int i = 0; i < NSTEP; ++i) {
+        f32x4 a[TK];
+        frag_load<TK>(a, row(i));
+        init(i);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mk = 0; mk < TK; ++mk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc(i) = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mk][r], act(i)[mk][r], acc(i), 0, 0, 0);
+        if (i > 0) fin(i - 1);
+#pragma unroll
+        for (int k = 0; k < 4 * TK; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, NFMC_EPI_VALU, 0);   // then a few VALU of the previous epilogue
+        }
+    }
+    fin(NSTEP - 1);
+    return;
+#endif
+#if !defined(NFMC_MFMA_PAIRS) && !defined(NFMC_MFMA_PREFETCH) && !defined(NFMC_MFMA_EPI)
+    // DEFAULT (fastest measured, see the table above)
+#pragma unroll
+    for (int i = 0; i < NSTEP; ++i) {   // one step at a time: reads, then MFMAs, then epilogue
+        f32x4 a[TK];
+        frag_load<TK>(a, row(i));
+        init(i);
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef NFMC_X_NO_MFMA
+#pragma unroll
+        for (int mk = 0; mk < TK; ++mk) asm volatile("" ::"v"(a[mk]));   // ablation: reads kept, no MFMAs
+#else
+#pragma unroll
+        for (int mk = 0; mk < TK; ++mk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc(i) = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mk][r], act(i)[mk][r], acc(i), 0, 0, 0);
+#endif
+        fin(i);
+    }
+    return;
+#endif
+#ifdef NFMC_MFMA_PREFETCH
+    // One step at a time; the NEXT step's LDS reads (A fragments and, in init(), its bias tile) are issued before this
+    // step's MFMAs, so that they travel under them.  init(i + 1) therefore runs before fin(i): callers double-buffer
+    // whatever both touch.  (The reads of a step must all be issued before the next step's, else the in-order LDS
+    // counter makes the MFMAs wait for the newest read: the first attempt read the bias after the prefetch and got
+    // s_waitcnt lgkmcnt(0) in front of every tile.)
+    f32x4 a0[TK], a1[TK];
+    frag_load<TK>(a0, row(0));
+    init(0);
+#pragma unroll
+    for (int i = 0; i < NSTEP; i += 2) {
+        frag_load<TK>(a1, row(i + 1));
+        init(i + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mk = 0; mk < TK; ++mk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc(i) = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[mk][r], act(i)[mk][r], acc(i), 0, 0, 0);
+        fin(i);
+        if (i + 2 < NSTEP) {
+            frag_load<TK>(a0, row(i + 2));
+            init(i + 2);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mk = 0; mk < TK; ++mk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc(i + 1) = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[mk][r], act(i + 1)[mk][r], acc(i + 1), 0, 0, 0);
+        fin(i + 1);
+    }
+    return;
+#endif
+#pragma unroll
+    for (int i = 0; i < NSTEP; i += 2) {
+        f32x4 a0[TK], a1[TK];
+        frag_load<TK>(a0, row(i));
+        frag_load<TK>(a1, row(i + 1));
+        init(i);
+        init(i + 1);
+        __builtin_amdgcn_sched_barrier(0);   // reads of this pair before its MFMAs, nothing of the next pair hoisted
+#ifdef NFMC_MFMA_NO_INTERLEAVE
+#pragma unroll
+        for (int mk = 0; mk < TK; ++mk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc(i) = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[mk][r], act(i)[mk][r], acc(i), 0, 0, 0);
+#pragma unroll
+        for (int mk = 0; mk < TK; ++mk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc(i + 1) = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[mk][r], act(i + 1)[mk][r], acc(i + 1), 0, 0, 0);
+#else
+#pragma unroll
+        for (int mk = 0; mk < TK; ++mk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                acc(i) = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[mk][r], act(i)[mk][r], acc(i), 0, 0, 0);
+                acc(i + 1) = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[mk][r], act(i + 1)[mk][r], acc(i + 1), 0, 0, 0);
+            }
+#endif
+        fin(i);
+        fin(i + 1);
+    }
 }
 
 // tile of a vector in C layout: elements 16*mo + 4*q + (0..3)
@@ -185,7 +364,8 @@ __device__ __forceinline__ f32x4 tanh4(f32x4 v) {
 constexpr int kImgFloats = 128 * 132;
 constexpr int kVecFloats = 256;          // one bias / vector area per image
 constexpr int kMfmaStatDoubles = kMfmaWaves * (2 * 128 + 2);
-constexpr size_t kMfmaLdsBytes = (size_t)(2 * kImgFloats + 2 * kVecFloats) * sizeof(float) + kMfmaStatDoubles * sizeof(double);
+constexpr int kMfmaStatOffset = kMfmaImages * (kImgFloats + kVecFloats);   // floats before the per-wave statistics
+constexpr size_t kMfmaLdsBytes = (size_t)kMfmaStatOffset * sizeof(float) + kMfmaStatDoubles * sizeof(double);
 
 // entry points of neutra_mfma.hip used by the C ABI in neutra_kernels.hip
 int nfmc_mfma_supported(int32_t d, int32_t n_hidden, int32_t n_hidden_layers);
@@ -209,13 +389,14 @@ struct WeightPipe {
     float* lds;
     int buf;
     __device__ __forceinline__ float* img() const { return lds + buf * kImgFloats; }
-    __device__ __forceinline__ float* vec() const { return lds + 2 * kImgFloats + buf * kVecFloats; }
+    __device__ __forceinline__ float* vec() const { return lds + kMfmaImages * kImgFloats + buf * kVecFloats; }
     // stage matrix W (rows x K) and, if given, a vector, into the next image; closes with the barrier
-    template <int K, int RBLK, int CBLK, int VBLK>
-    __device__ __forceinline__ void stage(const float* W, int rows, bool rev_rows, bool rev_cols, const float* v,
-                                          int vlen, bool vrev) {
-        buf ^= 1;
-        stage_matrix<K, RBLK, CBLK>(img(), W, rows, rev_rows, rev_cols);
+    template <int K, int RBLK, int CBLK, int VBLK, int ROWS>
+    __device__ __forceinline__ void stage(const float* W, bool rev_rows, bool rev_cols, const float* v, int vlen,
+                                          bool vrev) {
+        if constexpr (kMfmaImages == 2) buf ^= 1;
+        else __syncthreads();   // single image: every wave must be done reading the previous GEMM's operand
+        stage_matrix<K, RBLK, CBLK, ROWS>(img(), W, rev_rows, rev_cols);
         if (v) stage_vector<VBLK>(vec(), v, vlen, vrev);
         __syncthreads();
     }
@@ -227,27 +408,25 @@ template <int TS, int TH, int NHL>
 __device__ __forceinline__ void hidden_stack(const f32x4 (&src)[TS], f32x4 (&h1)[TH], f32x4 (&h2)[TH], const MLayer& L,
                                              bool rev, WeightPipe& wp, int col, int q) {
     constexpr int hp = 16 * TH, d_a = 16 * TS;
-    wp.template stage<d_a, 1, d_a, 1>(L.W1, hp, false, rev, L.b1, hp, false);
+    wp.template stage<d_a, 1, d_a, 1, hp>(L.W1, false, rev, L.b1, hp, false);
     {
         const float* img = wp.img();
         const float* vec = wp.vec();
-#pragma unroll
-        for (int mo = 0; mo < TH; ++mo) {
-            h1[mo] = vec_tile(vec, mo, q);
-            gemm_tile<TS>(h1[mo], img + (16 * mo + col) * (d_a + 4) + 4 * q, src);
-            h1[mo] = tanh4(h1[mo]);
-        }
+        gemm_phase<TS, TH>([&](int mo) { return img + (16 * mo + col) * (d_a + 4) + 4 * q; },
+                           [&](int mo) { h1[mo] = vec_tile(vec, mo, q); },
+                           [&](int mo) -> f32x4& { return h1[mo]; },
+                           [&](int) -> const f32x4(&)[TS] { return src; },
+                           [&](int mo) { h1[mo] = tanh4(h1[mo]); });
     }
     if constexpr (NHL > 1) {
-        wp.template stage<hp, 1, 1, 1>(L.Wh, hp, false, false, L.bh, hp, false);
+        wp.template stage<hp, 1, 1, 1, hp>(L.Wh, false, false, L.bh, hp, false);
         const float* img = wp.img();
         const float* vec = wp.vec();
-#pragma unroll
-        for (int mo = 0; mo < TH; ++mo) {
-            h2[mo] = vec_tile(vec, mo, q);
-            gemm_tile<TH>(h2[mo], img + (16 * mo + col) * (hp + 4) + 4 * q, h1);
-            h2[mo] = tanh4(h2[mo]);
-        }
+        gemm_phase<TH, TH>([&](int mo) { return img + (16 * mo + col) * (hp + 4) + 4 * q; },
+                           [&](int mo) { h2[mo] = vec_tile(vec, mo, q); },
+                           [&](int mo) -> f32x4& { return h2[mo]; },
+                           [&](int) -> const f32x4(&)[TH] { return h1; },
+                           [&](int mo) { h2[mo] = tanh4(h2[mo]);                            });
     }
 }
 

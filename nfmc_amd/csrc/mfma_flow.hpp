@@ -21,28 +21,34 @@ __device__ __forceinline__ float coupling_c(f32x4 (&x)[TD], const MLayer& L, flo
         if constexpr (NHL > 1) hidden_stack<TS, TH, NHL>(src, h1, hl, L, REV, wp, col, half);
         else hidden_stack<TS, TH, NHL>(src, hl, h1, L, REV, wp, col, half);
     }
-    wp.template stage<hp, D2, 1, D2>(L.W3, 2 * D2, REV, false, L.b3, 2 * D2, REV);
+    wp.template stage<hp, D2, 1, D2, 2 * D2>(L.W3, REV, false, L.b3, 2 * D2, REV);
     const float* img = wp.img();
     const float* vec = wp.vec();
     float ld = 0.f;
+    f32x4 ua2[2], ub2[2];   // per parity of the target tile: the next tile's bias is read while this one is in flight
+    // steps 2 mt / 2 mt + 1: the alpha / beta rows of target tile mt (a pair: separate accumulators, same operand)
+    gemm_phase<TH, 2 * TS>(
+        [&](int i) { return img + (16 * ((i & 1) * TS + (i >> 1)) + col) * (hp + 4) + 4 * half; },
+        [&](int i) { ((i & 1) ? ub2 : ua2)[(i >> 1) & 1] = vec_tile(vec, (i & 1) * TS + (i >> 1), half); },
+        [&](int i) -> f32x4& { return ((i & 1) ? ub2 : ua2)[(i >> 1) & 1]; },
+        [&](int) -> const f32x4(&)[TH] { return hl; },
+        [&](int i) {
+            if ((i & 1) == 0) return;
+            const int mt = i >> 1;
+            const f32x4 ua = ua2[mt & 1], ub = ub2[mt & 1];
 #pragma unroll
-    for (int mt = 0; mt < TS; ++mt) {
-        f32x4 ua = vec_tile(vec, mt, half), ub = vec_tile(vec, TS + mt, half);
-        gemm_tile<TH>(ua, img + (16 * mt + col) * (hp + 4) + 4 * half, hl);
-        gemm_tile<TH>(ub, img + (16 * (TS + mt) + col) * (hp + 4) + 4 * half, hl);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const float alpha = fast_exp(fmaf(0.5f, ua[t], log1m)) + mscale;
-            const float la = fast_ln(alpha);
-            if constexpr (INVERSE) {
-                x[TGT0 + mt][t] = (x[TGT0 + mt][t] - 0.5f * ub[t]) * __builtin_amdgcn_rcpf(alpha);
-                ld -= la;
-            } else {
-                x[TGT0 + mt][t] = fmaf(alpha, x[TGT0 + mt][t], 0.5f * ub[t]);
-                ld += la;
+            for (int t = 0; t < 4; ++t) {
+                const float alpha = fast_exp(fmaf(0.5f, ua[t], log1m)) + mscale;
+                const float la = fast_ln(alpha);
+                if constexpr (INVERSE) {
+                    x[TGT0 + mt][t] = (x[TGT0 + mt][t] - 0.5f * ub[t]) * __builtin_amdgcn_rcpf(alpha);
+                    ld -= la;
+                } else {
+                    x[TGT0 + mt][t] = fmaf(alpha, x[TGT0 + mt][t], 0.5f * ub[t]);
+                    ld += la;
+                }
             }
-        }
-    }
+        });
     return ld;
 }
 

@@ -79,79 +79,97 @@ __device__ __forceinline__ void coupling_inverse_backward_c(f32x4 (&x)[TD], f32x
     // conditioner outputs of every target tile, then the elementwise backward of the affine map
     f32x4 du[TS], dv[TS];
     {
-        wp.template stage<hp, D2, 1, D2>(L.W3, 2 * D2, REV, false, L.b3, 2 * D2, REV);
+        wp.template stage<hp, D2, 1, D2, 2 * D2>(L.W3, REV, false, L.b3, 2 * D2, REV);
         const float* img = wp.img();
         const float* vec = wp.vec();
+        f32x4 ua2[2], ub2[2];   // per parity of the target tile: the next tile's bias is read while this one is in flight
+        gemm_phase<TH, 2 * TS>(
+            [&](int i) { return img + (16 * ((i & 1) * TS + (i >> 1)) + col) * (hp + 4) + 4 * half; },
+            [&](int i) { ((i & 1) ? ub2 : ua2)[(i >> 1) & 1] = vec_tile(vec, (i & 1) * TS + (i >> 1), half); },
+            [&](int i) -> f32x4& { return ((i & 1) ? ub2 : ua2)[(i >> 1) & 1]; },
+            [&](int) -> const f32x4(&)[TH] { return hl; },
+            [&](int i) {
+                if ((i & 1) == 0) return;
+                const int mt = i >> 1;
+                const f32x4 ua = ua2[mt & 1], ub = ub2[mt & 1];
 #pragma unroll
-        for (int mt = 0; mt < TS; ++mt) {
-            f32x4 ua = vec_tile(vec, mt, half), ub = vec_tile(vec, TS + mt, half);
-            gemm_tile<TH>(ua, img + (16 * mt + col) * (hp + 4) + 4 * half, hl);
-            gemm_tile<TH>(ub, img + (16 * (TS + mt) + col) * (hp + 4) + 4 * half, hl);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const float alpha = fast_exp(fmaf(0.5f, ua[t], log1m)) + mscale;
-                const float beta = 0.5f * ub[t];
-                const float ra = __builtin_amdgcn_rcpf(alpha);
-                const float y = x[TGT0 + mt][t];
-                const float gv = g[TGT0 + mt][t] * ra;
-                const float d_alpha = fmaf(-gv, y, ra);
-                du[mt][t] = 0.5f * d_alpha * (alpha - mscale);
-                dv[mt][t] = -0.5f * gv;
-                g[TGT0 + mt][t] = gv;
-                x[TGT0 + mt][t] = fmaf(alpha, y, beta);
-            }
-        }
+                for (int t = 0; t < 4; ++t) {
+                    const float alpha = fast_exp(fmaf(0.5f, ua[t], log1m)) + mscale;
+                    const float beta = 0.5f * ub[t];
+                    const float ra = __builtin_amdgcn_rcpf(alpha);
+                    const float y = x[TGT0 + mt][t];
+                    const float gv = g[TGT0 + mt][t] * ra;
+                    const float d_alpha = fmaf(-gv, y, ra);
+                    du[mt][t] = 0.5f * d_alpha * (alpha - mscale);
+                    dv[mt][t] = -0.5f * gv;
+                    g[TGT0 + mt][t] = gv;
+                    x[TGT0 + mt][t] = fmaf(alpha, y, beta);
+                }
+            });
     }
     // dL/dh_last = W3^T [du; dv], through tanh of the last hidden layer (its activations die here)
     f32x4 dh[TH];
     {
-        wp.template stage<2 * D2, 1, D2, 1>(L.W3T, hp, false, REV, nullptr, 0, false);
+        wp.template stage<2 * D2, 1, D2, 1, hp>(L.W3T, false, REV, nullptr, 0, false);
         const float* img = wp.img();
+        // step i: hidden tile mo = 2 (i / 4) + (i & 1), operand half (i >> 1) & 1 (du, then dv): pairs are the same half of
+        // two DIFFERENT hidden tiles (separate accumulators); the dv half continues the sum the du half began
+        gemm_phase<TS, 2 * TH>(
+            [&](int i) { return img + (16 * (2 * (i >> 2) + (i & 1)) + col) * (2 * D2 + 4) + 4 * half + ((i >> 1) & 1) * D2; },
+            [&](int i) {
+                if (((i >> 1) & 1) == 0) {
 #pragma unroll
-        for (int mo = 0; mo < TH; ++mo) {
+                    for (int t = 0; t < 4; ++t) dh[2 * (i >> 2) + (i & 1)][t] = 0.f;
+                }
+            },
+            [&](int i) -> f32x4& { return dh[2 * (i >> 2) + (i & 1)]; },
+            [&](int i) -> const f32x4(&)[TS] { return ((i >> 1) & 1) ? dv : du; },
+            [&](int i) {
+                if (((i >> 1) & 1) == 0) return;
+                const int mo = 2 * (i >> 2) + (i & 1);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) dh[mo][t] = 0.f;
-            const float* arow = img + (16 * mo + col) * (2 * D2 + 4) + 4 * half;
-            gemm_tile<TS>(dh[mo], arow, du);
-            gemm_tile<TS>(dh[mo], arow + D2, dv);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) dh[mo][t] *= (1.f - hl[mo][t] * hl[mo][t]);
-        }
+                for (int t = 0; t < 4; ++t) dh[mo][t] *= (1.f - hl[mo][t] * hl[mo][t]);
+            });
     }
     if constexpr (NHL > 1) {
         // dL/dh1 = Wh^T dpre2 ...
         {
-            wp.template stage<hp, 1, 1, 1>(L.WhT, hp, false, false, nullptr, 0, false);
+            wp.template stage<hp, 1, 1, 1, hp>(L.WhT, false, false, nullptr, 0, false);
             const float* img = wp.img();
+            gemm_phase<TH, TH>([&](int mo) { return img + (16 * mo + col) * (hp + 4) + 4 * half; },
+                               [&](int mo) {
 #pragma unroll
-            for (int mo = 0; mo < TH; ++mo) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) hl[mo][t] = 0.f;
-                gemm_tile<TH>(hl[mo], img + (16 * mo + col) * (hp + 4) + 4 * half, dh);
-            }
+                                   for (int t = 0; t < 4; ++t) hl[mo][t] = 0.f;
+                               },
+                               [&](int mo) -> f32x4& { return hl[mo]; },
+                               [&](int) -> const f32x4(&)[TH] { return dh; },
+                               [&](int) {});
         }
         // ... times tanh'(pre1), with h1 = tanh(W1 src + b1) rebuilt one tile at a time
         {
-            wp.template stage<D2, 1, D2, 1>(L.W1, hp, false, REV, L.b1, hp, false);
+            wp.template stage<D2, 1, D2, 1, hp>(L.W1, false, REV, L.b1, hp, false);
             const float* img = wp.img();
             const float* vec = wp.vec();
             f32x4 src[TS];
 #pragma unroll
             for (int ms = 0; ms < TS; ++ms) src[ms] = x[SRC0 + ms];
+            f32x4 h1t[2];
+            gemm_phase<TS, TH>([&](int mo) { return img + (16 * mo + col) * (D2 + 4) + 4 * half; },
+                               [&](int mo) { h1t[mo & 1] = vec_tile(vec, mo, half); },
+                               [&](int mo) -> f32x4& { return h1t[mo & 1]; },
+                               [&](int) -> const f32x4(&)[TS] { return src; },
+                               [&](int mo) {
+                                   const f32x4 h = tanh4(h1t[mo & 1]);
 #pragma unroll
-            for (int mo = 0; mo < TH; ++mo) {
-                f32x4 h1t = vec_tile(vec, mo, half);
-                gemm_tile<TS>(h1t, img + (16 * mo + col) * (D2 + 4) + 4 * half, src);
-                h1t = tanh4(h1t);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) dh[mo][t] = hl[mo][t] * (1.f - h1t[t] * h1t[t]);
-            }
+                                   for (int t = 0; t < 4; ++t) dh[mo][t] = hl[mo][t] * (1.f - h[t] * h[t]);
+                               });
         }
     }
-    wp.template stage<hp, D2, 1, 1>(L.W1T, D2, REV, false, nullptr, 0, false);
+    wp.template stage<hp, D2, 1, 1, D2>(L.W1T, REV, false, nullptr, 0, false);
     const float* img = wp.img();
-#pragma unroll
-    for (int ms = 0; ms < TS; ++ms) gemm_tile<TH>(g[SRC0 + ms], img + (16 * ms + col) * (hp + 4) + 4 * half, dh);
+    gemm_phase<TH, TS>([&](int ms) { return img + (16 * ms + col) * (hp + 4) + 4 * half; }, [&](int) {},
+                       [&](int ms) -> f32x4& { return g[SRC0 + ms]; },
+                       [&](int) -> const f32x4(&)[TH] { return dh; }, [&](int) {});
 }
 
 // ---- U~(z), grad U~(z) for the wave's 16 chains.  x: in z (tile positions in latent order), out z again
@@ -251,7 +269,7 @@ __global__ void __launch_bounds__(kMfmaBlock, 2) neutra_leapfrog_mfma_kernel(Lea
     const int s = A.step;
 
     // statistics accumulate in LDS behind the weight images (nothing extra stays live across the GEMMs)
-    double* red = reinterpret_cast<double*>(lds + 2 * kImgFloats + 2 * kVecFloats);  // [8 waves][2*d + 2]
+    double* red = reinterpret_cast<double*>(lds + kMfmaStatOffset);  // [8 waves][2*d + 2]
     WeightPipe wp{lds, 0};
     uint32_t n_acc = 0, n_bad = 0;
     for (int i = threadIdx.x; i < kMfmaWaves * (2 * d + 2); i += kMfmaBlock) red[i] = 0.0;
