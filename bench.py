@@ -385,6 +385,9 @@ def main():
     ap.add_argument('--config', choices=sorted(CONFIGS), default='C3')
     ap.add_argument('--fit-nf', action='store_true', help='jump strategies: refit the flow every outer iteration, so the '
                                                           'all-gather of the refit buffer (C1) is on the measured path')
+    ap.add_argument('--rng-rounds', type=int, choices=[10, 7], default=10,
+                    help='Philox4x32 rounds of the noise stream: 10 = the library default (what `value` is quoted on); 7 = the '
+                         'opt-in stream.  With the default, C3 / C5 also time the 7-round stream and report it as `philox7`')
     ap.add_argument('--backend', choices=['nccl', 'gloo'], default='nccl')
     ap.add_argument('--rehearse', action='store_true', help='launcher / rendezvous / reduction only, no GPU work')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -417,9 +420,10 @@ def main():
     n_total = n_local * world
     x_start = initial_state(cfg, n_total).to(dev)   # resident in HBM before any timed region
 
-    def run(n_steps, x, time_kernels=False):
+    def run(n_steps, x, time_kernels=False, rounds=None):
         s = build_sampler(cfg, n_steps, fit_nf=args.fit_nf)
         s.seed = 0
+        s.rng_rounds = args.rng_rounds if rounds is None else rounds
         s.shard = shard
         s.time_kernels = time_kernels
         if distributed:
@@ -463,6 +467,25 @@ def main():
         dt_max, per_rank = _reduce_times(dt, world, dist, dev)
         ev = [a.elapsed_time(b) for (l, a, b) in (getattr(out, 'kernel_events', None) or []) if l == label]
         reps.append((dt_max, per_rank, out, ev))
+    # the opt-in Philox4x32-7 stream next to the default (three repetitions, same protocol): a reported side figure
+    alt = None
+    if args.rng_rounds == 10 and cfg['strategy'] in ('jump_mala', 'jump_hmc') and not args.fit_nf:
+        alt_reps = []
+        for _ in range(3):
+            dt7, out7 = run(args.steps, x_start, time_kernels=False if args.no_kernel_events else label, rounds=7)
+            dt7_max, _pr = _reduce_times(dt7, world, dist, dev)
+            ev7 = [a.elapsed_time(b) for (l, a, b) in (getattr(out7, 'kernel_events', None) or []) if l == label]
+            alt_reps.append((dt7_max, out7, ev7))
+        alt_reps.sort(key=lambda r_: r_[0])
+        dt7, out7, _e = alt_reps[1]
+        ev_all7 = [ms for r_ in alt_reps for ms in r_[2]]
+        alt = {'rounds': 7, 'value': n_total * cfg['transitions_per_step'] * args.steps / dt7,
+               'ms_per_step': dt7 / args.steps * 1e3, 'rep_ms': [1e3 * r_[0] for r_ in alt_reps],
+               'mean_launch_ms': (sum(ev_all7) / len(ev_all7)) if ev_all7 else None,
+               'variance_rel_err_max': float(((out7.variance - 0.5).abs() / 0.5).max()),
+               'mean_abs_max': float(out7.mean.abs().max()), 'mcmc_acceptance': out7.statistics.acceptance_rate,
+               'note': 'Philox4x32-7 (sample(..., rng_rounds=7)): the fewest rounds Random123 reports as passing BigCrush; '
+                       'opt-in, never what `value` is quoted on'}
     gc.enable()
 
     if rank == 0:
@@ -505,6 +528,9 @@ def main():
             line['parity']['second_moment_rel_err_max'] = float(((out.second_moment - 0.5).abs() / 0.5).max())
         if hasattr(st, 'jump_acceptance_rate'):
             line['parity']['jump_acceptance'] = st.jump_acceptance_rate
+        line['config']['rng'] = 'Philox4x32-%d, chain-id keyed (oracle/philox.py)' % args.rng_rounds
+        if alt is not None:
+            line['philox7'] = alt
         if world == 1 and not args.no_cpu_baseline:
             line['parity']['vs_cpu_oracle_same_seeds'] = parity_vs_oracle(cfg, dev)
             line['cpu_baseline'] = cpu_baseline(cfg)

@@ -61,7 +61,12 @@ typedef struct {
     uint64_t seed;
     uint64_t chain_offset;        /* global id of row 0 (chains sharded over GPUs keep global ids) */
     uint32_t step0;               /* transition index of the first step of this call */
-    uint32_t reserved;
+    uint32_t rounds;              /* 0 or 10: Philox4x32-10 (the library's stream).  7: Philox4x32-7, an opt-in stream with
+                                     30 % fewer generator instructions (the smallest round count Random123 reports as
+                                     passing BigCrush); supported by nfmc_mala_steps_f32 / nfmc_hmc_steps_f32 on their
+                                     exact-fit quadratic kernels (no jump tail), by the register-layout kernels of
+                                     nfmc_flow_mh_steps_f32 without diagnostics, and by nfmc_philox_*; elsewhere
+                                     NFMC_EUNSUPPORTED.  oracle/philox.py carries the same parameter. */
     const float* replay_normals;  /* NULL -> native Philox; else (n_steps, n, d) */
     const float* replay_uniforms; /* NULL -> native Philox; else (n_steps, n)     */
 } NfmcRng;

@@ -459,6 +459,7 @@ class Sampler:
         self.fuse = 'auto'    # 'auto': a plain callable target that potentials.recognize() reproduces as a quadratic
                               # is evaluated in closed form inside the kernels; False / 'never': always call it
         self.seed = None      # native-stream seed; None: drawn from torch's global RNG per sample() call
+        self.rng_rounds = 10  # 10: Philox4x32-10 (the library's stream); 7: the opt-in Philox4x32-7 stream of the exact-fit kernels
         self.shard = None     # dist.Shard when the chains are split over GPUs
         self.replay = None    # (normals, uniforms) to replay instead of the native streams (parity tests)
 

@@ -24,12 +24,14 @@ constexpr int kStatTail = 4;         // per-workgroup scratch tail: accepted, no
 constexpr uint32_t kTagNoise = 0, kTagAccept = 1, kTagLatent = 2, kTagJump = 3;
 
 // ------------------------------------------------------------------------------------------------
-// Philox4x32-10 (Salmon et al. SC'11).  The key schedule is wave-uniform, so the compiler keeps the
-// ten round keys in SGPRs; the 32x32->64 products become v_mad_u64_u32, the two xors of a word one v_bitop3_b32.
-__device__ __forceinline__ uint4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
-                                                uint32_t k1) {
+// Philox4x32-R (Salmon et al. SC'11); R = 10 is the library's stream, R = 7 an opt-in one (NfmcRng.rounds: the
+// smallest round count the Random123 authors report as passing BigCrush, 30 % fewer generator instructions).  The key
+// schedule is wave-uniform, so the compiler keeps the round keys in SGPRs; the 32x32->64 products become
+// v_mad_u64_u32, the two xors of a word one v_bitop3_b32.
+template <int R>
+__device__ __forceinline__ uint4 philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < R; ++r) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
         // gfx950's three-input bit op (truth table 0x96 = a ^ b ^ c): one VOP3 instead of two dependent v_xor --
@@ -45,6 +47,19 @@ __device__ __forceinline__ uint4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_
         k1 += 0xBB67AE85u;
     }
     return make_uint4(c0, c1, c2, c3);
+}
+__device__ __forceinline__ uint4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                                uint32_t k1) {
+    return philox4x32<10>(c0, c1, c2, c3, k0, k1);
+}
+// NfmcRng.rounds: 0 and 10 mean Philox4x32-10; 7 is the opt-in stream; anything else is an argument error
+inline int rng_rounds(const NfmcRng& r) { return r.rounds == 0 ? 10 : (int)r.rounds; }
+inline bool rng_rounds_ok(const NfmcRng& r, bool seven_supported) {
+    return r.rounds == 0 || r.rounds == 10 || (r.rounds == 7 && seven_supported);
+}
+// for entry points that only have the default stream: 0 ok, NFMC_EUNSUPPORTED for the opt-in one, NFMC_EINVAL otherwise
+inline int rng_default_only(const NfmcRng& r) {
+    return (r.rounds == 0 || r.rounds == 10) ? NFMC_OK : (r.rounds == 7 ? NFMC_EUNSUPPORTED : NFMC_EINVAL);
 }
 
 // (0,1) uniform with 23 random bits, exact in fp32: (2 (r >> 9) + 1) 2^-24.
@@ -63,9 +78,10 @@ __device__ __forceinline__ void box_muller(uint32_t ra, uint32_t rb, float& za, 
 }
 
 // Four normals for coordinate block `blk` of (chain, step) on stream `tag`.
+template <int R = 10>
 __device__ __forceinline__ void philox_normal4(uint32_t chain, uint32_t step, uint32_t blk, uint32_t tag, uint32_t k0,
                                                uint32_t k1, float (&z)[4]) {
-    const uint4 r = philox4x32_10(chain, step, blk, tag, k0, k1);
+    const uint4 r = philox4x32<R>(chain, step, blk, tag, k0, k1);
     box_muller(r.x, r.y, z[0], z[1]);
     box_muller(r.z, r.w, z[2], z[3]);
 }

@@ -371,7 +371,7 @@ struct FlowB {
 // latent z ~ N(0, I) for this lane's positions: position p holds logical latent coordinate (revl ? d-1-p : p).
 // `replay`: NULL -> native stream 2, else the (n, d) latents of this transition.
 // ALIGNED4: d % 4 == 0 is known at compile time (exact-fit layouts), so the per-coordinate branch is not emitted.
-template <int CPL, int LPC, bool ALIGNED4 = false>
+template <int CPL, int LPC, bool ALIGNED4 = false, int R = 10>
 __device__ __forceinline__ void draw_latent(float (&z)[CPL], const float* __restrict__ replay, uint64_t seed,
                                             uint32_t step, uint32_t gchain, int64_t row, int64_t n, int d, int g,
                                             bool revl) {
@@ -391,7 +391,7 @@ __device__ __forceinline__ void draw_latent(float (&z)[CPL], const float* __rest
         for (int q = 0; q < CPL / 4; ++q) {
             const int b = q * LPC + g;
             float w[4];
-            philox_normal4(gchain, step, (uint32_t)(revl ? (d >> 2) - 1 - b : b), kTagLatent, k0, k1, w);
+            philox_normal4<R>(gchain, step, (uint32_t)(revl ? (d >> 2) - 1 - b : b), kTagLatent, k0, k1, w);
 #pragma unroll
             for (int r = 0; r < 4; ++r) z[4 * q + r] = (4 * b + r < d) ? (revl ? w[3 - r] : w[r]) : 0.f;
         }
@@ -403,7 +403,7 @@ __device__ __forceinline__ void draw_latent(float (&z)[CPL], const float* __rest
             float v = 0.f;
             if (c >= 0) {
                 float w[4];
-                philox_normal4(gchain, step, (uint32_t)(c >> 2), kTagLatent, k0, k1, w);
+                philox_normal4<R>(gchain, step, (uint32_t)(c >> 2), kTagLatent, k0, k1, w);
                 const int e = c & 3;
                 v = e == 0 ? w[0] : (e == 1 ? w[1] : (e == 2 ? w[2] : w[3]));
             }

@@ -9,7 +9,7 @@ namespace nfmc {
 // DIAG = false is the production instantiation: no replayed noise, no sample store, no mask / log-ratio outputs --
 // the branches on those pointers (and the scalar registers that carry them through the tile loop: the DIAG kernel
 // spills SGPRs into VGPR lanes there) are compiled out.  The host picks it when all of those arguments are NULL.
-template <int CPL, int LPC, int HP, template <int, int, bool> class Pot, bool FAST, bool DIAG>
+template <int CPL, int LPC, int HP, template <int, int, bool> class Pot, bool FAST, bool DIAG, int RR = 10>
 #ifndef NFMC_FLOWB_WPE
 #define NFMC_FLOWB_WPE 1
 #endif
@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(kBlock, NFMC_FLOWB_WPE) flow_mh_b_kernel(NfmcF
         StoreCursor keep(a.samples);
         for (int s = 0; s < a.n_steps; ++s) {
             float xp[CPL];
-            draw_latent<CPL, LPC, FAST>(xp, (DIAG && a.rng.replay_normals) ? a.rng.replay_normals + (int64_t)s * n * d : nullptr, a.rng.seed,
+            draw_latent<CPL, LPC, FAST, RR>(xp, (DIAG && a.rng.replay_normals) ? a.rng.replay_normals + (int64_t)s * n * d : nullptr, a.rng.seed,
                                   a.rng.step0 + (uint32_t)s, gchain, row, n, d, g, revl);  // flow.sample: jump.py:205 / imh.py:221
             float part = 0.f;
 #pragma unroll
@@ -90,7 +90,7 @@ __global__ void __launch_bounds__(kBlock, NFMC_FLOWB_WPE) flow_mh_b_kernel(NfmcF
                 if (DIAG && a.rng.replay_uniforms) {
                     u = active ? a.rng.replay_uniforms[(int64_t)s * n + row] : 0.5f;
                 } else {
-                    const uint4 r = philox4x32_10(gchain, a.rng.step0 + (uint32_t)s, 0u, kTagJump, (uint32_t)a.rng.seed,
+                    const uint4 r = philox4x32<RR>(gchain, a.rng.step0 + (uint32_t)s, 0u, kTagJump, (uint32_t)a.rng.seed,
                                                   (uint32_t)(a.rng.seed >> 32));
                     u = u32_to_uniform(r.x);
                 }
@@ -139,7 +139,12 @@ static int launch_b(const NfmcFlowMhArgs& a, bool fast, int64_t tiles, int grid,
         if (dry) return 0;                                                                                      \
         const bool diag = !F || a.rng.replay_normals || a.rng.replay_uniforms || a.samples.base || a.masks_out ||    \
                           a.log_ratio_out;                                                                      \
-        auto kern = diag ? flow_mh_b_kernel<CPL, LPC, HP, POT, F, true> : flow_mh_b_kernel<CPL, LPC, HP, POT, F, (F ? false : true)>; \
+        const bool r7 = rng_rounds(a.rng) == 7;   /* opt-in Philox4x32-7 stream: exact-fit kernels only */          \
+        if (r7 && !F) return NFMC_EUNSUPPORTED;                                                                 \
+        auto kern = r7 ? (diag ? flow_mh_b_kernel<CPL, LPC, HP, POT, F, true, (F ? 7 : 10)>                        \
+                               : flow_mh_b_kernel<CPL, LPC, HP, POT, F, (F ? false : true), (F ? 7 : 10)>)         \
+                       : (diag ? flow_mh_b_kernel<CPL, LPC, HP, POT, F, true>                                      \
+                               : flow_mh_b_kernel<CPL, LPC, HP, POT, F, (F ? false : true)>);                      \
         if (lds > 48 * 1024) {                                                                                  \
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,   \
                                                (int)lds);                                                       \

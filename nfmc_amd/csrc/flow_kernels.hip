@@ -340,6 +340,7 @@ extern "C" int nfmc_realnvp_inverse_f32(const NfmcRealNVP* flow, const float* z,
     if (n <= 0 || (!z && !rng)) return NFMC_EINVAL;
     NfmcRng r = {};
     if (rng) r = *rng;
+    if (int rr = rng_default_only(r)) return rr;
     r.replay_normals = nullptr;  // explicit latents come through `z`
     if (use_mfma_flow(flow) && al16(x) && al16(z)) return nfmc_realnvp_inverse_mfma_f32(flow, z, n, x, logdet, log_q, &r, stream);
     const int64_t tiles = (n + 63) / 64;
@@ -363,7 +364,7 @@ static int check_flow_mh(const NfmcFlowMhArgs& a) {
     if (a.pot.kind != NFMC_POT_QUADRATIC && a.pot.kind != NFMC_POT_FUNNEL) return NFMC_EUNSUPPORTED;
     if (a.stats.sum_x && (!a.stats.sum_x2 || !a.stats.counters || !a.stats.scratch)) return NFMC_EINVAL;
     if (a.adjusted && (a.rng.replay_normals != nullptr) != (a.rng.replay_uniforms != nullptr)) return NFMC_EINVAL;
-    if (!store_ok(a.samples)) return NFMC_EINVAL;
+    if (!store_ok(a.samples) || !rng_rounds_ok(a.rng, true)) return NFMC_EINVAL;
     return NFMC_OK;
 }
 
@@ -377,6 +378,7 @@ extern "C" int nfmc_flow_mh_supported_f32(const NfmcFlowMhArgs* args) {
     int grid = 0, dp = 0;
     rc = (getenv("NFMC_FLOW_TILE_PATH") || a.flow.n_bins != 0) ? NFMC_EUNSUPPORTED : flow_mh_b_launch(a, nullptr, &grid, &dp, true);
     if (rc != NFMC_EUNSUPPORTED) return rc;
+    if (rng_rounds(a.rng) != 10) return NFMC_EUNSUPPORTED;   // the opt-in stream exists in the register kernels only
     if (use_mfma_flow(&a.flow) && al16(a.x) && al16(a.samples.base)) return NFMC_OK;
     return flow_mh_tile_lds(a.flow) <= kMaxLdsBytes ? NFMC_OK : NFMC_EUNSUPPORTED;
 }
@@ -391,6 +393,7 @@ extern "C" int nfmc_flow_mh_steps_f32(const NfmcFlowMhArgs* args, nfmc_stream_t 
     hipStream_t st = (hipStream_t)stream;
     int grid = 0;
     rc = (getenv("NFMC_FLOW_TILE_PATH") || a.flow.n_bins != 0) ? NFMC_EUNSUPPORTED : flow_mh_b_launch(a, st, &grid, &dp, false);
+    if (rc == NFMC_EUNSUPPORTED && rng_rounds(a.rng) != 10) return NFMC_EUNSUPPORTED;
     if (rc == NFMC_EUNSUPPORTED && use_mfma_flow(&a.flow) && al16(a.x) && al16(a.samples.base)) {
         // wide conditioners at d = 64 / 128 (16-byte aligned rows): matrix cores
         rc = nfmc_flow_mh_steps_mfma_f32(a, stream, &grid, &dp);

@@ -329,6 +329,7 @@ static int imh_parallel_run(const NfmcFlowMhArgs* args, void* work, int64_t work
     NfmcFlowMhArgs a = *args;
     const NfmcRealNVP& f = a.flow;
     if (!a.x || !a.logq || a.n <= 0 || a.n_steps <= 0 || !a.adjusted || !store_ok(a.samples)) return NFMC_EINVAL;
+    if (int rr = rng_default_only(a.rng)) return rr;
     if (!f.ea0_log_scale || !f.ea0_shift || !f.ea1_log_scale || !f.ea1_shift || (f.n_coupling > 0 && !f.weights)) return NFMC_EINVAL;
     if (f.d < 2 || f.d > 512 || a.n_steps > NFMC_IMH_PARALLEL_MAX_STEPS) return NFMC_ESHAPE;
     if (f.n_hidden <= 0 || f.n_hidden > 8 || f.n_hidden_layers <= 0 || f.n_bins != 0) return NFMC_EUNSUPPORTED;

@@ -13,8 +13,12 @@ __global__ void __launch_bounds__(kBlock) philox_normals_kernel(NfmcRng rng, uin
         const int64_t row = t / nblk;
         const int blk = (int)(t - row * nblk);
         float z[4];
-        philox_normal4((uint32_t)(rng.chain_offset + (uint64_t)row), rng.step0, (uint32_t)blk, tag, (uint32_t)rng.seed,
-                       (uint32_t)(rng.seed >> 32), z);
+        if (rng.rounds == 7)
+            philox_normal4<7>((uint32_t)(rng.chain_offset + (uint64_t)row), rng.step0, (uint32_t)blk, tag, (uint32_t)rng.seed,
+                              (uint32_t)(rng.seed >> 32), z);
+        else
+            philox_normal4<10>((uint32_t)(rng.chain_offset + (uint64_t)row), rng.step0, (uint32_t)blk, tag, (uint32_t)rng.seed,
+                               (uint32_t)(rng.seed >> 32), z);
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             if (4 * blk + k < d) out[row * d + 4 * blk + k] = z[k];
@@ -24,11 +28,13 @@ __global__ void __launch_bounds__(kBlock) philox_normals_kernel(NfmcRng rng, uin
 __device__ __forceinline__ float stream_uniform(const NfmcRng& rng, uint32_t tag, int64_t row) {
     const uint32_t gchain = (uint32_t)(rng.chain_offset + (uint64_t)row);
     const uint32_t k0 = (uint32_t)rng.seed, k1 = (uint32_t)(rng.seed >> 32);
+    const bool r7 = rng.rounds == 7;
     if (tag == kTagAccept) {
-        const uint4 r = philox4x32_10(gchain, rng.step0 >> 2, 0u, kTagAccept, k0, k1);
+        const uint4 r = r7 ? philox4x32<7>(gchain, rng.step0 >> 2, 0u, kTagAccept, k0, k1)
+                           : philox4x32<10>(gchain, rng.step0 >> 2, 0u, kTagAccept, k0, k1);
         return u32_to_uniform(pick_word(r, rng.step0 & 3u));
     }
-    const uint4 r = philox4x32_10(gchain, rng.step0, 0u, tag, k0, k1);
+    const uint4 r = r7 ? philox4x32<7>(gchain, rng.step0, 0u, tag, k0, k1) : philox4x32<10>(gchain, rng.step0, 0u, tag, k0, k1);
     return u32_to_uniform(r.x);
 }
 
@@ -176,7 +182,7 @@ using namespace nfmc;
 
 extern "C" int nfmc_philox_normals_f32(const NfmcRng* rng, int32_t tag, int64_t n, int32_t d, float* out,
                                        nfmc_stream_t stream) {
-    if (!rng || !out || n <= 0 || d <= 0) return NFMC_EINVAL;
+    if (!rng || !out || n <= 0 || d <= 0 || !rng_rounds_ok(*rng, true)) return NFMC_EINVAL;
     const int nblk = (d + 3) / 4;
     hipLaunchKernelGGL(philox_normals_kernel, dim3(grid_for(n * nblk)), dim3(kBlock), 0, (hipStream_t)stream, *rng,
                        (uint32_t)tag, n, d, nblk, out);
@@ -185,7 +191,7 @@ extern "C" int nfmc_philox_normals_f32(const NfmcRng* rng, int32_t tag, int64_t 
 }
 
 extern "C" int nfmc_philox_uniforms_f32(const NfmcRng* rng, int32_t tag, int64_t n, float* out, nfmc_stream_t stream) {
-    if (!rng || !out || n <= 0) return NFMC_EINVAL;
+    if (!rng || !out || n <= 0 || !rng_rounds_ok(*rng, true)) return NFMC_EINVAL;
     if (tag != (int)kTagAccept && tag != (int)kTagJump) return NFMC_EINVAL;
     hipLaunchKernelGGL(philox_uniforms_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, *rng,
                        (uint32_t)tag, n, out);
@@ -234,6 +240,7 @@ extern "C" int nfmc_mh_accept_select_f32(const NfmcSelectArgs* args, nfmc_stream
     if (!args || !args->x || !args->x_prime) return NFMC_EINVAL;
     NfmcSelectArgs a = *args;
     if (a.n <= 0 || a.d <= 0 || a.n_carry < 0 || a.n_carry > 2) return NFMC_EINVAL;
+    if (int rr = rng_default_only(a.rng)) return rr;
     if (a.d > 1024) return NFMC_ESHAPE;
     for (int k = 0; k < a.n_carry; ++k)
         if (!a.carry[k] || !a.carry_prime[k]) return NFMC_EINVAL;
@@ -277,6 +284,7 @@ extern "C" int nfmc_langevin_propose_f32(const float* x, const float* grad_u, co
                                          float step_size, int64_t n, int32_t d, const NfmcRng* rng, float* x_prime,
                                          nfmc_stream_t stream) {
     if (!x || !grad_u || !rng || !x_prime || n <= 0 || d <= 0 || !(step_size > 0.f)) return NFMC_EINVAL;
+    if (int rr = rng_default_only(*rng)) return rr;
     const float sqrt2h = (float)sqrt(2.0 * (double)step_size);
     hipLaunchKernelGGL(langevin_propose_kernel, dim3(grid_for(n * ((d + 3) / 4))), dim3(kBlock), 0, (hipStream_t)stream,
                        x, grad_u, inv_mass_diag, step_size, sqrt2h, n, (int)d, *rng, x_prime);

@@ -433,6 +433,7 @@ extern "C" int nfmc_neutra_hmc_steps_f32(const NfmcNeutraHmcArgs* args, nfmc_str
     if (!args) return NFMC_EINVAL;
     NfmcNeutraHmcArgs a = *args;
     if (a.stats.sum_x && a.stats.defer) return NFMC_EUNSUPPORTED;   // NeuTra folds its statistics per call
+    if (int rr = rng_default_only(a.rng)) return rr;
     if (a.flow.n_bins != 0) return NFMC_EUNSUPPORTED;
     if (a.flow.n_hidden > 32) {
         if (!a.z || a.n <= 0 || a.n_steps <= 0 || a.n_leapfrog <= 0 || !(a.step_size > 0.f)) return NFMC_EINVAL;

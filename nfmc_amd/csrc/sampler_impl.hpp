@@ -72,7 +72,7 @@ struct MassCoef {
 };
 
 // noise for this lane's CPL coordinates of (chain, step): native Philox or replay from HBM
-template <int CPL, int LPC>
+template <int CPL, int LPC, int R = 10>
 __device__ __forceinline__ void draw_normals(const NfmcRng& rng, uint32_t tag, uint32_t gchain, int64_t row, int64_t n,
                                              int d, int g, int s, float (&e)[CPL]) {
     if (rng.replay_normals) {
@@ -87,7 +87,7 @@ __device__ __forceinline__ void draw_normals(const NfmcRng& rng, uint32_t tag, u
 #pragma unroll
         for (int b = 0; b < CPL / 4; ++b) {
             float z[4];
-            philox_normal4(gchain, rng.step0 + (uint32_t)s, (uint32_t)(b * LPC + g), tag, k0, k1, z);
+            philox_normal4<R>(gchain, rng.step0 + (uint32_t)s, (uint32_t)(b * LPC + g), tag, k0, k1, z);
             e[4 * b] = z[0];
             e[4 * b + 1] = z[1];
             e[4 * b + 2] = z[2];
@@ -96,13 +96,14 @@ __device__ __forceinline__ void draw_normals(const NfmcRng& rng, uint32_t tag, u
     }
 }
 
-struct AcceptUniform {
+template <int R = 10>
+struct AcceptUniformR {
     uint4 r;
     __device__ __forceinline__ float draw(const NfmcRng& rng, uint32_t gchain, int64_t row, int64_t n, int s) {
         if (rng.replay_uniforms) return row < n ? rng.replay_uniforms[(int64_t)s * n + row] : 0.5f;
         const uint32_t step = rng.step0 + (uint32_t)s;
         if (s == 0 || (step & 3u) == 0u)
-            r = philox4x32_10(gchain, step >> 2, 0u, kTagAccept, (uint32_t)rng.seed, (uint32_t)(rng.seed >> 32));
+            r = philox4x32<R>(gchain, step >> 2, 0u, kTagAccept, (uint32_t)rng.seed, (uint32_t)(rng.seed >> 32));
         return u32_to_uniform(pick_word(r, step & 3u));
     }
 };
@@ -173,7 +174,7 @@ __device__ __forceinline__ bool jump_once(float (&x)[CPL], const FlowT& fl, cons
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int CPL, int LPC, template <int, int, bool> class Pot, bool FAST, int JHP>
+template <int CPL, int LPC, template <int, int, bool> class Pot, bool FAST, int JHP, int RR = 10>
 __global__ void __launch_bounds__(kBlock, NFMC_WPE) mala_kernel(NfmcMalaArgs a, float sqrt2h, int64_t tiles, JumpDev jd) {
     extern __shared__ __attribute__((aligned(16))) float flow_lds[];
     constexpr int CPW = kWave / LPC;
@@ -216,7 +217,7 @@ __global__ void __launch_bounds__(kBlock, NFMC_WPE) mala_kernel(NfmcMalaArgs a, 
         const uint32_t gchain = (uint32_t)(a.rng.chain_offset + (uint64_t)row);
         float x[CPL];
         load_row<CPL, LPC, FAST>(a.x, row, d, g, active, x);
-        AcceptUniform au;
+        AcceptUniformR<RR> au;
         StoreCursor keep(a.samples);
         float sq = 0.f, sq_prop = 0.f;   // FAST quadratic: this lane's share of |x|^2 (current state / proposal)
         if constexpr (Pot<CPL, LPC, FAST>::kQuadratic && FAST) {
@@ -226,7 +227,7 @@ __global__ void __launch_bounds__(kBlock, NFMC_WPE) mala_kernel(NfmcMalaArgs a, 
 
         for (int s = 0; s < a.n_steps; ++s) {
             float e[CPL], xp[CPL];
-            draw_normals<CPL, LPC>(a.rng, kTagNoise, gchain, row, n, d, g, s, e);
+            draw_normals<CPL, LPC, RR>(a.rng, kTagNoise, gchain, row, n, d, g, s, e);
             bool accept = true;
             float lr = 0.f;
             if constexpr (Pot<CPL, LPC, FAST>::kQuadratic && FAST) {
@@ -319,7 +320,7 @@ __global__ void __launch_bounds__(kBlock, NFMC_WPE) mala_kernel(NfmcMalaArgs a, 
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int CPL, int LPC, template <int, int, bool> class Pot, bool FAST, int JHP>
+template <int CPL, int LPC, template <int, int, bool> class Pot, bool FAST, int JHP, int RR = 10>
 __global__ void __launch_bounds__(kBlock, NFMC_WPE) hmc_kernel(NfmcHmcArgs a, int64_t tiles, JumpDev jd) {
     extern __shared__ __attribute__((aligned(16))) float flow_lds[];
     constexpr int CPW = kWave / LPC;
@@ -356,12 +357,12 @@ __global__ void __launch_bounds__(kBlock, NFMC_WPE) hmc_kernel(NfmcHmcArgs a, in
         const uint32_t gchain = (uint32_t)(a.rng.chain_offset + (uint64_t)row);
         float x[CPL];
         load_row<CPL, LPC, FAST>(a.x, row, d, g, active, x);
-        AcceptUniform au;
+        AcceptUniformR<RR> au;
         StoreCursor keep(a.samples);
 
         for (int s = 0; s < a.n_steps; ++s) {
             float p[CPL], q[CPL];
-            draw_normals<CPL, LPC>(a.rng, kTagNoise, gchain, row, n, d, g, s, p);
+            draw_normals<CPL, LPC, RR>(a.rng, kTagNoise, gchain, row, n, d, g, s, p);
             float dh = 0.f;  // this lane's share of H0 - H1
             {
                 const auto ctx = pot.prepare(x, g, d);
@@ -470,6 +471,16 @@ int launch_mala_cfg(const NfmcMalaArgs& a, const JumpDev& jd, bool fast, int64_t
         }                                                                                                         \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, st, a, sqrt2h, tiles, jd);                        \
     }
+    if (rng_rounds(a.rng) == 7) {   // opt-in Philox4x32-7 stream: the exact-fit quadratic kernel without a jump tail
+        if constexpr (JHP == 0) {
+            if (fast && a.pot.kind == NFMC_POT_QUADRATIC) {
+                auto kern = mala_kernel<CPL, LPC, QuadraticPot, true, 0, 7>;
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, st, a, sqrt2h, tiles, jd);
+                return NFMC_OK;
+            }
+        }
+        return NFMC_EUNSUPPORTED;
+    }
     if (a.pot.kind == NFMC_POT_FUNNEL) {
         if (fast) NFMC_L(FunnelPot, true) else NFMC_L(FunnelPot, false)
     } else {
@@ -493,6 +504,16 @@ int launch_hmc_cfg(const NfmcHmcArgs& a, const JumpDev& jd, bool fast, int64_t t
             if (e != hipSuccess) return (int)e;                                                                   \
         }                                                                                                         \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, st, a, tiles, jd);                                \
+    }
+    if (rng_rounds(a.rng) == 7) {
+        if constexpr (JHP == 0) {
+            if (fast && a.pot.kind == NFMC_POT_QUADRATIC) {
+                auto kern = hmc_kernel<CPL, LPC, QuadraticPot, true, 0, 7>;
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, st, a, tiles, jd);
+                return NFMC_OK;
+            }
+        }
+        return NFMC_EUNSUPPORTED;
     }
     if (a.pot.kind == NFMC_POT_FUNNEL) {
         if (fast) NFMC_L(FunnelPot, true) else NFMC_L(FunnelPot, false)

@@ -43,6 +43,7 @@ static int check_common(const Args* a) {
     if (a->pot.kind != NFMC_POT_QUADRATIC && a->pot.kind != NFMC_POT_FUNNEL) return NFMC_EUNSUPPORTED;
     if (((uintptr_t)a->x & 3u) != 0) return NFMC_EALIGN;
     if (!store_ok(a->samples)) return NFMC_EINVAL;
+    if (!rng_rounds_ok(a->rng, true)) return NFMC_EINVAL;
     if ((a->rng.replay_normals == nullptr) != (a->rng.replay_uniforms == nullptr) && (a->adjust & 1)) return NFMC_EINVAL;
     if (a->stats.sum_x && (!a->stats.sum_x2 || !a->stats.counters || !a->stats.scratch)) return NFMC_EINVAL;
     if (a->jump) {

@@ -29,7 +29,7 @@ class NfmcPotential(C.Structure):
 
 
 class NfmcRng(C.Structure):
-    _fields_ = [('seed', C.c_uint64), ('chain_offset', C.c_uint64), ('step0', C.c_uint32), ('reserved', C.c_uint32),
+    _fields_ = [('seed', C.c_uint64), ('chain_offset', C.c_uint64), ('step0', C.c_uint32), ('rounds', C.c_uint32),
                 ('replay_normals', c_fp), ('replay_uniforms', c_fp)]
 
 
@@ -333,6 +333,7 @@ def null_stats():
     return NfmcStats(None, None, None, None, 0, 0, 0)
 
 
-def make_rng(seed, chain_offset, step0, replay_normals=None, replay_uniforms=None):
-    return NfmcRng(int(seed) & 0xFFFFFFFFFFFFFFFF, int(chain_offset), int(step0) & 0xFFFFFFFF, 0,
+def make_rng(seed, chain_offset, step0, replay_normals=None, replay_uniforms=None, rounds=0):
+    """rounds: 0 / 10 = Philox4x32-10 (default stream), 7 = the opt-in Philox4x32-7 stream."""
+    return NfmcRng(int(seed) & 0xFFFFFFFFFFFFFFFF, int(chain_offset), int(step0) & 0xFFFFFFFF, int(rounds),
                    ptr(replay_normals), ptr(replay_uniforms))

@@ -88,6 +88,11 @@ class Run:
         else:
             seed = int(sampler.seed)
         self.seed = seed
+        # 10 (default) or 7: the opt-in Philox4x32-7 stream (NfmcRng.rounds).  Kernels without it answer
+        # NFMC_EUNSUPPORTED, which surfaces as a ValueError: no launch silently falls back to the other stream.
+        self.rounds = int(getattr(sampler, 'rng_rounds', 10) or 10)
+        if self.rounds not in (7, 10):
+            raise ValueError('rng_rounds must be 10 (Philox4x32-10) or 7 (Philox4x32-7)')
         self.replay = None
         if sampler.replay is not None:
             normals, uniforms = sampler.replay
@@ -108,8 +113,8 @@ class Run:
         if self.replay is not None:
             nz, un = self.replay.take(k, with_uniforms=adjusted)
             self._keep = (nz, un)
-            return hip.make_rng(self.seed, self.chain_offset, step0, nz, un)
-        return hip.make_rng(self.seed, self.chain_offset, step0)
+            return hip.make_rng(self.seed, self.chain_offset, step0, nz, un, rounds=self.rounds)
+        return hip.make_rng(self.seed, self.chain_offset, step0, rounds=self.rounds)
 
     def sync(self):
         torch.cuda.synchronize(self.dev)

@@ -127,7 +127,7 @@ def _flow_mh_probe_args(run: Run, flow, pot, logq, adjusted):
     a.adjusted = 1 if adjusted else 0
     a.flow = st
     a.pot = pot.descriptor(run.dev)
-    a.rng = hip.make_rng(run.seed, run.chain_offset, 0)
+    a.rng = hip.make_rng(run.seed, run.chain_offset, 0, rounds=run.rounds)
     a.stats = hip.null_stats()
     return a, _keep
 
@@ -184,7 +184,7 @@ def split_flow_mh(run: Run, flow, target, event_shape, step, adjusted, stats_str
     n, d = run.n, run.d
     with torch.no_grad():
         if flow_is_native(flow) or isinstance(flow, Flow):   # this package's flow: the run's own noise streams
-            rng = hip.make_rng(run.seed, run.chain_offset, step)
+            rng = hip.make_rng(run.seed, run.chain_offset, step, rounds=run.rounds)
             if run.replay is not None:
                 nz, _ = run.replay.take(1, with_uniforms=False)
                 x_prime, ld = flow.bijection.inverse(nz[0].reshape(n, *event_shape))
@@ -225,7 +225,7 @@ def split_flow_mh(run: Run, flow, target, event_shape, step, adjusted, stats_str
         st.n_carry = 1
         st.carry[0] = hip.ptr(logq)
         st.carry_prime[0] = hip.ptr(f_xp)
-    st.rng = hip.make_rng(run.seed, run.chain_offset, step)
+    st.rng = hip.make_rng(run.seed, run.chain_offset, step, rounds=run.rounds)
     st.rng_tag = hip.TAG_JUMP
     st.stats = stats_struct
     st.mask_out = None

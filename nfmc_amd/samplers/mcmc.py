@@ -225,6 +225,7 @@ class MCMCSampler(Sampler):
         if (self.params.tuning and pot is not None and isinstance(self, MetropolisSampler)
                 and (run.shard is None or run.shard.world == 1) and os.environ.get('NFMC_TUNE_DEVICE', '1') != '0'):
             tune = DeviceTuning(self, run)
+            run.rounds = 10   # warmup launches run on the general kernels, which carry the default stream only
             limit = max(1, min(int(getattr(self.params, 'tune_every', 1)), hip.MAX_STEPS_PER_CALL))
         while done < K:
             if run.time_is_up(t0, time_limit_seconds):
@@ -290,7 +291,7 @@ class MCMCSampler(Sampler):
         st.log_ratio = hip.ptr(lr) if lr is not None else None
         un = self._last_uniforms
         st.uniforms = hip.ptr(un) if un is not None else None
-        st.rng = hip.make_rng(run.seed, run.chain_offset, step)
+        st.rng = hip.make_rng(run.seed, run.chain_offset, step, rounds=run.rounds)
         st.rng_tag = hip.TAG_ACCEPT
         st.stats = run.stats.struct()
         mask = torch.empty(n, dtype=torch.uint8, device=run.dev)
@@ -401,7 +402,7 @@ class Langevin(MetropolisSampler):
         except TargetFailure:
             return self._rejected_step(xf, per, per)
         x_prime = torch.empty_like(xf)
-        rng = hip.make_rng(seed, off, step, nz, None)
+        rng = hip.make_rng(seed, off, step, nz, None, rounds=run.rounds if run is not None else 0)
         hip.check(lib.nfmc_langevin_propose_f32(hip.ptr(xf), hip.ptr(g), hip.ptr(imd), h, n, d, C.byref(rng),
                                                 hip.ptr(x_prime), hip.stream()), 'nfmc_langevin_propose_f32')
         n_calls = n_grads = n
@@ -496,7 +497,7 @@ class MH(Langevin):
             noise = nz[0]
         else:
             noise = torch.empty(n, d, dtype=torch.float32, device=dev)
-            rng = hip.make_rng(seed, off, step)
+            rng = hip.make_rng(seed, off, step, rounds=run.rounds if run is not None else 0)
             hip.check(hip.lib().nfmc_philox_normals_f32(C.byref(rng), hip.TAG_NOISE, n, d, hip.ptr(noise), hip.stream()),
                       'nfmc_philox_normals_f32')
         x_prime = (xf + noise * self.kernel.inv_mass_diag.to(dev, torch.float32)[None]).contiguous()
@@ -517,7 +518,7 @@ class MH(Langevin):
             n_calls = 2 * n
             if run is None:
                 unif = torch.empty(n, dtype=torch.float32, device=dev)
-                rng = hip.make_rng(seed, off, step)
+                rng = hip.make_rng(seed, off, step, rounds=run.rounds if run is not None else 0)
                 hip.check(hip.lib().nfmc_philox_uniforms_f32(C.byref(rng), hip.TAG_ACCEPT, n, hip.ptr(unif), hip.stream()),
                           'nfmc_philox_uniforms_f32')
                 mask = torch.log(unif) < self._last_log_ratio
@@ -590,7 +591,7 @@ class HMC(MetropolisSampler):
             noise = nz[0]
         else:
             noise = torch.empty(n, d, dtype=torch.float32, device=dev)
-            rng = hip.make_rng(seed, off, step)
+            rng = hip.make_rng(seed, off, step, rounds=run.rounds if run is not None else 0)
             hip.check(lib.nfmc_philox_normals_f32(C.byref(rng), hip.TAG_NOISE, n, d, hip.ptr(noise), hip.stream()),
                       'nfmc_philox_normals_f32')
         p = noise * (1 / m.sqrt())
@@ -623,7 +624,7 @@ class HMC(MetropolisSampler):
             n_calls += 2 * n
             if run is None:
                 unif = torch.empty(n, dtype=torch.float32, device=dev)
-                rng = hip.make_rng(seed, off, step)
+                rng = hip.make_rng(seed, off, step, rounds=run.rounds if run is not None else 0)
                 hip.check(lib.nfmc_philox_uniforms_f32(C.byref(rng), hip.TAG_ACCEPT, n, hip.ptr(unif), hip.stream()),
                           'nfmc_philox_uniforms_f32')
                 mask = torch.log(unif) < self._last_log_ratio

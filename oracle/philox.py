@@ -6,7 +6,8 @@ torch's CPU mt19937 generator (`langevin.py:63,106`, `hmc.py:100,111`, `jump.py:
 defines its own *native* stream and this file is its executable specification:
 
   Philox4x32-10 (Salmon et al., SC'11; constants and known-answer vectors from the
-  Random123 distribution's `kat_vectors`), keyed by the 64-bit seed, with counter
+  Random123 distribution's `kat_vectors`; `rounds=7` gives the opt-in Philox4x32-7 stream of
+  NfmcRng.rounds), keyed by the 64-bit seed, with counter
 
       (c0, c1, c2, c3) = (global chain id, transition index, coordinate block, stream tag)
 
@@ -44,13 +45,14 @@ TAG_JUMP = 3
 _MASK32 = np.uint64(0xFFFFFFFF)
 
 
-def philox4x32_10(c0, c1, c2, c3, k0, k1):
-    """Vectorised Philox4x32-10.  All inputs broadcastable uint32 arrays; returns 4 uint32 arrays."""
+def philox4x32_10(c0, c1, c2, c3, k0, k1, rounds=10):
+    """Vectorised Philox4x32-`rounds` (10: the library's stream; 7: the opt-in stream, NfmcRng.rounds).  All inputs
+    broadcastable uint32 arrays; returns 4 uint32 arrays."""
     c0, c1, c2, c3 = np.broadcast_arrays(*(np.asarray(v, dtype=np.uint32) for v in (c0, c1, c2, c3)))
     k0 = np.uint32(k0)
     k1 = np.uint32(k1)
     with np.errstate(over='ignore'):
-        for rnd in range(10):
+        for rnd in range(rounds):
             p0 = PHILOX_M0 * c0.astype(np.uint64)
             p1 = PHILOX_M1 * c2.astype(np.uint64)
             hi0 = (p0 >> np.uint64(32)).astype(np.uint32)
@@ -58,7 +60,7 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
             hi1 = (p1 >> np.uint64(32)).astype(np.uint32)
             lo1 = (p1 & _MASK32).astype(np.uint32)
             c0, c1, c2, c3 = hi1 ^ c1 ^ k0, lo1, hi0 ^ c3 ^ k1, lo0
-            if rnd != 9:
+            if rnd != rounds - 1:
                 k0 = np.uint32(k0 + PHILOX_W0)
                 k1 = np.uint32(k1 + PHILOX_W1)
     return c0, c1, c2, c3
@@ -86,30 +88,30 @@ def box_muller(ra, rb):
     return (rad * np.cos(ang)).astype(np.float32), (rad * np.sin(ang)).astype(np.float32)
 
 
-def normal_field(seed, chain_ids, step, d, tag):
+def normal_field(seed, chain_ids, step, d, tag, rounds=10):
     """(len(chain_ids), d) fp32 standard normals of one transition for stream `tag`."""
     k0, k1 = _seed_key(seed)
     chain_ids = np.asarray(chain_ids, dtype=np.uint32)
     nblk = (d + 3) // 4
     blocks = np.arange(nblk, dtype=np.uint32)
-    r0, r1, r2, r3 = philox4x32_10(chain_ids[:, None], np.uint32(step), blocks[None, :], np.uint32(tag), k0, k1)
+    r0, r1, r2, r3 = philox4x32_10(chain_ids[:, None], np.uint32(step), blocks[None, :], np.uint32(tag), k0, k1, rounds)
     z0, z1 = box_muller(r0, r1)
     z2, z3 = box_muller(r2, r3)
     out = np.stack([z0, z1, z2, z3], axis=-1).reshape(len(chain_ids), nblk * 4)
     return np.ascontiguousarray(out[:, :d])
 
 
-def accept_uniform(seed, chain_ids, step):
+def accept_uniform(seed, chain_ids, step, rounds=10):
     """(len(chain_ids),) fp32 uniforms for the Metropolis test of transition `step` (stream 1)."""
     k0, k1 = _seed_key(seed)
     chain_ids = np.asarray(chain_ids, dtype=np.uint32)
-    r = philox4x32_10(chain_ids, np.uint32(step >> 2), np.uint32(0), np.uint32(TAG_ACCEPT), k0, k1)
+    r = philox4x32_10(chain_ids, np.uint32(step >> 2), np.uint32(0), np.uint32(TAG_ACCEPT), k0, k1, rounds)
     return u32_to_uniform(r[step & 3])
 
 
-def jump_uniform(seed, chain_ids, step):
+def jump_uniform(seed, chain_ids, step, rounds=10):
     """(len(chain_ids),) fp32 uniforms for the flow-proposal MH test of transition `step` (stream 3)."""
     k0, k1 = _seed_key(seed)
     chain_ids = np.asarray(chain_ids, dtype=np.uint32)
-    r = philox4x32_10(chain_ids, np.uint32(step), np.uint32(0), np.uint32(TAG_JUMP), k0, k1)
+    r = philox4x32_10(chain_ids, np.uint32(step), np.uint32(0), np.uint32(TAG_JUMP), k0, k1, rounds)
     return u32_to_uniform(r[0])

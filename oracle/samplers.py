@@ -68,21 +68,22 @@ class RecordingNoise:
 
 
 class PhiloxNoise:
-    def __init__(self, seed, chain_offset=0):
+    def __init__(self, seed, chain_offset=0, rounds=10):
         self.seed = seed
         self.chain_offset = chain_offset
+        self.rounds = rounds   # 10: the library's stream; 7: the opt-in Philox4x32-7 stream
 
     def _ids(self, n):
         return np.arange(self.chain_offset, self.chain_offset + n, dtype=np.uint32)
 
     def normal(self, n, shape, step, tag):
         d = int(math.prod(shape))
-        return torch.from_numpy(philox.normal_field(self.seed, self._ids(n), step, d, tag)).reshape(n, *shape)
+        return torch.from_numpy(philox.normal_field(self.seed, self._ids(n), step, d, tag, self.rounds)).reshape(n, *shape)
 
     def uniform(self, n, step, tag):
         if tag == philox.TAG_ACCEPT:
-            return torch.from_numpy(philox.accept_uniform(self.seed, self._ids(n), step))
-        return torch.from_numpy(philox.jump_uniform(self.seed, self._ids(n), step))
+            return torch.from_numpy(philox.accept_uniform(self.seed, self._ids(n), step, self.rounds))
+        return torch.from_numpy(philox.jump_uniform(self.seed, self._ids(n), step, self.rounds))
 
 
 # --------------------------------------------------------------------------- streaming moments

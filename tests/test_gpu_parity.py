@@ -519,6 +519,68 @@ def test_jump_mala_native_stream_matches_oracle(dev):
     assert out.statistics.n_accepted_jumps > 0.1 * n * T   # the scaled flow proposes well: jumps do get accepted
 
 
+def test_philox_7_round_stream(dev):
+    """The opt-in Philox4x32-7 stream (NfmcRng.rounds = 7, `sample(..., rng_rounds=7)`): words and normals equal the
+    oracle's (oracle/philox.py with rounds=7, itself pinned by the Random123 known-answer vectors), MALA and jump_mala
+    runs on it equal the oracle fed the same stream, launches without a 7-round kernel raise ValueError."""
+    from nfmc_amd import hip, sample
+    from nfmc_amd.containers import NFMCKernel
+    from nfmc_amd.flows import Flow, RealNVP
+    from nfmc_amd.potentials import Funnel, SumOfSquares
+    from nfmc_amd.samplers import jump, mcmc
+    from oracle import philox, samplers as osamp, potentials as opot, flow as oflow
+    n, d = 70, 22
+    out = torch.empty(n, d, device=dev)
+    rng = hip.make_rng(0xDEADBEEF12345, 1000, 7, rounds=7)
+    hip.check(hip.lib().nfmc_philox_normals_f32(C.byref(rng), hip.TAG_NOISE, n, d, hip.ptr(out), hip.stream()), 'normals')
+    want = philox.normal_field(0xDEADBEEF12345, np.arange(1000, 1000 + n, dtype=np.uint32), 7, d, philox.TAG_NOISE, rounds=7)
+    np.testing.assert_allclose(out.cpu().numpy(), want, atol=4e-6)
+    un = torch.empty(n, device=dev)
+    hip.check(hip.lib().nfmc_philox_uniforms_f32(C.byref(rng), hip.TAG_ACCEPT, n, hip.ptr(un), hip.stream()), 'uniforms')
+    assert np.array_equal(un.cpu().numpy(), philox.accept_uniform(0xDEADBEEF12345, np.arange(1000, 1000 + n, dtype=np.uint32), 7, rounds=7))
+    # MALA on the exact-fit kernel
+    d, n, k = 64, 300, 12
+    x0 = torch.randn(n, d, generator=torch.Generator().manual_seed(5))
+    s = mcmc.MALA((d,), SumOfSquares((d,)), None, mcmc.LangevinParameters(n_iterations=k))
+    s.seed, s.rng_rounds = 4242, 7
+    o7 = s.sample(x0, show_progress=False)
+    tr = osamp.mcmc_sample(x0, opot.sum_squares, 'langevin', k, d ** (-1 / 3), noise=osamp.PhiloxNoise(4242, rounds=7))
+    got, want = o7.samples.reshape(k, n, d), tr.stacked()
+    same = (got - want).abs().amax(dim=(0, 2)) < 1e-4
+    assert same.float().mean() > 0.98
+    np.testing.assert_allclose(got[:, same].numpy(), want[:, same].numpy(), atol=1e-4, rtol=0)
+    s.rng_rounds = 10
+    o10 = s.sample(x0, show_progress=False)
+    assert not torch.allclose(o10.samples, o7.samples)          # a different stream
+    # HMC and jump_mala (register flow-MH kernel)
+    h = mcmc.HMC((d,), SumOfSquares((d,)), mcmc.HMCKernel(event_size=d, n_leapfrog_steps=4, step_size=0.05), mcmc.HMCParameters(n_iterations=4))
+    h.seed, h.rng_rounds = 9, 7
+    oh = h.sample(x0, show_progress=False)
+    trh = osamp.mcmc_sample(x0, opot.sum_squares, 'hmc', 4, 0.05, n_leapfrog=4, noise=osamp.PhiloxNoise(9, rounds=7))
+    sameh = (oh.samples.reshape(4, n, d) - trh.stacked()).abs().amax(dim=(0, 2)) < 1e-4
+    assert sameh.float().mean() > 0.98
+    torch.manual_seed(8)
+    of = oflow.perturb_(oflow.Flow(oflow.RealNVP((d,))), 5, 0.1, 0.7071)
+    f = Flow(RealNVP((d,)))
+    f.load_state_dict(of.state_dict())
+    T, K = 2, 5
+    j = jump.JumpMALA((d,), SumOfSquares((d,)), NFMCKernel((d,), flow=f), jump.JumpNFMCParameters(n_iterations=T), None,
+                      mcmc.LangevinParameters(n_iterations=K))
+    j.seed, j.rng_rounds = 31337, 7
+    oj = j.sample(x0, show_progress=False)
+    trj = osamp.jump_sample(x0, opot.sum_squares, of, 'langevin', T, K, d ** (-1 / 3), noise=osamp.PhiloxNoise(31337, rounds=7))
+    samej = (oj.samples.reshape(T * (K + 1), n, d) - trj.stacked()).abs().amax(dim=(0, 2)) < 2e-4
+    assert samej.float().mean() > 0.97
+    assert abs(oj.statistics.n_accepted_jumps - trj.n_accepted_jumps) <= max(2, int(0.03 * n * T))
+    # no 7-round kernel: fail loudly, never fall back to the other stream
+    with pytest.raises(ValueError):
+        sample(Funnel((d,), 3.0), strategy='mala', x0=x0, n_iterations=2, show_progress=False, rng_rounds=7)
+    with pytest.raises(ValueError):
+        sample(SumOfSquares((d,)), strategy='neutra_hmc', x0=x0, n_iterations=2, show_progress=False, rng_rounds=7)
+    with pytest.raises(ValueError):
+        sample(SumOfSquares((d,)), strategy='mala', x0=x0, n_iterations=2, show_progress=False, rng_rounds=8)
+
+
 # ------------------------------------------------------------------------------------------ size-independent properties
 def test_moments_of_sum_squares_target_large(dev):
     """U = sum x^2 => N(0, I/2): mean 0, variance 0.5 (README.md:45-46) at n=65536, d=64."""

@@ -205,3 +205,18 @@ def test_rqs_flow_known_answers():
     second = out[2:, -1] - 2 * out[1:-1, -1] + out[:-2, -1]
     assert float(second.abs().max()) > 1e-4
     assert len(f.bijection.layers) == 2 + 2 * 3
+
+
+def test_philox_7_round_stream_known_answers():
+    """The opt-in stream (NfmcRng.rounds = 7): Philox4x32-7 known-answer vectors of the Random123 distribution
+    (kat_vectors: `philox4x32 7 ...`), next to the 10-round ones the default stream is pinned with."""
+    z, f = np.uint32(0), np.uint32(0xffffffff)
+    got = [int(v) for v in philox.philox4x32_10(z, z, z, z, 0, 0, rounds=7)]
+    assert got == [0x5f6fb709, 0x0d893f64, 0x4f121f81, 0x4f730a48]
+    got = [int(v) for v in philox.philox4x32_10(f, f, f, f, 0xffffffff, 0xffffffff, rounds=7)]
+    assert got == [0x5207ddc2, 0x45165e59, 0x4d8ee751, 0x8c52f662]
+    got = [int(v) for v in philox.philox4x32_10(z, z, z, z, 0, 0, rounds=10)]
+    assert got == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    a = philox.normal_field(5, np.arange(4, dtype=np.uint32), 3, 8, 0, rounds=7)
+    b = philox.normal_field(5, np.arange(4, dtype=np.uint32), 3, 8, 0, rounds=10)
+    assert np.isfinite(a).all() and not np.allclose(a, b)
