@@ -147,6 +147,7 @@ class NeuTra(Sampler):
             # NeuTraMH / arbitrary targets / shapes without a fused kernel: the inner sampler's split path on the
             # adjusted target (neutra.py:116-127)
             inner.seed, inner.shard, inner.replay = self.seed, self.shard, self.replay
+            inner.rng_rounds = self.rng_rounds
             out = inner.sample(x0, show_progress=show_progress, time_limit_seconds=time_limit_seconds)
             out.kernel.flow = self.kernel.flow
             return out
@@ -188,7 +189,7 @@ class NeuTra(Sampler):
                 with run.timed('neutra_hmc_steps'):
                     hip.check(hip.lib().nfmc_neutra_hmc_steps_f32(C.byref(a), hip.stream()), 'nfmc_neutra_hmc_steps_f32')
             except hip.NfmcArgumentError as e:
-                if done == 0 and e.no_kernel:   # validation precedes every launch: nothing has run yet
+                if done == 0 and e.no_kernel and run.rounds == 10:   # validation precedes every launch: nothing has run yet
                     bar.close()
                     return split()
                 if store is not None:
