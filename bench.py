@@ -88,6 +88,7 @@ CONFIGS = {
 }
 C4_MACS_PER_GRADIENT = 245760     # per chain: 2 couplings x (forward 3 GEMMs + reverse sweep) at d=128, H=128 x 2
 PARITY_ROWS = 8192
+PMC_STEPS = 3                     # --steps of the PMC passes in tools/profile_bench.sh
 
 
 def build_sampler(cfg, n_steps, fit_nf=False, flow_seed=1):
@@ -134,6 +135,10 @@ def _match_scale_(flow, std=0.7071067811865476):
     import torch
     with torch.no_grad():
         flow.bijection.layers[0].log_scale.add_(-math.log(std))
+        d = int(flow.bijection.layers[0].log_scale.numel())
+        for p in flow.parameters():          # the couplings' output layers: a tenth of their random initial size
+            if p.dim() == 2 and p.shape[0] == 2 * (d - d // 2):
+                p.mul_(0.1)
     return flow
 
 
@@ -182,7 +187,8 @@ def cpu_baseline(cfg):
     calibrated on a short run first; the best one is used and reported as `cores`."""
     import torch
     flow = _oracle_flow(cfg)
-    n = cfg['n_per_gpu'] if cfg['strategy'] != 'neutra_hmc' else 4096
+    n = cfg['n_per_gpu']
+    n_steps = 4 if cfg['strategy'] == 'imh' else 1     # bench steps in the sample: a few seconds of CPU work per config
     x0 = initial_state(cfg, n)
     small = dict(cfg, inner=max(1, cfg['inner'] // 25))
     _oracle_run(small, x0[:1024], flow, 1)   # warm
@@ -197,11 +203,11 @@ def cpu_baseline(cfg):
             best_t, best_dt = nt, dt
     torch.set_num_threads(best_t)
     t0 = time.perf_counter()
-    _tr, transitions = _oracle_run(cfg, x0, flow, 1)
+    _tr, transitions = _oracle_run(cfg, x0, flow, n_steps)
     dt = time.perf_counter() - t0
     torch.set_num_threads(avail)
     return {'value': n * transitions / dt, 'unit': 'chain-steps/s', 'cores': best_t, 'kind': 'port',
-            'sample': f'1 bench step ({transitions} transitions) of {n} chains, d={cfg["d"]}, oracle/samplers.py in '
+            'sample': f'{n_steps} bench step(s) ({transitions} transitions) of {n} chains, d={cfg["d"]}, oracle/samplers.py in '
                       f'{dt:.1f} s on {best_t} threads (best of 8/16/32/64/{avail} on a short calibration run)'}
 
 
@@ -356,6 +362,10 @@ def roofline(cfg_name, cfg, n_local, mean_ms, launches, transitions_per_launch):
     per_launch_transitions = n_local * transitions_per_launch
     alg_bytes = (8 * d + (8 if cfg['strategy'] == 'imh' else 0)) * per_launch_transitions
     insts = pm.get('SQ_INSTS_VALU') if pm else None
+    if insts and cfg['strategy'] == 'imh':
+        # one nfmc_imh_parallel_f32 call covers ALL steps of a run: the PMC passes (tools/profile_bench.sh: --steps 3)
+        # counted 3 * 50 transitions per call, the live call has transitions_per_launch of them
+        insts = insts * transitions_per_launch / (PMC_STEPS * cfg['inner'])
     ach = insts / secs / 1e9 if (insts and secs) else None
     r.update(bound='valu', achieved=ach, peak=VALU_PEAK_GINST, unit='G wave-inst/s',
              frac=(ach / VALU_PEAK_GINST) if ach else None, traffic=traffic,
