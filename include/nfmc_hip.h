@@ -177,6 +177,11 @@ typedef struct {
     float* inv_mass_diag;      /* (d,) device, updated in place when tune_inv_mass_diag; must be the call's inv_mass_diag */
     int32_t tune_step_size;
     int32_t tune_inv_mass_diag;
+    int32_t every;             /* transitions per controller update.  0 or >= n_steps: one update after the call's n_steps
+                                  transitions.  Otherwise the call enqueues ceil(n_steps / every) kernel + controller
+                                  pairs itself (noise, masks and the sample store advance between them), so a whole
+                                  warmup is ONE call: no host work between updates */
+    int32_t reserved;
 } NfmcTune;
 int64_t nfmc_tune_state_doubles(int32_t d);
 

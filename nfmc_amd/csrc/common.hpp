@@ -367,6 +367,18 @@ __device__ __forceinline__ float* store_row_of(const NfmcSampleStore& s, int t, 
     if (!s.base || k < 0 || k % s.stride != 0) return nullptr;
     return s.base + (int64_t)((s.row + k / s.stride) % s.ring_rows) * nd;
 }
+// the store descriptor of the NEXT launch after one that offered k transitions (host side of StoreCursor)
+inline void store_advance(NfmcSampleStore& s, int k) {
+    if (!s.base) return;
+    if (k <= s.countdown) {
+        s.countdown -= k;
+        return;
+    }
+    const int rest = k - s.countdown;                       // from the launch's first kept transition to its end
+    const int kept = (rest + s.stride - 1) / s.stride;
+    s.row = (s.row + kept) % s.ring_rows;
+    s.countdown = s.stride - 1 - (rest - ((kept - 1) * s.stride + 1));
+}
 inline bool store_ok(const NfmcSampleStore& s) {
     return !s.base || (s.stride >= 1 && s.countdown >= 0 && s.countdown < s.stride && s.ring_rows >= 1 && s.row >= 0 &&
                        s.row < s.ring_rows);

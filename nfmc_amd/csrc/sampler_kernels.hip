@@ -68,46 +68,81 @@ static bool fast_path(const Args* a, const Cfg& c) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Warmup: statistics fold + tuning controller in one launch (NfmcTune).  The column totals of the call's per-workgroup
-// partials are folded into the run's accumulators exactly like stats_finish_kernel<true> does, and also left in the
-// tuning state; the workgroup that finishes last (a ticket counter, release / acquire through device-scope fences)
-// then runs the controller: mass-diagonal update over the coordinates, dual averaging of the step size on thread 0.
+// Warmup: statistics fold + tuning controller in one launch of ONE workgroup (NfmcTune).  The column totals of the
+// call's per-workgroup partials are folded into the run's accumulators like stats_finish_kernel<true> does and kept in
+// the tuning state; then the same workgroup runs the controller: mass-diagonal update over the coordinates, dual
+// averaging of the step size on thread 0.  (A first version spread the fold over several workgroups and let the last
+// one to arrive -- ticket counter, device-scope fences -- run the controller: on this multi-XCD part a device-scope
+// release writes back the whole L2 of the XCD, 25-30 us per controller update with the sampler's 32 MB of state dirty
+// in it.  Tuning launches therefore use at most kTuneGrid workgroups, so that one workgroup folds their slabs in a
+// few load round trips.)
+constexpr int kTuneGrid = 256;   // one load round trip of the folding workgroup (two need more than its 128 VGPRs per thread)
+template <int NCHUNK>   // round trips: slabs / 256
 __global__ void __launch_bounds__(kFinishBlock) tune_finish_kernel(double* __restrict__ scratch, int nblocks, int dp, int d,
                                                                    NfmcStats st, NfmcTune tn, unsigned long long attempted) {
     __shared__ double part[kFinishSlices][kFinishCols];
-    __shared__ bool last;
     const int width = 2 * dp + kStatTail;
     const int col = threadIdx.x % kFinishCols, slice = threadIdx.x / kFinishCols;
-    const int t = blockIdx.x * kFinishCols + col;
     double* __restrict__ totals = tn.state + NFMC_TUNE_WORDS;
-    double p0 = 0.0;
-    if (t < width)
-        for (int b = slice; b < nblocks; b += kFinishSlices) p0 += take<true>(scratch + (size_t)b * width + t);
-    part[slice][col] = p0;
-    __syncthreads();
-    if (slice == 0 && t < width) {
-        double s = 0.0;
+    // The slabs were written by workgroups on all eight XCDs, so every dependent load round trip of this workgroup goes
+    // through memory: a thread therefore issues ALL its loads of kGroups column groups -- 8 rows each, what kTuneGrid
+    // workgroups leave per thread -- before it adds anything (5 groups cover d <= 64 in one round trip).
+    constexpr int kGroups = 5, kRows = 8;   // 40 fp64 loads in flight per thread (1024 threads: 128 VGPRs each)
+    for (int t0 = 0; t0 < width; t0 += kGroups * kFinishCols) {
+        double acc[kGroups];
 #pragma unroll
-        for (int k = 0; k < kFinishSlices; ++k) s += part[k][col];
-        totals[t] = s;
-        if (t < dp) {
-            if (t < d) st.sum_x[t] += s;
-        } else if (t < 2 * dp) {
-            if (t - dp < d) st.sum_x2[t - dp] += s;
-        } else if (t == 2 * dp) {
-            st.counters[NFMC_CNT_ACCEPTED] += (unsigned long long)(s + 0.5);
-            st.counters[NFMC_CNT_ATTEMPTED] += attempted;
-        } else if (t == 2 * dp + 1) {
-            st.counters[NFMC_CNT_NONFINITE] += (unsigned long long)(s + 0.5);
+        for (int gi = 0; gi < kGroups; ++gi) acc[gi] = 0.0;
+#pragma unroll
+        for (int r0 = 0; r0 < NCHUNK * kRows * kFinishSlices; r0 += kRows * kFinishSlices) {   // 256 slabs per round trip
+            double v[kGroups][kRows];
+#pragma unroll
+            for (int gi = 0; gi < kGroups; ++gi) {
+                const int t = t0 + gi * kFinishCols + col;
+#pragma unroll
+                for (int u = 0; u < kRows; ++u) {
+                    const int b = r0 + slice + u * kFinishSlices;
+                    v[gi][u] = (t < width && b < nblocks) ? scratch[(size_t)b * width + t] : 0.0;
+                }
+            }
+#pragma unroll
+            for (int gi = 0; gi < kGroups; ++gi) {
+                const int t = t0 + gi * kFinishCols + col;
+#pragma unroll
+                for (int u = 0; u < kRows; ++u) acc[gi] += v[gi][u];   // row order
+#pragma unroll
+                for (int u = 0; u < kRows; ++u) {
+                    const int b = r0 + slice + u * kFinishSlices;
+                    if (t < width && b < nblocks) scratch[(size_t)b * width + t] = 0.0;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);   // one chunk's 40 loads in flight at a time (128 VGPRs per thread)
+        }
+#pragma unroll
+        for (int gi = 0; gi < kGroups; ++gi) {
+            const int t = t0 + gi * kFinishCols + col;
+            const double p0 = acc[gi];
+            __syncthreads();   // part[] of the previous column group has been consumed
+            part[slice][col] = p0;
+            __syncthreads();
+            if (slice == 0 && t < width) {
+                double s = 0.0;
+#pragma unroll
+                for (int k = 0; k < kFinishSlices; ++k) s += part[k][col];
+                totals[t] = s;
+                if (t < dp) {
+                    if (t < d) st.sum_x[t] += s;
+                } else if (t < 2 * dp) {
+                    if (t - dp < d) st.sum_x2[t - dp] += s;
+                } else if (t == 2 * dp) {
+                    st.counters[NFMC_CNT_ACCEPTED] += (unsigned long long)(s + 0.5);
+                    st.counters[NFMC_CNT_ATTEMPTED] += attempted;
+                } else if (t == 2 * dp + 1) {
+                    st.counters[NFMC_CNT_NONFINITE] += (unsigned long long)(s + 0.5);
+                }
+            }
         }
     }
-    __threadfence();
-    __syncthreads();
-    unsigned long long* ticket = reinterpret_cast<unsigned long long*>(tn.state + NFMC_TUNE_TICKET);
-    if (threadIdx.x == 0) last = atomicAdd(ticket, 1ull) == (unsigned long long)(gridDim.x - 1);
-    __syncthreads();
-    if (!last) return;
-    __threadfence();
+    __syncthreads();   // totals[] written by this workgroup's own threads: workgroup scope is enough
     const double n_tot = (double)attempted;
     if (tn.tune_inv_mass_diag && tn.inv_mass_diag && n_tot > 1.0) {   // mcmc/base.py:146-151
         const double beta = tn.state[NFMC_TUNE_IMD_ADJUSTMENT];
@@ -117,22 +152,19 @@ __global__ void __launch_bounds__(kFinishBlock) tune_finish_kernel(double* __res
             tn.inv_mass_diag[j] = (float)(beta * var + (1.0 - beta) * (double)tn.inv_mass_diag[j]);
         }
     }
-    if (threadIdx.x == 0) {
-        if (tn.tune_step_size) {                                                   // mcmc/base.py:153-161, tuning.py:22-38
-            const double acc = totals[2 * dp];
-            const double err = tn.state[NFMC_TUNE_TARGET] - acc / n_tot;
-            const double S = tn.state[NFMC_TUNE_ERROR_SUM] + err;
-            const double it = tn.state[NFMC_TUNE_ITERATION];
-            const double log_raw = tn.state[NFMC_TUNE_ANCHOR] - S / (sqrt(it) * tn.state[NFMC_TUNE_GAMMA]);
-            const double w = pow(it, -tn.state[NFMC_TUNE_KAPPA]);
-            const double log_smooth = w * log_raw + (1.0 - w) * tn.state[NFMC_TUNE_LOG_SMOOTH];
-            tn.state[NFMC_TUNE_ERROR_SUM] = S;
-            tn.state[NFMC_TUNE_LOG_RAW] = log_raw;
-            tn.state[NFMC_TUNE_LOG_SMOOTH] = log_smooth;
-            tn.state[NFMC_TUNE_ITERATION] = it + 1.0;
-            tn.state[NFMC_TUNE_STEP_SIZE] = exp(log_smooth);
-        }
-        *ticket = 0ull;
+    if (threadIdx.x == 0 && tn.tune_step_size) {                                   // mcmc/base.py:153-161, tuning.py:22-38
+        const double acc = totals[2 * dp];
+        const double err = tn.state[NFMC_TUNE_TARGET] - acc / n_tot;
+        const double S = tn.state[NFMC_TUNE_ERROR_SUM] + err;
+        const double it = tn.state[NFMC_TUNE_ITERATION];
+        const double log_raw = tn.state[NFMC_TUNE_ANCHOR] - S / (sqrt(it) * tn.state[NFMC_TUNE_GAMMA]);
+        const double w = pow(it, -tn.state[NFMC_TUNE_KAPPA]);
+        const double log_smooth = w * log_raw + (1.0 - w) * tn.state[NFMC_TUNE_LOG_SMOOTH];
+        tn.state[NFMC_TUNE_ERROR_SUM] = S;
+        tn.state[NFMC_TUNE_LOG_RAW] = log_raw;
+        tn.state[NFMC_TUNE_LOG_SMOOTH] = log_smooth;
+        tn.state[NFMC_TUNE_ITERATION] = it + 1.0;
+        tn.state[NFMC_TUNE_STEP_SIZE] = exp(log_smooth);
     }
 }
 
@@ -183,7 +215,8 @@ extern "C" int nfmc_mala_steps_f32(const NfmcMalaArgs* args, nfmc_stream_t strea
     const int dp = c.cpl * c.lpc;
     const int cpw = kWave / c.lpc;
     const int64_t tiles = (a.n + (int64_t)kWavesPerBlock * cpw - 1) / ((int64_t)kWavesPerBlock * cpw);
-    const int grid = (int)(tiles < kMaxGrid ? tiles : kMaxGrid);
+    const int gmax = a.tune.state ? kTuneGrid : kMaxGrid;   // warmup: few slabs for the one-workgroup fold
+    const int grid = (int)(tiles < gmax ? tiles : gmax);
     if (a.stats.sum_x && a.stats.scratch_bytes < (int64_t)grid * (2 * dp + kStatTail) * (int64_t)sizeof(double))
         return NFMC_ESCRATCH;
     if (check_defer(a.stats, dp, a.d)) return NFMC_EINVAL;
@@ -192,16 +225,34 @@ extern "C" int nfmc_mala_steps_f32(const NfmcMalaArgs* args, nfmc_stream_t strea
     const JumpDev jd = jump_dev(a.jump);
     unsigned long long* jc = a.jump ? a.jump->counters : nullptr;
     a.jump = nullptr;  // host pointer: never dereferenced on the device
+    if (a.tune.state) {
+        // warmup: `every` transitions per controller update, all pairs of the call enqueued here
+        const int every = (a.tune.every > 0 && a.tune.every < a.n_steps) ? a.tune.every : a.n_steps;
+        const int total = a.n_steps;
+        for (int s0 = 0; s0 < total; s0 += every) {
+            const int k = total - s0 < every ? total - s0 : every;
+            NfmcMalaArgs b = a;
+            b.n_steps = k;
+            b.rng.step0 = a.rng.step0 + (uint32_t)s0;
+            if (a.rng.replay_normals) b.rng.replay_normals = a.rng.replay_normals + (int64_t)s0 * a.n * a.d;
+            if (a.rng.replay_uniforms) b.rng.replay_uniforms = a.rng.replay_uniforms + (int64_t)s0 * a.n;
+            if (a.masks_out) b.masks_out = a.masks_out + (int64_t)s0 * a.n;
+            if (a.log_ratio_out) b.log_ratio_out = a.log_ratio_out + (int64_t)s0 * a.n;
+            rc = launch_mala_j0(b, jd, c, fast, tiles, grid, sqrt2h, st);
+            if (rc) return rc;
+            hipLaunchKernelGGL(tune_finish_kernel<1>, dim3(1), dim3(kFinishBlock), 0, st, a.stats.scratch, grid,
+                               dp, a.d, a.stats, a.tune, (unsigned long long)a.n * (unsigned long long)k);
+            NFMC_HIP_CHECK_LAUNCH();
+            store_advance(a.samples, k);
+        }
+        return NFMC_OK;
+    }
     rc = jhp == 0 ? launch_mala_j0(a, jd, c, fast, tiles, grid, sqrt2h, st)
                   : (jhp == 4 ? launch_mala_j4(a, jd, c, fast, tiles, grid, sqrt2h, st)
                               : launch_mala_j8(a, jd, c, fast, tiles, grid, sqrt2h, st));
     if (rc) return rc;
     NFMC_HIP_CHECK_LAUNCH();
-    if (a.tune.state) {
-        hipLaunchKernelGGL(tune_finish_kernel, dim3(stats_finish_grid(dp)), dim3(kFinishBlock), 0, st, a.stats.scratch, grid, dp,
-                           a.d, a.stats, a.tune, (unsigned long long)a.n * (unsigned long long)a.n_steps);
-        NFMC_HIP_CHECK_LAUNCH();
-    } else if (a.stats.sum_x && !a.stats.defer) {
+    if (a.stats.sum_x && !a.stats.defer) {
         hipLaunchKernelGGL(stats_finish_kernel<true>, dim3(stats_finish_grid(dp)), dim3(kFinishBlock), 0, st, a.stats.scratch,
                            grid, dp, a.d, a.stats, (unsigned long long)a.n * (unsigned long long)a.n_steps, jc,
                            (unsigned long long)a.n);
@@ -223,7 +274,8 @@ extern "C" int nfmc_hmc_steps_f32(const NfmcHmcArgs* args, nfmc_stream_t stream)
     const int dp = c.cpl * c.lpc;
     const int cpw = kWave / c.lpc;
     const int64_t tiles = (a.n + (int64_t)kWavesPerBlock * cpw - 1) / ((int64_t)kWavesPerBlock * cpw);
-    const int grid = (int)(tiles < kMaxGrid ? tiles : kMaxGrid);
+    const int gmax = a.tune.state ? kTuneGrid : kMaxGrid;   // warmup: few slabs for the one-workgroup fold
+    const int grid = (int)(tiles < gmax ? tiles : gmax);
     if (a.stats.sum_x && a.stats.scratch_bytes < (int64_t)grid * (2 * dp + kStatTail) * (int64_t)sizeof(double))
         return NFMC_ESCRATCH;
     if (check_defer(a.stats, dp, a.d)) return NFMC_EINVAL;
@@ -231,15 +283,32 @@ extern "C" int nfmc_hmc_steps_f32(const NfmcHmcArgs* args, nfmc_stream_t stream)
     const JumpDev jd = jump_dev(a.jump);
     unsigned long long* jc = a.jump ? a.jump->counters : nullptr;
     a.jump = nullptr;
+    if (a.tune.state) {
+        const int every = (a.tune.every > 0 && a.tune.every < a.n_steps) ? a.tune.every : a.n_steps;
+        const int total = a.n_steps;
+        for (int s0 = 0; s0 < total; s0 += every) {
+            const int k = total - s0 < every ? total - s0 : every;
+            NfmcHmcArgs b = a;
+            b.n_steps = k;
+            b.rng.step0 = a.rng.step0 + (uint32_t)s0;
+            if (a.rng.replay_normals) b.rng.replay_normals = a.rng.replay_normals + (int64_t)s0 * a.n * a.d;
+            if (a.rng.replay_uniforms) b.rng.replay_uniforms = a.rng.replay_uniforms + (int64_t)s0 * a.n;
+            if (a.masks_out) b.masks_out = a.masks_out + (int64_t)s0 * a.n;
+            if (a.log_ratio_out) b.log_ratio_out = a.log_ratio_out + (int64_t)s0 * a.n;
+            rc = launch_hmc_j0(b, jd, c, fast, tiles, grid, st);
+            if (rc) return rc;
+            hipLaunchKernelGGL(tune_finish_kernel<1>, dim3(1), dim3(kFinishBlock), 0, st, a.stats.scratch, grid,
+                               dp, a.d, a.stats, a.tune, (unsigned long long)a.n * (unsigned long long)k);
+            NFMC_HIP_CHECK_LAUNCH();
+            store_advance(a.samples, k);
+        }
+        return NFMC_OK;
+    }
     rc = jhp == 0 ? launch_hmc_j0(a, jd, c, fast, tiles, grid, st)
                   : (jhp == 4 ? launch_hmc_j4(a, jd, c, fast, tiles, grid, st) : launch_hmc_j8(a, jd, c, fast, tiles, grid, st));
     if (rc) return rc;
     NFMC_HIP_CHECK_LAUNCH();
-    if (a.tune.state) {
-        hipLaunchKernelGGL(tune_finish_kernel, dim3(stats_finish_grid(dp)), dim3(kFinishBlock), 0, st, a.stats.scratch, grid, dp,
-                           a.d, a.stats, a.tune, (unsigned long long)a.n * (unsigned long long)a.n_steps);
-        NFMC_HIP_CHECK_LAUNCH();
-    } else if (a.stats.sum_x && !a.stats.defer) {
+    if (a.stats.sum_x && !a.stats.defer) {
         hipLaunchKernelGGL(stats_finish_kernel<true>, dim3(stats_finish_grid(dp)), dim3(kFinishBlock), 0, st, a.stats.scratch,
                            grid, dp, a.d, a.stats, (unsigned long long)a.n * (unsigned long long)a.n_steps, jc,
                            (unsigned long long)a.n);

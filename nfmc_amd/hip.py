@@ -55,7 +55,8 @@ class NfmcJumpTail(C.Structure):
 
 
 class NfmcTune(C.Structure):
-    _fields_ = [('state', c_fp), ('inv_mass_diag', c_fp), ('tune_step_size', C.c_int32), ('tune_inv_mass_diag', C.c_int32)]
+    _fields_ = [('state', c_fp), ('inv_mass_diag', c_fp), ('tune_step_size', C.c_int32), ('tune_inv_mass_diag', C.c_int32),
+                ('every', C.c_int32), ('reserved', C.c_int32)]
 
 
 TUNE_STEP_SIZE, TUNE_LOG_SMOOTH, TUNE_ERROR_SUM, TUNE_ITERATION, TUNE_ANCHOR, TUNE_LOG_RAW = 0, 1, 2, 3, 4, 5

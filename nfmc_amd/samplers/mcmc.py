@@ -82,9 +82,12 @@ class DeviceTuning:
         self.tune_imd = bool(p.tune_inv_mass_diag and run.n > 1)            # mcmc/base.py:146
         self.updates = 0
 
-    def struct(self):
-        self.updates += 1
-        return hip.NfmcTune(hip.ptr(self.state, torch.float64), hip.ptr(self.imd), int(self.tune_step), int(self.tune_imd))
+    def struct(self, every=0, n_steps=1):
+        """NfmcTune for a call of n_steps transitions with one controller update per `every` of them."""
+        every = int(every) if every and every < n_steps else 0
+        self.updates += -(-n_steps // every) if every else 1
+        return hip.NfmcTune(hip.ptr(self.state, torch.float64), hip.ptr(self.imd), int(self.tune_step), int(self.tune_imd),
+                            every, 0)
 
     def download(self, kernel):
         """The tuned kernel back on the host (one copy, at the end of the warmup)."""
@@ -226,7 +229,9 @@ class MCMCSampler(Sampler):
                 and (run.shard is None or run.shard.world == 1) and os.environ.get('NFMC_TUNE_DEVICE', '1') != '0'):
             tune = DeviceTuning(self, run)
             run.rounds = 10   # warmup launches run on the general kernels, which carry the default stream only
-            limit = max(1, min(int(getattr(self.params, 'tune_every', 1)), hip.MAX_STEPS_PER_CALL))
+            # one ABI call enqueues every (kernel, controller) pair of up to 512 transitions: no host work per update
+            tune.every = max(1, int(getattr(self.params, 'tune_every', 1)))
+            limit = hip.MAX_STEPS_PER_CALL if time_limit_seconds is None and not show_progress else max(32, tune.every)
         while done < K:
             if run.time_is_up(t0, time_limit_seconds):
                 break
@@ -368,7 +373,7 @@ class Langevin(MetropolisSampler):
         a.rng = rng if rng is not None else run.rng(step0, k, adjusted=self.params.adjustment)
         if tune is not None:   # the controller rides on the per-call statistics fold
             a.stats = run.stats.struct()
-            a.tune = tune.struct()
+            a.tune = tune.struct(getattr(tune, 'every', 0), k)
         else:
             a.stats = run.stats.struct(defer=True, attempted=run.n * k, jump_attempted=run.n if jump is not None else 0)
         a.samples = hip.store_struct(samples, k + (1 if jump is not None else 0))
@@ -562,7 +567,7 @@ class HMC(MetropolisSampler):
         a.rng = rng if rng is not None else run.rng(step0, k, adjusted=self.params.adjustment)
         if tune is not None:   # the controller rides on the per-call statistics fold
             a.stats = run.stats.struct()
-            a.tune = tune.struct()
+            a.tune = tune.struct(getattr(tune, 'every', 0), k)
         else:
             a.stats = run.stats.struct(defer=True, attempted=run.n * k, jump_attempted=run.n if jump is not None else 0)
         a.samples = hip.store_struct(samples, k + (1 if jump is not None else 0))
