@@ -297,6 +297,8 @@ def _reduce_times(dt, world, dist, dev):
     import torch
     if dist is None:
         return dt, [dt]
+    if dist.get_backend() == 'gloo':
+        dev = 'cpu'
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     allt = torch.empty(world, dtype=torch.float64, device=dev)
     dist.all_gather_into_tensor(allt, t)
@@ -400,6 +402,9 @@ def main():
                          'opt-in stream.  With the default, C3 / C5 also time the 7-round stream and report it as `philox7`')
     ap.add_argument('--backend', choices=['nccl', 'gloo'], default='nccl')
     ap.add_argument('--rehearse', action='store_true', help='launcher / rendezvous / reduction only, no GPU work')
+    ap.add_argument('--share-device', action='store_true',
+                    help='(rehearsal on a one-GPU box, with --backend gloo) every rank computes on cuda:0: the whole N-rank '
+                         'bench path -- launcher, sharding, collectives, reductions -- with real kernels; not a measurement')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-events', action='store_true', help='(experiment) no HIP events in the timed region')
     args = ap.parse_args()
@@ -417,6 +422,8 @@ def main():
     cfg = CONFIGS[args.config]
     # NFMC_BENCH_FORCE_DIST=1: take the multi-rank code path (RCCL init, barriers, collectives) with one rank
     distributed = world > 1 or os.environ.get('NFMC_BENCH_FORCE_DIST') == '1'
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     dist = None
@@ -528,6 +535,7 @@ def main():
             'repetitions': len(reps), 'rep_ms': rep_ms, 'rep_ms_median': statistics.median(rep_ms),
             'rep_ms_min': min(rep_ms), 'rep_ms_max': max(rep_ms),
             'world_size_reported_by_backend': dist.get_world_size() if dist is not None else 1,
+            'backend': dist.get_backend() if dist is not None else None,
             'per_rank_ms': [1e3 * v for v in per_rank],
             'roofline': roofline(args.config, cfg, n_local, mean_ms, n_launches, transitions_per_launch),
             'parity': {'mean_abs_max': float(out.mean.abs().max()), 'variance_mean': float(out.variance.mean()),
