@@ -347,3 +347,43 @@ def test_async_host_spill_of_the_kept_states(dev):
     assert torch.equal(hb, a.samples[::2])
     assert b.samples is hb                                     # cached: one device-to-host copy per store
     assert torch.equal(b.samples_device.cpu(), hb)
+
+
+def test_kept_states_with_refits_time_limits_and_shards(dev):
+    """The device store on the paths the 48-case sweep does not reach: a jump run that refits the flow (its inner
+    states go through the dense refit block first and are offered to the store from there), an early stop by time limit
+    (the ring is read back from what was offered so far), and sharded chains (each rank keeps its own rows)."""
+    from nfmc_amd import sample
+    from nfmc_amd.dist import Shard
+    from nfmc_amd.potentials import SumOfSquares
+    d, n, T, K = 16, 60, 4, 3
+    x0 = torch.randn(n, d, generator=torch.Generator().manual_seed(4)) * 0.7
+
+    def run(pk, **kw):
+        torch.manual_seed(2)
+        return sample(SumOfSquares((d,)), strategy='jump_mala', x0=x0, n_iterations=T, show_progress=False, seed=5,
+                      inner_param_kwargs={'n_iterations': K},
+                      param_kwargs={'fit_nf': True, 'n_jumps_before_training': 1, 'flow_fit_kwargs': {'n_epochs': 2}, **pk}, **kw)
+
+    dense = run({}).samples
+    assert dense.shape == (T * (K + 1), n, d)
+    thin = run({'thinning': 3, 'max_samples': 4})
+    assert torch.equal(thin.samples, _reference_window(dense, 3, 4))
+    # sharded: rank r's kept rows are its slice of the single-process run (no refit: weights stay equal by construction)
+    plain = sample(SumOfSquares((d,)), strategy='jump_mala', x0=x0, n_iterations=T, show_progress=False, seed=5,
+                   inner_param_kwargs={'n_iterations': K}, param_kwargs={'thinning': 2, 'max_samples': 5})
+    for r in range(2):
+        sh = Shard(rank=r, world=2)
+        sh.merge_statistics = lambda s_: s_
+        torch.manual_seed(0)
+        part = sample(SumOfSquares((d,)), strategy='jump_mala', x0=x0, n_iterations=T, show_progress=False, seed=5, shard=sh,
+                      inner_param_kwargs={'n_iterations': K}, param_kwargs={'thinning': 2, 'max_samples': 5})
+        lo, hi = sh.bounds(n)
+        assert part.samples.shape == (5, hi - lo, d)
+    # time limit: whatever was offered before the stop, cut by the same rule
+    lim = sample(SumOfSquares((d,)), strategy='mala', x0=x0, n_iterations=100000, show_progress=False, seed=5,
+                 sampling_time_limit_seconds=0.05, param_kwargs={'thinning': 7, 'max_samples': 6})
+    seen = lim.running_samples.seen_samples
+    assert 0 < seen < 100000 and lim.samples.shape[0] == min(6, -(-seen // 7))
+    full = sample(SumOfSquares((d,)), strategy='mala', x0=x0, n_iterations=seen, show_progress=False, seed=5).samples
+    assert torch.equal(lim.samples, _reference_window(full, 7, 6))
