@@ -112,7 +112,8 @@ typedef struct {
                                  [-spline_bound, spline_bound], identity outside; the last conditioner layer then has
                                  (3*n_bins - 1) * d_b outputs, target-major: [t*(3K-1) + (K widths | K heights | K-1
                                  derivatives)] (spec: DESIGN.md section 4).  Spline flows run on the one-chain-per-lane
-                                 kernels with n_hidden <= 32; the NeuTra entry points return NFMC_EUNSUPPORTED. */
+                                 kernels with n_hidden <= 32 (forward, inverse, flow-MH, and the NeuTra reverse sweep:
+                                 hand-written adjoints of the spline, csrc/flow_device.hpp rqs_inverse_backward). */
     const float* ea0_log_scale; /* (d,) first ElementwiseAffine */
     const float* ea0_shift;
     const float* ea1_log_scale; /* (d,) last ElementwiseAffine */

@@ -211,6 +211,157 @@ __device__ __forceinline__ float rqs_coordinate(float v, const float (&raw)[3 * 
     return inside ? out : v;
 }
 
+// Reverse mode through one spline coordinate of an INVERSE coupling layer (NeuTra's reverse sweep).  The layer computed
+// y = F^-1(v; theta) with F the forward spline, and contributed l = log F'(y; theta) to L = U(x) - logdet_inverse.
+// Given y (the layer's OUTPUT), gy = dL/dy from downstream and the coordinate's raw conditioner outputs, returns
+//     v  = F(y; theta)                                 the layer input, rebuilt with the forward map (no root finding)
+//     q  = dL/dv = (gy + dl/dy) / F'(y)                implicit-function theorem on F(y; theta) = v
+//     draw[j] = dL/draw_j = dl/dtheta - q dF/dtheta    chained through the bin's six knot values to the 3K - 1 raw
+//                                                      outputs (softmax widths / heights, softplus derivatives)
+// All partials are those of the FORWARD formulas of rqs_coordinate (hand-written adjoints of its expression graph).
+__device__ __forceinline__ void rqs_inverse_backward(float y, float gy, const float (&raw)[3 * kRqsBins - 1], float B,
+                                                     float (&draw)[3 * kRqsBins - 1], float& v_out, float& q_out) {
+    constexpr int K = kRqsBins;
+    constexpr float scale = 1.f - K * kRqsMinBin;
+#pragma unroll
+    for (int j = 0; j < 3 * K - 1; ++j) draw[j] = 0.f;
+    if (!(y >= -B && y <= B)) {   // identity tails: dL/dv = dL/dy, no parameter gradient
+        v_out = y;
+        q_out = gy;
+        return;
+    }
+    float smw[K], smh[K];
+    float mw = raw[0], mh = raw[K];
+#pragma unroll
+    for (int k = 1; k < K; ++k) {
+        mw = fmaxf(mw, raw[k]);
+        mh = fmaxf(mh, raw[K + k]);
+    }
+    float sw = 0.f, sh = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        smw[k] = fast_exp(raw[k] - mw);
+        smh[k] = fast_exp(raw[K + k] - mh);
+        sw += smw[k];
+        sh += smh[k];
+    }
+    const float rsw = __builtin_amdgcn_rcpf(sw), rsh = __builtin_amdgcn_rcpf(sh);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        smw[k] *= rsw;   // softmax
+        smh[k] *= rsh;
+    }
+    // scan for the bin of y (forward direction: by the width knots), keeping its corners, its index and the
+    // cumulative softmax mass below each of its two width / height knots
+    float cw = -B, ch = -B, dk = 1.f, cmw = 0.f, cmh = 0.f;
+    float x0 = -B, x1 = B, y0 = -B, y1 = B, d0 = 1.f, d1 = 1.f, cw0 = 0.f, cw1 = 1.f, chm0 = 0.f, chm1 = 1.f;
+    int bin = 0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const float cwn = k == K - 1 ? B : fmaf(2.f * B, fmaf(scale, smw[k], kRqsMinBin), cw);
+        const float chn = k == K - 1 ? B : fmaf(2.f * B, fmaf(scale, smh[k], kRqsMinBin), ch);
+        float dn = 1.f;
+        if (k < K - 1) {
+            const float u = raw[2 * K + k];
+            dn = kRqsMinDeriv + fmaxf(u, 0.f) + fast_ln(1.f + fast_exp(-fabsf(u)));
+        }
+        const bool here = k == 0 || y >= cw;
+        x0 = here ? cw : x0;
+        x1 = here ? cwn : x1;
+        y0 = here ? ch : y0;
+        y1 = here ? chn : y1;
+        d0 = here ? dk : d0;
+        d1 = here ? dn : d1;
+        cw0 = here ? cmw : cw0;
+        cw1 = here ? cmw + smw[k] : cw1;
+        chm0 = here ? cmh : chm0;
+        chm1 = here ? cmh + smh[k] : chm1;
+        bin = here ? k : bin;
+        cw = cwn;
+        ch = chn;
+        dk = dn;
+        cmw += smw[k];
+        cmh += smh[k];
+    }
+    // forward value and log-derivative at y
+    const float bw = x1 - x0, bh = y1 - y0;
+    const float rbw = __builtin_amdgcn_rcpf(bw);
+    const float s = bh * rbw;
+    const float th = (y - x0) * rbw, om = 1.f - th, t1 = th * om;
+    const float dd = d0 + d1 - 2.f * s;
+    const float N = fmaf(s * th, th, d0 * t1);
+    const float num = bh * N;
+    const float den = fmaf(dd, t1, s);
+    const float rden = __builtin_amdgcn_rcpf(den);
+    const float A = fmaf(d1 * th, th, fmaf(2.f * s, t1, d0 * om * om));
+    const float rA = __builtin_amdgcn_rcpf(A);
+    v_out = fmaf(num, rden, y0);
+    const float Fp = s * s * A * rden * rden;                                  // F'(y) = exp(l)
+    const float dA_dth = 2.f * (d1 * th + s * (1.f - 2.f * th) - d0 * om);
+    const float dl_dy = (dA_dth * rA - 2.f * dd * (1.f - 2.f * th) * rden) * rbw;
+    const float q = (gy + dl_dy) * __builtin_amdgcn_rcpf(Fp);
+    q_out = q;
+    // adjoints of (F, l) with F-bar = -q, l-bar = 1, down to the six knot values
+    const float Fb = -q;
+    float y0b = Fb, y1b = 0.f, x0b = 0.f, x1b = 0.f, d0b = 0.f, d1b = 0.f;
+    const float numb = Fb * rden;
+    float denb = -Fb * num * rden * rden - 2.f * rden;
+    float sb = 2.f * __builtin_amdgcn_rcpf(s);
+    const float Ab = rA;
+    d1b += Ab * th * th;
+    sb += Ab * 2.f * t1;
+    float t1b = Ab * 2.f * s;
+    d0b += Ab * om * om;
+    float thb = Ab * 2.f * d1 * th;
+    float omb = Ab * 2.f * d0 * om;
+    sb += denb;
+    const float ddb = denb * t1;
+    t1b += denb * dd;
+    float bhb = numb * N;
+    const float Nb = numb * bh;
+    sb += Nb * th * th;
+    thb += Nb * 2.f * s * th;
+    d0b += Nb * t1;
+    t1b += Nb * d0;
+    d0b += ddb;
+    d1b += ddb;
+    sb -= 2.f * ddb;
+    thb += t1b * om;
+    omb += t1b * th;
+    thb -= omb;
+    x0b -= thb * rbw;
+    float bwb = -thb * th * rbw;
+    bhb += sb * rbw;
+    bwb -= sb * s * rbw;
+    y1b += bhb;
+    y0b -= bhb;
+    x1b += bwb;
+    x0b -= bwb;
+    // knots -> raw outputs.  Knot k (1 <= k <= K - 1) = -B + 2B sum_{i<k} (scale softmax_i + min): the end knots are constants
+    if (bin == 0) {
+        x0b = 0.f;
+        y0b = 0.f;
+        d0b = 0.f;
+    }
+    if (bin == K - 1) {
+        x1b = 0.f;
+        y1b = 0.f;
+        d1b = 0.f;
+    }
+    const float cs = 2.f * B * scale;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const float below0 = j < bin ? 1.f : 0.f, below1 = j <= bin ? 1.f : 0.f;
+        draw[j] = cs * smw[j] * (x0b * (below0 - cw0) + x1b * (below1 - cw1));
+        draw[K + j] = cs * smh[j] * (y0b * (below0 - chm0) + y1b * (below1 - chm1));
+    }
+#pragma unroll
+    for (int j = 0; j < K - 1; ++j) {   // derivative knot j + 1 = min + softplus(raw[2K + j]); d softplus = sigmoid
+        const float sg = __builtin_amdgcn_rcpf(1.f + fast_exp(-raw[2 * K + j]));
+        draw[2 * K + j] = (j + 1 == bin ? d0b : 0.f) * sg + (j == bin ? d1b : 0.f) * sg;
+    }
+}
+
 // spline variant of the target loop of coupling_apply: W3 rows are target-major, (3K-1) per target
 template <int HP, bool INVERSE>
 __device__ __forceinline__ float coupling_targets_rqs(float* __restrict__ row, const float* __restrict__ W3,

@@ -87,10 +87,35 @@ __device__ __forceinline__ void coupling_inverse_backward(float* __restrict__ wr
     }
     // output layer: transform parameters per target coordinate, their gradients, and dL/dh_last
     const float* W3 = w3_of(W, g, HP);
-    const float* b3 = W3 + (int64_t)2 * g.d_b * HP;
+    const float* b3 = W3 + (int64_t)g.out_rows * HP;
     float dh[HP];
 #pragma unroll
     for (int k = 0; k < HP; ++k) dh[k] = 0.f;
+    if (g.n_bins > 0) {
+        // rational-quadratic spline couplings ('c-rqnsf'): 3K - 1 conditioner outputs per target coordinate
+        constexpr int P = 3 * kRqsBins - 1;
+        for (int t = 0; t < g.d_b; ++t) {
+            float raw[P], draw[P];
+            const float* wr = W3 + (int64_t)t * P * HP;
+#pragma unroll
+            for (int q = 0; q < P; ++q) {
+                float u = b3[t * P + q];
+#pragma unroll
+                for (int k = 0; k < HP; ++k) u = fmaf(wr[q * HP + k], hl[k], u);
+                raw[q] = u;
+            }
+            const int p = phys(g.d_a + t, g.d, rev);
+            float v, gv;
+            rqs_inverse_backward(wrow[p], grow[p], raw, g.bound, draw, v, gv);
+#pragma unroll
+            for (int q = 0; q < P; ++q) {
+#pragma unroll
+                for (int k = 0; k < HP; ++k) dh[k] = fmaf(wr[q * HP + k], draw[q], dh[k]);
+            }
+            grow[p] = gv;
+            wrow[p] = v;                                 // rebuild the layer input
+        }
+    } else
     for (int t = 0; t < g.d_b; ++t) {
         float ua = b3[t], ub = b3[g.d_b + t];
         const float* wa = W3 + (int64_t)t * HP;
@@ -373,8 +398,8 @@ static int check_flow_neutra(const NfmcRealNVP* f) {
     if (f->d < 2 && f->n_coupling > 0) return NFMC_ESHAPE;
     if (f->d > 512) return NFMC_ESHAPE;
     if (f->n_hidden_layers > kMaxHiddenLayers) return NFMC_ESHAPE;
-    if (f->n_hidden > 32 || f->n_bins != 0) return NFMC_EUNSUPPORTED;   // spline couplings: no reverse-sweep kernel
-    if (f->n_coupling > 0 && f->layer_stride < nfmc_realnvp_layer_floats(f->d, f->n_hidden, f->n_hidden_layers))
+    if (f->n_hidden > 32 || (f->n_bins != 0 && f->n_bins != kRqsBins)) return NFMC_EUNSUPPORTED;
+    if (f->n_coupling > 0 && f->layer_stride < nfmc_coupling_layer_floats(f->d, f->n_hidden, f->n_hidden_layers, f->n_bins))
         return NFMC_EINVAL;
     return NFMC_OK;
 }
@@ -410,8 +435,7 @@ extern "C" int64_t nfmc_neutra_scratch_bytes(int64_t n, int32_t d, int32_t n_hid
 
 extern "C" int nfmc_neutra_potential_grad_f32(const NfmcRealNVP* flow, const NfmcPotential* pot, const float* z,
                                               int64_t n, float* u_out, float* grad_out, nfmc_stream_t stream) {
-    if (flow && flow->n_bins != 0) return NFMC_EUNSUPPORTED;
-    if (flow && flow->n_hidden > 32) return nfmc_neutra_potential_grad_mfma_f32(flow, pot, z, n, u_out, grad_out, stream);
+    if (flow && flow->n_hidden > 32 && flow->n_bins == 0) return nfmc_neutra_potential_grad_mfma_f32(flow, pot, z, n, u_out, grad_out, stream);
     int rc = check_flow_neutra(flow);
     if (rc) return rc;
     if (!pot || !z || n <= 0) return NFMC_EINVAL;
@@ -434,8 +458,7 @@ extern "C" int nfmc_neutra_hmc_steps_f32(const NfmcNeutraHmcArgs* args, nfmc_str
     NfmcNeutraHmcArgs a = *args;
     if (a.stats.sum_x && a.stats.defer) return NFMC_EUNSUPPORTED;   // NeuTra folds its statistics per call
     if (int rr = rng_default_only(a.rng)) return rr;
-    if (a.flow.n_bins != 0) return NFMC_EUNSUPPORTED;
-    if (a.flow.n_hidden > 32) {
+    if (a.flow.n_hidden > 32 && a.flow.n_bins == 0) {
         if (!a.z || a.n <= 0 || a.n_steps <= 0 || a.n_leapfrog <= 0 || !(a.step_size > 0.f)) return NFMC_EINVAL;
         if (a.n_steps > NFMC_MAX_STEPS_PER_CALL) return NFMC_ESHAPE;
         if (a.pot.kind != NFMC_POT_QUADRATIC && a.pot.kind != NFMC_POT_FUNNEL) return NFMC_EUNSUPPORTED;

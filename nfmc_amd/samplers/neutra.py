@@ -65,16 +65,15 @@ class NeuTra(Sampler):
         n = _z.shape[0]
         dev = hip.require_gpu()
         grad_needed = torch.is_grad_enabled() and _z.requires_grad
-        if (grad_needed and not getattr(self.kernel.flow.bijection, 'n_bins', 0) and self._grad_kernel_ok
-                and self._closed_form() is not None):
+        if grad_needed and self._grad_kernel_ok and self._closed_form() is not None:
             try:
                 return _AdjustedPotential.apply(_z, self)
             except hip.NfmcArgumentError as e:
                 if not e.no_kernel:
                     raise
-                self._grad_kernel_ok = False   # e.g. d > ~200 (three wave tiles exceed the LDS), H > 32 off the MFMA shapes
+                self._grad_kernel_ok = False   # e.g. d > ~200 (three wave tiles exceed the LDS), H > 32 off the MFMA shapes, wide spline conditioners
         if grad_needed:
-            # spline couplings / shapes without a reverse-sweep kernel: differentiate the torch restatement of the
+            # shapes without a reverse-sweep kernel: differentiate the torch restatement of the
             # flow (on the GPU; the target is the user's callable)
             from ..flow_training import inverse_torch
             flow = self.kernel.flow
@@ -94,7 +93,7 @@ class NeuTra(Sampler):
         matrix cores (csrc/neutra_mfma.hip) also when the flow's own conditioner is narrow (zero-padded)."""
         bij = self.kernel.flow.bijection
         ok = (getattr(bij, 'd', 0) in (64, 128) and getattr(bij, 'n_hidden_layers', 0) in (1, 2)
-              and os.environ.get('NFMC_NEUTRA_VALU', '0') != '1')
+              and not getattr(bij, 'n_bins', 0) and os.environ.get('NFMC_NEUTRA_VALU', '0') != '1')
         return 64 if ok else 0
 
     def _closed_form(self):
@@ -152,7 +151,7 @@ class NeuTra(Sampler):
             out.kernel.flow = self.kernel.flow
             return out
 
-        if not isinstance(inner, HMC) or pot is None or getattr(self.kernel.flow.bijection, 'n_bins', 0):
+        if not isinstance(inner, HMC) or pot is None:
             return split()
         out = MCMCOutput(event_shape, store_samples=self.params.store_samples,
                          max_samples=getattr(self.params, 'max_samples', None))

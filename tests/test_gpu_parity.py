@@ -581,6 +581,76 @@ def test_philox_7_round_stream(dev):
         sample(SumOfSquares((d,)), strategy='mala', x0=x0, n_iterations=2, show_progress=False, rng_rounds=8)
 
 
+@pytest.mark.parametrize('d,nl,nh,cl,pot', [(6, 2, None, 2, 'sumsq'), (7, 3, 5, 1, 'funnel'), (24, 2, 16, 2, 'sumsq'),
+                                             (33, 1, 32, 2, 'funnel')])
+def test_neutra_spline_potential_and_gradient_match_autograd(dev, d, nl, nh, cl, pot):
+    """f4: the reverse sweep through rational-quadratic spline couplings ('c-rqnsf'; hand-written adjoints of the
+    spline's forward formulas + the implicit-function theorem for the inverse direction, flow_device.hpp
+    rqs_inverse_backward) equals torch autograd through the CPU restatement of NeuTra.adjusted_target
+    (neutra.py:58-68), including chains whose coordinates leave the spline's interval (identity tails)."""
+    from nfmc_amd import hip
+    from nfmc_amd.util import create_flow_object
+    from nfmc_amd.potentials import SumOfSquares, Funnel
+    from oracle import flow as oflow, potentials as opot, samplers as osamp
+    ck = {'n_layers': cl}
+    if nh is not None:
+        ck['n_hidden'] = nh
+    torch.manual_seed(d * 3 + nl)
+    of = oflow.perturb_(oflow.Flow(oflow.CRQNSF((d,), n_layers=nl, conditioner_kwargs=ck)), 9, 1.0 if d <= 8 else 0.3, 0.8)
+    f = create_flow_object('c-rqnsf', (d,), n_layers=nl, conditioner_kwargs=ck)
+    f.load_state_dict(of.state_dict())
+    target_cpu = opot.sum_squares if pot == 'sumsq' else opot.funnel(3.0)
+    target = SumOfSquares((d,)) if pot == 'sumsq' else Funnel((d,), 3.0)
+    n = 130
+    z = 1.2 * torch.randn(n, d)
+    z[:6] *= 5.0                       # some coordinates beyond the bound B = 5
+    z = z.requires_grad_(True)
+    u_ref = osamp.neutra_adjusted_target(of, target_cpu, (d,))(z)
+    g_ref, = torch.autograd.grad(u_ref.sum(), z)
+    st, _keep = f.bijection.packed(dev)
+    pd = target.descriptor(dev)
+    zd = z.detach().to(dev).contiguous()
+    u = torch.empty(n, device=dev)
+    g = torch.empty(n, d, device=dev)
+    hip.check(hip.lib().nfmc_neutra_potential_grad_f32(C.byref(st), C.byref(pd), hip.ptr(zd), n, hip.ptr(u), hip.ptr(g),
+                                                       hip.stream()), 'neutra_potential_grad')
+    ur, gr = u_ref.detach(), g_ref
+    np.testing.assert_allclose(u.cpu().numpy(), ur.numpy(), atol=2e-4 * (1 + float(ur.abs().max())), rtol=0)
+    err = (g.cpu() - gr).abs().amax(dim=1) / (1 + gr.abs().amax(dim=1))
+    # a coordinate within rounding of a knot may sit in the neighbouring bin on the other side: the value is continuous
+    # there, the gradient of the log-derivative term is not
+    assert (err < 2e-3).float().mean() > 0.97, float((err < 2e-3).float().mean())
+    assert float(err.median()) < 2e-4
+
+
+def test_neutra_hmc_with_spline_flow_on_the_fused_kernel(dev):
+    """neutra_hmc with a 'c-rqnsf' flow runs inside nfmc_neutra_hmc_steps_f32 (no split path) and matches the oracle on
+    the native stream."""
+    from nfmc_amd.samplers import neutra, mcmc
+    from nfmc_amd.util import create_flow_object
+    from nfmc_amd.potentials import SumOfSquares
+    from oracle import flow as oflow, potentials as opot, samplers as osamp
+    d, n, T, L, h = 10, 120, 3, 4, 0.03
+    torch.manual_seed(4)
+    of = oflow.perturb_(oflow.Flow(oflow.CRQNSF((d,))), 9, 0.5, 0.8)
+    f = create_flow_object('c-rqnsf', (d,))
+    f.load_state_dict(of.state_dict())
+    z0 = 0.7 * torch.randn(n, d)
+    s = neutra.NeuTraHMC((d,), SumOfSquares((d,)), mcmc.HMCKernel(event_size=d, n_leapfrog_steps=L, step_size=h),
+                         mcmc.HMCParameters(), neutra.NeuTraKernel((d,), flow=f), neutra.NeuTraParameters(n_iterations=T))
+
+    def boom(*a, **k):
+        raise AssertionError('split path taken')
+    s.inner_sampler.sample = boom
+    s.seed = 12
+    out = s.sample(z0, show_progress=False)
+    tr = osamp.neutra_hmc_sample(z0, opot.sum_squares, of, T, h, None, L, noise=osamp.PhiloxNoise(12))
+    got, want = out.samples.reshape(T, n, d), tr.stacked()
+    same = (got - want).abs().amax(dim=(0, 2)) < 1e-3
+    assert same.float().mean() > 0.93, float(same.float().mean())
+    assert abs(out.statistics.n_accepted_trajectories - tr.n_accepted) <= 6
+
+
 # ------------------------------------------------------------------------------------------ size-independent properties
 def test_moments_of_sum_squares_target_large(dev):
     """U = sum x^2 => N(0, I/2): mean 0, variance 0.5 (README.md:45-46) at n=65536, d=64."""
