@@ -19,7 +19,9 @@ store_samples=False, x0 ~ N(0, I) from torch.manual_seed(0) on the CPU, uploaded
 "step" = one outer iteration = 101 Markov transitions of every chain.  W untimed warm-up steps carry the state from
 x0 to stationarity; then R (>= 5) timed repetitions of EXACTLY K steps each, every repetition bracketed by barrier +
 synchronize on both sides and reduced by MAX over ranks; `value` / `ms_per_step` come from the MEDIAN repetition
-(median of >= 5 runs), all repetitions are listed in `rep_ms`.
+(median of >= 5 runs), all repetitions are listed in `rep_ms`.  One further repetition of the same K
+steps carries HIP events around every launch of the dominant kernel (`events_rep_ms`; the events cost 3-4 % of a
+step, so it is not one of the R).
   value = n_chains_total * transitions_per_step * K / t_median.
 
 roofline.  The dominant kernel of C3 is `mala_kernel`: it keeps the state in VGPRs for the 100 transitions of a
@@ -479,23 +481,34 @@ def main():
     gc.disable()
     reps = []
     label = cfg['label']
-    for _ in range(args.reps):
-        dt, out = run(args.steps, x_start, time_kernels=False if args.no_kernel_events else label)
+    # R repetitions WITHOUT events give `value` (an event pair per launch costs ~6 us of stream time: 3-4 % of a C3 step,
+    # measured); one more repetition of the same K steps, same brackets, WITH HIP events on the launch stream around
+    # every launch of the dominant kernel gives the roofline's launch duration (`events_rep_ms` is its wall time)
+    for i in range(args.reps + (0 if args.no_kernel_events else 1)):
+        timed_launches = (i == args.reps)
+        dt, out = run(args.steps, x_start, time_kernels=label if timed_launches else False)
         dt_max, per_rank = _reduce_times(dt, world, dist, dev)
         ev = [a.elapsed_time(b) for (l, a, b) in (getattr(out, 'kernel_events', None) or []) if l == label]
-        reps.append((dt_max, per_rank, out, ev))
+        if timed_launches:
+            events_rep = (dt_max, ev)
+        else:
+            reps.append((dt_max, per_rank, out, ev))
+    if args.no_kernel_events:
+        events_rep = (None, [])
     # the opt-in Philox4x32-7 stream next to the default (three repetitions, same protocol): a reported side figure
     alt = None
     if args.rng_rounds == 10 and cfg['strategy'] in ('jump_mala', 'jump_hmc') and not args.fit_nf:
-        alt_reps = []
-        for _ in range(3):
-            dt7, out7 = run(args.steps, x_start, time_kernels=False if args.no_kernel_events else label, rounds=7)
+        alt_reps, ev_all7 = [], []
+        for i7 in range(3 if args.no_kernel_events else 4):
+            timed_launches = (i7 == 3)
+            dt7, out7 = run(args.steps, x_start, time_kernels=label if timed_launches else False, rounds=7)
             dt7_max, _pr = _reduce_times(dt7, world, dist, dev)
-            ev7 = [a.elapsed_time(b) for (l, a, b) in (getattr(out7, 'kernel_events', None) or []) if l == label]
-            alt_reps.append((dt7_max, out7, ev7))
+            if timed_launches:
+                ev_all7 = [a.elapsed_time(b) for (l, a, b) in (getattr(out7, 'kernel_events', None) or []) if l == label]
+            else:
+                alt_reps.append((dt7_max, out7))
         alt_reps.sort(key=lambda r_: r_[0])
-        dt7, out7, _e = alt_reps[1]
-        ev_all7 = [ms for r_ in alt_reps for ms in r_[2]]
+        dt7, out7 = alt_reps[1]
         alt = {'rounds': 7, 'value': n_total * cfg['transitions_per_step'] * args.steps / dt7,
                'ms_per_step': dt7 / args.steps * 1e3, 'rep_ms': [1e3 * r_[0] for r_ in alt_reps],
                'mean_launch_ms': (sum(ev_all7) / len(ev_all7)) if ev_all7 else None,
@@ -509,7 +522,7 @@ def main():
         order = sorted(range(len(reps)), key=lambda i: reps[i][0])
         med = order[len(order) // 2]
         dt, per_rank, out, _ev = reps[med]
-        all_ev = [ms for r_ in reps for ms in r_[3]]
+        all_ev = list(events_rep[1])
         # what one HIP-event pair brackets: one launch of the inner kernel (C3: 100 MALA transitions, C5: 5
         # trajectories); for C4 one nfmc_neutra_hmc_steps_f32 call = K trajectory launches; for C2 one
         # nfmc_imh_parallel_f32 call = the three kernels of K*50 transitions (reported as ONE "launch")
@@ -533,6 +546,7 @@ def main():
                        'sharding': f'chains x{world}, no data-path collective; one statistics all-reduce per sample()'
                                    + ('; refit-buffer all-gather every outer iteration' if args.fit_nf else '')},
             'repetitions': len(reps), 'rep_ms': rep_ms, 'rep_ms_median': statistics.median(rep_ms),
+            'events_rep_ms': (1e3 * events_rep[0]) if events_rep[0] is not None else None,
             'rep_ms_min': min(rep_ms), 'rep_ms_max': max(rep_ms),
             'world_size_reported_by_backend': dist.get_world_size() if dist is not None else 1,
             'backend': dist.get_backend() if dist is not None else None,
