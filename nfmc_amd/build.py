@@ -24,6 +24,13 @@ LIB = os.path.join(HERE, 'libnfmc_hip%s.so' % ('.' + VARIANT if VARIANT else '')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-I' + INCLUDE, '-I' + CSRC,
          '-Wno-unused-result'] + os.environ.get('NFMC_EXTRA_FLAGS', '').split()
+# The matrix-core units keep their per-chain state as arrays of 16-byte tiles (f32x4 x[8], ...) that live across loops.
+# LLVM's AMDGPU alloca promotion turns such an array into ONE <32 x float> value = one 1024-bit register tuple: 32
+# contiguous registers, spilled and reloaded as a whole (measured: the gradient tile set was reloaded 8 x 16 bytes before
+# every GEMM step that accumulated into one of its tiles).  With the promotion limited to 16 bytes SROA splits the arrays
+# into independent 128-bit values instead.
+UNIT_FLAGS = {'neutra_mfma.hip': ['-mllvm', '-amdgpu-promote-alloca-to-vector-limit=16'],
+              'flow_mfma.hip': ['-mllvm', '-amdgpu-promote-alloca-to-vector-limit=16']}
 
 
 def sources():
@@ -40,12 +47,13 @@ def _digest():
                 with open(p, 'rb') as fh:
                     h.update(fh.read())
     h.update(' '.join(FLAGS).encode())
+    h.update(repr(sorted(UNIT_FLAGS.items())).encode())
     return h.hexdigest()
 
 
 def _compile(src):
     obj = os.path.join(OBJ, src[:-4] + '.o')
-    cmd = [HIPCC] + FLAGS + ['-c', os.path.join(CSRC, src), '-o', obj]
+    cmd = [HIPCC] + FLAGS + UNIT_FLAGS.get(src, []) + ['-c', os.path.join(CSRC, src), '-o', obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError('hipcc failed for %s:\n%s' % (src, r.stderr[-4000:]))

@@ -40,6 +40,9 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 #ifndef NFMC_STAGE_BATCH
 #define NFMC_STAGE_BATCH 4
 #endif
+#ifndef NFMC_FRAG_CHUNK
+#define NFMC_FRAG_CHUNK 4
+#endif
 #ifndef NFMC_EPI_VALU
 #define NFMC_EPI_VALU 4
 #endif
@@ -47,6 +50,7 @@ constexpr int kMfmaWaves = NFMC_MFMA_WAVES;
 constexpr int kMfmaImages = NFMC_MFMA_IMAGES;
 constexpr int kMfmaBlock = 64 * kMfmaWaves;
 constexpr int kMfmaChains = 16 * kMfmaWaves;     // chains per workgroup
+constexpr int kCkMaxGrid = 512;                  // workgroup slots of the NeuTra trajectory kernel (2 per CU); more chain tiles grid-stride
 
 struct MLayer {
     const float *W1, *W1T, *b1, *Wh, *WhT, *bh, *W3, *W3T, *b3;
@@ -218,22 +222,54 @@ __device__ __forceinline__ void gemm_phase(Row row, Init init, Acc acc, Act act,
     return;
 #endif
 #if !defined(NFMC_MFMA_PAIRS) && !defined(NFMC_MFMA_PREFETCH) && !defined(NFMC_MFMA_EPI)
-    // DEFAULT (fastest measured, see the table above)
+#ifdef NFMC_SKEW_SPLIT
+    // Experiment: the partner waves of a SIMD run the SAME steps one epilogue apart -- these waves do MFMAs(i) and then
+    // the epilogue of step i - 1, the others MFMAs(i), epilogue(i) -- so that one wave's elementwise work falls under
+    // the other's MFMAs instead of both running it together with the matrix pipe idle.
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & NFMC_SKEW_SPLIT) {
+#pragma unroll
+        for (int i = 0; i < NSTEP; ++i) {
+            f32x4 a[TK];
+            frag_load<TK>(a, row(i));
+            init(i);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mk = 0; mk < TK; ++mk)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc(i) = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mk][r], act(i)[mk][r], acc(i), 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (i > 0) fin(i - 1);
+        }
+        fin(NSTEP - 1);
+        return;
+    }
+#endif
+    // DEFAULT (fastest measured, see the table above).  A step's A fragments are read in chunks of at most kFragChunk
+    // k-tiles (4 registers each): the scheduler may move the NEXT chunk's reads above this chunk's MFMAs (the fence
+    // stops anything further), so the fragments cost 2 x 4 x kFragChunk registers at the peak -- 32 instead of 64 for
+    // an 8-tile step: the kernel lives at the 256-register limit of two waves per SIMD and spills cost more than the
+    // shorter look-ahead (16 MFMAs = 512 cycles still cover an LDS read).
+    constexpr int CH = TK < NFMC_FRAG_CHUNK ? TK : NFMC_FRAG_CHUNK;
+    static_assert(TK % CH == 0, "whole chunks");
 #pragma unroll
     for (int i = 0; i < NSTEP; ++i) {   // one step at a time: reads, then MFMAs, then epilogue
-        f32x4 a[TK];
-        frag_load<TK>(a, row(i));
         init(i);
-        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c0 = 0; c0 < TK; c0 += CH) {
+            f32x4 a[CH];
+            frag_load<CH>(a, row(i) + 16 * c0);
+            __builtin_amdgcn_sched_barrier(0);
 #ifdef NFMC_X_NO_MFMA
 #pragma unroll
-        for (int mk = 0; mk < TK; ++mk) asm volatile("" ::"v"(a[mk]));   // ablation: reads kept, no MFMAs
+            for (int mk = 0; mk < CH; ++mk) asm volatile("" ::"v"(a[mk]));   // ablation: reads kept, no MFMAs
 #else
 #pragma unroll
-        for (int mk = 0; mk < TK; ++mk)
+            for (int mk = 0; mk < CH; ++mk)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc(i) = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mk][r], act(i)[mk][r], acc(i), 0, 0, 0);
+                for (int r = 0; r < 4; ++r)
+                    acc(i) = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mk][r], act(i)[c0 + mk][r], acc(i), 0, 0, 0);
 #endif
+        }
         fin(i);
     }
     return;
@@ -388,17 +424,32 @@ int nfmc_flow_mh_steps_mfma_f32(const NfmcFlowMhArgs& a, nfmc_stream_t stream, i
 struct WeightPipe {
     float* lds;
     int buf;
+#ifdef NFMC_TRACE
+    // Diagnostic build (tools/trace_c4.py): workgroup 0 writes (id << 48 | s_memtime) marks, one stream per wave
+    unsigned long long* tr = nullptr;
+    __device__ __forceinline__ void mark(int id) {
+        if (tr) {
+            if ((threadIdx.x & 63) == 0) *tr = ((unsigned long long)id << 48) | (__builtin_amdgcn_s_memtime() & 0xFFFFFFFFFFFFull);
+            ++tr;
+        }
+    }
+#else
+    __device__ __forceinline__ void mark(int) {}
+#endif
     __device__ __forceinline__ float* img() const { return lds + buf * kImgFloats; }
     __device__ __forceinline__ float* vec() const { return lds + kMfmaImages * kImgFloats + buf * kVecFloats; }
     // stage matrix W (rows x K) and, if given, a vector, into the next image; closes with the barrier
     template <int K, int RBLK, int CBLK, int VBLK, int ROWS>
     __device__ __forceinline__ void stage(const float* W, bool rev_rows, bool rev_cols, const float* v, int vlen,
                                           bool vrev) {
+        mark(1);
         if constexpr (kMfmaImages == 2) buf ^= 1;
         else __syncthreads();   // single image: every wave must be done reading the previous GEMM's operand
         stage_matrix<K, RBLK, CBLK, ROWS>(img(), W, rev_rows, rev_cols);
         if (v) stage_vector<VBLK>(vec(), v, vlen, vrev);
+        mark(2);
         __syncthreads();
+        mark(3);
     }
 };
 

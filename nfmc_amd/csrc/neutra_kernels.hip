@@ -428,9 +428,20 @@ using namespace nfmc;
         default: { constexpr int HP = 32; CALL; } break; \
     }
 
-extern "C" int64_t nfmc_neutra_scratch_bytes(int64_t n, int32_t d, int32_t n_hidden) {
-    if (n <= 0 || d <= 0 || n_hidden <= 32) return 0;
-    return (4 * n * (int64_t)d + 2 * n) * (int64_t)sizeof(float);
+extern "C" int64_t nfmc_neutra_scratch_bytes(int64_t n, int32_t d, int32_t n_hidden, int32_t n_hidden_layers,
+                                             int32_t n_coupling) {
+    if (n <= 0 || d <= 0 || n_hidden <= 32 || n_hidden_layers <= 0 || n_coupling < 0) return 0;
+    // momentum, gradient, U~ and H0 of every chain, then the activation checkpoints of every resident wave
+    // (mfma_flow.hpp: CkLayout -- hidden activations, alpha, beta of every coupling layer, 1 KB tiles)
+    const int64_t th = nfmc_realnvp_padded_hidden(n_hidden) / 16, td = d / 16;
+    const int64_t layer_floats = ((n_hidden_layers > 1 ? 2 : 1) * th + td) * 256;
+    const int64_t tiles = (n + kMfmaChains - 1) / kMfmaChains;
+    const int64_t slots = tiles < kCkMaxGrid ? tiles : kCkMaxGrid;
+    int64_t floats = 2 * n * (int64_t)d + 2 * n + slots * kMfmaWaves * n_coupling * layer_floats;
+#ifdef NFMC_TRACE
+    floats += 2 * kMfmaWaves * 4096;   // diagnostic build: the mark streams of workgroup 0
+#endif
+    return floats * (int64_t)sizeof(float);
 }
 
 extern "C" int nfmc_neutra_potential_grad_f32(const NfmcRealNVP* flow, const NfmcPotential* pot, const float* z,

@@ -63,22 +63,63 @@ __device__ __forceinline__ float potential_value_grad_c(const f32x4 (&x)[TD], f3
 // Register budget (two waves per SIMD, 256 VGPRs): x, g and at most THREE hidden-width tile sets are live at
 // any point (h_last, the du/dv tiles, dL/dh); with two hidden layers the first layer's activations are not kept
 // across the transposed products but rebuilt where tanh' is needed (+7 % multiply-adds instead of 32 registers).
-template <int TD, int TH, int NHL, bool REV>
+// What the reverse sweep reads back of one layer at its start (requested one GEMM ahead of its use: adjusted_grad_c)
+template <int TD, int TH>
+struct CkTiles {
+    f32x4 al[TD / 2], be[TD / 2], hl[TH];
+};
+template <int TD, int TH, int NHL>
+__device__ __forceinline__ void ck_request(CkTiles<TD, TH>& c, float* ck) {
+    using CL = CkLayout<TD, TH, NHL>;
+#pragma unroll
+    for (int mt = 0; mt < TD / 2; ++mt) {
+        c.al[mt] = *ck_tile(ck, CL::kAlpha + mt);
+        c.be[mt] = *ck_tile(ck, CL::kBeta + mt);
+    }
+#pragma unroll
+    for (int m = 0; m < TH; ++m) c.hl[m] = *ck_tile(ck, CL::kHl + m);
+}
+
+template <int TD, int TH, int NHL, bool REV, bool CK, class Ahead>
 __device__ __forceinline__ void coupling_inverse_backward_c(f32x4 (&x)[TD], f32x4 (&g)[TD], const MLayer& L,
                                                             float mscale, float log1m, WeightPipe& wp, int col,
-                                                            int half) {
+                                                            int half, float* ck, const CkTiles<TD, TH>& kept,
+                                                            Ahead before_last_gemm) {
     constexpr int TS = TD / 2, SRC0 = REV ? TS : 0, TGT0 = REV ? 0 : TS, D2 = 8 * TD, hp = 16 * TH;
+    using CL = CkLayout<TD, TH, NHL>;
     f32x4 hl[TH];   // activations of the LAST hidden layer
-    {
-        f32x4 src[TS], h1[TH];
-#pragma unroll
-        for (int ms = 0; ms < TS; ++ms) src[ms] = x[SRC0 + ms];
-        if constexpr (NHL > 1) hidden_stack<TS, TH, NHL>(src, h1, hl, L, REV, wp, col, half);
-        else hidden_stack<TS, TH, NHL>(src, hl, h1, L, REV, wp, col, half);
-    }
-    // conditioner outputs of every target tile, then the elementwise backward of the affine map
     f32x4 du[TS], dv[TS];
-    {
+    // elementwise backward of the affine map of one target tile, given alpha and beta
+    auto affine_backward = [&](int mt, const f32x4& al, const f32x4& be) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float alpha = al[t];
+            const float ra = __builtin_amdgcn_rcpf(alpha);
+            const float y = x[TGT0 + mt][t];
+            const float gv = g[TGT0 + mt][t] * ra;
+            const float d_alpha = fmaf(-gv, y, ra);
+            du[mt][t] = 0.5f * d_alpha * (alpha - mscale);
+            dv[mt][t] = -0.5f * gv;
+            g[TGT0 + mt][t] = gv;
+            x[TGT0 + mt][t] = fmaf(alpha, y, be[t]);
+        }
+    };
+    if constexpr (CK) {
+        // everything the inverse sweep kept of this layer: no hidden stack, no W3 product
+#pragma unroll
+        for (int mt = 0; mt < TS; ++mt) affine_backward(mt, kept.al[mt], kept.be[mt]);
+#pragma unroll
+        for (int m = 0; m < TH; ++m) hl[m] = kept.hl[m];
+        wp.mark(15);
+    } else {
+        {
+            f32x4 src[TS], h1[TH];
+#pragma unroll
+            for (int ms = 0; ms < TS; ++ms) src[ms] = x[SRC0 + ms];
+            if constexpr (NHL > 1) hidden_stack<TS, TH, NHL>(src, h1, hl, L, REV, wp, col, half);
+            else hidden_stack<TS, TH, NHL>(src, hl, h1, L, REV, wp, col, half);
+        }
+        // conditioner outputs of every target tile, then the elementwise backward of the affine map
         wp.template stage<hp, D2, 1, D2, 2 * D2>(L.W3, REV, false, L.b3, 2 * D2, REV);
         const float* img = wp.img();
         const float* vec = wp.vec();
@@ -91,20 +132,13 @@ __device__ __forceinline__ void coupling_inverse_backward_c(f32x4 (&x)[TD], f32x
             [&](int i) {
                 if ((i & 1) == 0) return;
                 const int mt = i >> 1;
-                const f32x4 ua = ua2[mt & 1], ub = ub2[mt & 1];
+                f32x4 al, be;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    const float alpha = fast_exp(fmaf(0.5f, ua[t], log1m)) + mscale;
-                    const float beta = 0.5f * ub[t];
-                    const float ra = __builtin_amdgcn_rcpf(alpha);
-                    const float y = x[TGT0 + mt][t];
-                    const float gv = g[TGT0 + mt][t] * ra;
-                    const float d_alpha = fmaf(-gv, y, ra);
-                    du[mt][t] = 0.5f * d_alpha * (alpha - mscale);
-                    dv[mt][t] = -0.5f * gv;
-                    g[TGT0 + mt][t] = gv;
-                    x[TGT0 + mt][t] = fmaf(alpha, y, beta);
+                    al[t] = fast_exp(fmaf(0.5f, ua2[mt & 1][t], log1m)) + mscale;
+                    be[t] = 0.5f * ub2[mt & 1][t];
                 }
+                affine_backward(mt, al, be);
             });
     }
     // dL/dh_last = W3^T [du; dv], through tanh of the last hidden layer (its activations die here)
@@ -132,6 +166,11 @@ __device__ __forceinline__ void coupling_inverse_backward_c(f32x4 (&x)[TD], f32x
             });
     }
     if constexpr (NHL > 1) {
+        f32x4 h1k[CK ? TH : 1];   // checkpointed first-layer activations: requested before the GEMM that hides the latency
+        if constexpr (CK) {
+#pragma unroll
+            for (int mo = 0; mo < TH; ++mo) h1k[mo] = *ck_tile(ck, CL::kH1 + mo);
+        }
         // dL/dh1 = Wh^T dpre2 ...
         {
             wp.template stage<hp, 1, 1, 1, hp>(L.WhT, false, false, nullptr, 0, false);
@@ -145,8 +184,14 @@ __device__ __forceinline__ void coupling_inverse_backward_c(f32x4 (&x)[TD], f32x
                                [&](int) -> const f32x4(&)[TH] { return dh; },
                                [&](int) {});
         }
-        // ... times tanh'(pre1), with h1 = tanh(W1 src + b1) rebuilt one tile at a time
-        {
+        // ... times tanh'(pre1): h1 from the checkpoint, or rebuilt (h1 = tanh(W1 src + b1)) one tile at a time
+        if constexpr (CK) {
+#pragma unroll
+            for (int mo = 0; mo < TH; ++mo) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) dh[mo][t] = hl[mo][t] * (1.f - h1k[mo][t] * h1k[mo][t]);
+            }
+        } else {
             wp.template stage<D2, 1, D2, 1, hp>(L.W1, false, REV, L.b1, hp, false);
             const float* img = wp.img();
             const float* vec = wp.vec();
@@ -165,6 +210,7 @@ __device__ __forceinline__ void coupling_inverse_backward_c(f32x4 (&x)[TD], f32x
                                });
         }
     }
+    before_last_gemm();
     wp.template stage<hp, D2, 1, 1, D2>(L.W1T, REV, false, nullptr, 0, false);
     const float* img = wp.img();
     gemm_phase<TH, TS>([&](int ms) { return img + (16 * ms + col) * (hp + 4) + 4 * half; }, [&](int) {},
@@ -174,39 +220,86 @@ __device__ __forceinline__ void coupling_inverse_backward_c(f32x4 (&x)[TD], f32x
 
 // ---- U~(z), grad U~(z) for the wave's 16 chains.  x: in z (tile positions in latent order), out z again
 // (rebuilt through the inverse of every step); g: gradient in the same positions.  Workgroup-collective.
-template <int TD, int TH, int NHL>
+// CK: the inverse sweep leaves every layer's activations in the wave's checkpoint area `ck` (mfma_flow.hpp: CkLayout)
+// and the reverse sweep reads them back; without, the reverse sweep recomputes them (no scratch needed).
+template <int TD, int TH, int NHL, bool CK = false, bool EAC = false>
 __device__ __forceinline__ float adjusted_grad_c(f32x4 (&x)[TD], f32x4 (&g)[TD], const NfmcRealNVP& f,
-                                                 const NfmcPotential& pot, WeightPipe& wp, int col, int half, int lane) {
+                                                 const NfmcPotential& pot, WeightPipe& wp, int col, int half, int lane,
+                                                 float* ck = nullptr, const float* eac = nullptr) {
     constexpr int d = 16 * TD, hp = 16 * TH;
+    using CL = CkLayout<TD, TH, NHL>;
     const bool rev_last = (f.n_coupling & 1) != 0;
     const float log1m = __logf(1.f - f.min_scale);
-    float ldp = flow_inverse_sweep_c<TD, TH, NHL>(x, f, wp, col, half);
+    wp.mark(10);
+    float ldp = flow_inverse_sweep_c<TD, TH, NHL, CK, EAC>(x, f, wp, col, half, ck, eac);
+    wp.mark(11);
+    // the first layer of the reverse sweep is the one the inverse sweep finished with: its tiles are requested before
+    // the potential so that the latency hides behind it
+    CkTiles<TD, TH> kept;
+#ifdef NFMC_T_EARLY
+    if constexpr (CK) {
+        if (f.n_coupling > 0) ck_request<TD, TH, NHL>(kept, ck);
+    }
+#endif
     const float u = potential_value_grad_c<TD>(x, g, pot, half, lane);
     // reverse sweep
 #pragma unroll
     for (int m = 0; m < TD; ++m) {
-        const f32x4 ls = vec_tile(f.ea0_log_scale, m, half), sh = vec_tile(f.ea0_shift, m, half);
+        f32x4 ls, sh, e, ei;
+        ea_tile<EAC>(ls, e, sh, eac, EaPlanes::kLs0, EaPlanes::kE0, EaPlanes::kSh0, f.ea0_log_scale, f.ea0_shift, m, half, d, false, 1.f);
+        if constexpr (EAC) ei = vec_tile(eac + EaPlanes::kEi0 * EaPlanes::kStride, m, half);
+        else
+#pragma unroll
+            for (int t = 0; t < 4; ++t) ei[t] = fast_exp(-ls[t]);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            g[m][t] *= fast_exp(-ls[t]);
-            x[m][t] = fmaf(fast_exp(ls[t]), x[m][t], sh[t]);
+            g[m][t] *= ei[t];
+            x[m][t] = fmaf(e[t], x[m][t], sh[t]);
         }
     }
     for (int l = 0; l < f.n_coupling; ++l) {
         const MLayer L = mfma_layer(f.weights + l * f.layer_stride, d, hp, NHL);
-        if ((l & 1) == 0) coupling_inverse_backward_c<TD, TH, NHL, true>(x, g, L, f.min_scale, log1m, wp, col, half);
-        else coupling_inverse_backward_c<TD, TH, NHL, false>(x, g, L, f.min_scale, log1m, wp, col, half);
+        float* ckl = CK ? ck + (size_t)l * CL::kLayerFloats : nullptr;
+        CkTiles<TD, TH> next;
+        // the next layer's tiles are requested before this layer's last GEMM (x, g, one hidden-width tile set and the
+        // fragments are live there: room for them)
+        auto ahead = [&]() {
+            if constexpr (CK) {
+#ifdef NFMC_T_AHEAD
+                if (l + 1 < f.n_coupling) ck_request<TD, TH, NHL>(next, ckl + CL::kLayerFloats);
+#endif
+            }
+        };
+#ifndef NFMC_T_AHEAD
+#ifndef NFMC_T_EARLY
+        if constexpr (CK) { ck_request<TD, TH, NHL>(kept, ckl); }
+#else
+        if constexpr (CK) { if (l > 0) ck_request<TD, TH, NHL>(kept, ckl); }
+#endif
+#endif
+        if ((l & 1) == 0) coupling_inverse_backward_c<TD, TH, NHL, true, CK>(x, g, L, f.min_scale, log1m, wp, col, half, ckl, kept, ahead);
+        else coupling_inverse_backward_c<TD, TH, NHL, false, CK>(x, g, L, f.min_scale, log1m, wp, col, half, ckl, kept, ahead);
+#ifdef NFMC_T_AHEAD
+        if constexpr (CK) {
+            if (l + 1 < f.n_coupling) kept = next;
+        }
+#endif
     }
 #pragma unroll
     for (int m = 0; m < TD; ++m) {
-        const f32x4 ls = rev_last ? vec_tile_rev(f.ea1_log_scale, m, half, d) : vec_tile(f.ea1_log_scale, m, half);
-        const f32x4 sh = rev_last ? vec_tile_rev(f.ea1_shift, m, half, d) : vec_tile(f.ea1_shift, m, half);
+        f32x4 ls, sh, e, ei;
+        ea_tile<EAC>(ls, e, sh, eac, EaPlanes::kLs1, EaPlanes::kE1, EaPlanes::kSh1, f.ea1_log_scale, f.ea1_shift, m, half, d, rev_last, 1.f);
+        if constexpr (EAC) ei = vec_tile(eac + EaPlanes::kEi1 * EaPlanes::kStride, m, half);
+        else
+#pragma unroll
+            for (int t = 0; t < 4; ++t) ei[t] = fast_exp(-ls[t]);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            g[m][t] *= fast_exp(-ls[t]);
-            x[m][t] = fmaf(fast_exp(ls[t]), x[m][t], sh[t]);
+            g[m][t] *= ei[t];
+            x[m][t] = fmaf(e[t], x[m][t], sh[t]);
         }
     }
+    wp.mark(12);
     return u - chain_sum(ldp);
 }
 
@@ -239,22 +332,16 @@ __global__ void __launch_bounds__(kMfmaBlock, 2) neutra_grad_mfma_kernel(NfmcRea
 struct LeapArgs {
     NfmcNeutraHmcArgs a;
     float *p, *gz, *uz, *h0;  // scratch: momentum; gradient and U~ at the current state; H0
+    float* ck;                 // scratch: activation checkpoints, one area per (workgroup slot, wave) -- mfma_flow.hpp: CkLayout
     int step;                  // transition index within this call
     float* sample_row;         // store row this transition is kept in (NfmcSampleStore walked on the host), or NULL
 };
 
-// mass / momentum helpers in C layout: tile position pos <-> logical latent coordinate (rev ? d-1-pos : pos)
-template <int TD>
-__device__ __forceinline__ void mass_tiles(f32x4 (&m)[TD], const float* imd, int half, bool rev) {
-    constexpr int d = 16 * TD;
-#pragma unroll
-    for (int k = 0; k < TD; ++k) {
-        if (imd) m[k] = rev ? vec_tile_rev(imd, k, half, d) : vec_tile(imd, k, half);
-        else
-#pragma unroll
-            for (int t = 0; t < 4; ++t) m[k][t] = 1.f;
-    }
-}
+#ifndef NFMC_T_EAC
+#define NFMC_T_EAC true
+#endif
+// LDS of the trajectory kernel: the matrix-core carve-up (mfma_device.hpp), then the EaPlanes constants
+constexpr size_t kLeapLdsBytes = kMfmaLdsBytes + EaPlanes::kFloats * sizeof(float);
 
 template <int TD, int TH, int NHL>
 __global__ void __launch_bounds__(kMfmaBlock, 2) neutra_leapfrog_mfma_kernel(LeapArgs A, int64_t tiles, int dp) {
@@ -270,11 +357,21 @@ __global__ void __launch_bounds__(kMfmaBlock, 2) neutra_leapfrog_mfma_kernel(Lea
 
     // statistics accumulate in LDS behind the weight images (nothing extra stays live across the GEMMs)
     double* red = reinterpret_cast<double*>(lds + kMfmaStatOffset);  // [8 waves][2*d + 2]
+    float* const eac = lds + kMfmaLdsBytes / sizeof(float);          // EaPlanes: elementwise-affine constants, mass diagonal
+    const float* const massp = eac + EaPlanes::kMass * EaPlanes::kStride;
     WeightPipe wp{lds, 0};
     uint32_t n_acc = 0, n_bad = 0;
+    float* const ck = A.ck + ((size_t)blockIdx.x * kMfmaWaves + __builtin_amdgcn_readfirstlane(wave)) * a.flow.n_coupling *
+                                 CkLayout<TD, TH, NHL>::kLayerFloats + 4 * lane;
     for (int i = threadIdx.x; i < kMfmaWaves * (2 * d + 2); i += kMfmaBlock) red[i] = 0.0;
+    ea_planes_fill(eac, a.flow, a.inv_mass_diag, d);
     __syncthreads();
     const int L = a.n_leapfrog;
+#ifdef NFMC_TRACE
+    if (blockIdx.x == 0)
+        wp.tr = reinterpret_cast<unsigned long long*>(A.ck + (size_t)gridDim.x * kMfmaWaves * a.flow.n_coupling *
+                                                                 CkLayout<TD, TH, NHL>::kLayerFloats) + wave * 4096;
+#endif
 
     for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         const int64_t row_t = tile * kMfmaChains + wave * 16 + col;
@@ -282,58 +379,54 @@ __global__ void __launch_bounds__(kMfmaBlock, 2) neutra_leapfrog_mfma_kernel(Lea
         const int64_t rrow_t = active ? row_t : n - 1;
         f32x4 x[TD], g[TD];
         float u = 0.f;
-        for (int l = 0; l < L; ++l) {
-        {
-            // per-step opaque copies of the row index: the HBM addresses below are loop invariant and would
-            // otherwise be hoisted out of the leapfrog loop and held through every gradient
+        {   // ---- start of the trajectory: momentum draw, H0, the first half step (hmc.py:100-106, 68-70)
             int64_t row_in = row_t, rrow_in = rrow_t;
             asm volatile("" : "+v"(row_in), "+v"(rrow_in));
-            f32x4 p[TD], mass[TD];
-            mass_tiles<TD>(mass, a.inv_mass_diag, half, rev);
-            if (l == 0) {
-                load_ctiles<TD>(x, a.z, rrow_in, d, half, rev);
-                load_ctiles<TD>(g, A.gz, rrow_in, d, half, rev);
-                float kin = 0.f;
-                const uint32_t gchain = (uint32_t)(a.rng.chain_offset + (uint64_t)rrow_in);
+            f32x4 p[TD];
+            load_ctiles<TD>(x, a.z, rrow_in, d, half, rev);
+            load_ctiles<TD>(g, A.gz, rrow_in, d, half, rev);
+            float kin = 0.f;
+            const uint32_t gchain = (uint32_t)(a.rng.chain_offset + (uint64_t)rrow_in);
 #pragma unroll
-                for (int m = 0; m < TD; ++m) {
-                    const int p0 = 16 * m + 4 * half;  // tile position of this lane's 4-block (= one Philox block)
-                    float zz[4];
-                    if (a.rng.replay_normals) {
-                        const float* src = a.rng.replay_normals + ((int64_t)s * n + rrow_in) * d;
+            for (int m = 0; m < TD; ++m) {
+                const int p0 = 16 * m + 4 * half;  // tile position of this lane's 4-block (= one Philox block)
+                float zz[4];
+                if (a.rng.replay_normals) {
+                    const float* src = a.rng.replay_normals + ((int64_t)s * n + rrow_in) * d;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) zz[j] = src[rev ? d - 1 - (p0 + j) : p0 + j];
-                    } else {
-                        const int blk = rev ? (d - 4 - p0) >> 2 : p0 >> 2;
-                        float w[4];
-                        philox_normal4(gchain, a.rng.step0 + (uint32_t)s, (uint32_t)blk, kTagNoise, (uint32_t)a.rng.seed,
-                                       (uint32_t)(a.rng.seed >> 32), w);
+                    for (int j = 0; j < 4; ++j) zz[j] = src[rev ? d - 1 - (p0 + j) : p0 + j];
+                } else {
+                    const int blk = rev ? (d - 4 - p0) >> 2 : p0 >> 2;
+                    float w[4];
+                    philox_normal4(gchain, a.rng.step0 + (uint32_t)s, (uint32_t)blk, kTagNoise, (uint32_t)a.rng.seed,
+                                   (uint32_t)(a.rng.seed >> 32), w);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) zz[j] = rev ? w[3 - j] : w[j];
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float mm = mass[m][j];
-                        const float v = zz[j] * (1.f / sqrtf(mm));   // hmc.py:100
-                        p[m][j] = v;
-                        kin = fmaf(v * v, mm, kin);
-                    }
+                    for (int j = 0; j < 4; ++j) zz[j] = rev ? w[3 - j] : w[j];
                 }
-                kin = chain_sum(kin);
-                if (active && half == 0) A.h0[row_in] = A.uz[row_in] + 0.5f * kin;  // hmc.py:103-106
-            } else {   // position and gradient tiles are still in registers from the previous step
-                load_ctiles<TD>(p, A.p, rrow_in, d, half, rev);
-            }
+                const f32x4 mass = vec_tile(massp, m, half);
 #pragma unroll
-            for (int m = 0; m < TD; ++m)
+                for (int j = 0; j < 4; ++j) {
+                    const float mm = mass[j];
+                    const float v = zz[j] * (1.f / sqrtf(mm));   // hmc.py:100
+                    p[m][j] = v;
+                    kin = fmaf(v * v, mm, kin);
+                }
+            }
+            kin = chain_sum(kin);
+            if (active && half == 0) A.h0[row_in] = A.uz[row_in] + 0.5f * kin;  // hmc.py:103-106
+#pragma unroll
+            for (int m = 0; m < TD; ++m) {
+                const f32x4 mass = vec_tile(massp, m, half);
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {  // hmc.py:68-70
                     p[m][t] = fmaf(-hh, g[m][t], p[m][t]);
-                    x[m][t] = fmaf(h, p[m][t] * mass[m][t], x[m][t]);
+                    x[m][t] = fmaf(h, p[m][t] * mass[t], x[m][t]);
                 }
+            }
             if (active) store_ctiles<TD>(p, A.p, row_in, d, half, rev);  // momentum is not live across the GEMMs
         }
-        u = adjusted_grad_c<TD, TH, NHL>(x, g, a.flow, a.pot, wp, col, half, lane);
+        for (int l = 0; l < L; ++l) {
+        u = adjusted_grad_c<TD, TH, NHL, true, NFMC_T_EAC>(x, g, a.flow, a.pot, wp, col, half, lane, ck, eac);
         // everything below addresses HBM by the row index: an opaque copy keeps that address arithmetic from
         // being computed before the gradient and held in registers through it (cf. stage_matrix)
         int64_t row = row_t, rrow = rrow_t;
@@ -345,20 +438,32 @@ __global__ void __launch_bounds__(kMfmaBlock, 2) neutra_leapfrog_mfma_kernel(Lea
 #pragma unroll
             for (int t = 0; t < 4; ++t) p[m][t] = fmaf(-hh, g[m][t], p[m][t]);  // hmc.py:71
         if (l + 1 < L) {
+            // the next step's first half (hmc.py:68-70) on the momentum just loaded: ONE load and ONE store of the momentum
+            // tile per leapfrog step and no store -> load round trip between the two half steps (same fmas, same order)
+#pragma unroll
+            for (int m = 0; m < TD; ++m) {
+                const f32x4 mass = vec_tile(massp, m, half);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    p[m][t] = fmaf(-hh, g[m][t], p[m][t]);
+                    x[m][t] = fmaf(h, p[m][t] * mass[t], x[m][t]);
+                }
+            }
             if (active) store_ctiles<TD>(p, A.p, row, d, half, rev);
             continue;
         }
         // ---- end of the trajectory: Hamiltonian test, masked update, statistics
+        wp.mark(20);
         bool accept = true;
         float lr = 0.f;
         if (a.adjust) {
             float kin = 0.f;
-            f32x4 mass[TD];
-            mass_tiles<TD>(mass, a.inv_mass_diag, half, rev);
 #pragma unroll
-            for (int m = 0; m < TD; ++m)
+            for (int m = 0; m < TD; ++m) {
+                const f32x4 mass = vec_tile(massp, m, half);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) kin = fmaf(p[m][t] * p[m][t], mass[m][t], kin);
+                for (int t = 0; t < 4; ++t) kin = fmaf(p[m][t] * p[m][t], mass[t], kin);
+            }
             kin = chain_sum(kin);
             lr = A.h0[rrow] - (u + 0.5f * kin);  // hmc.py:107-111
             float uni;
@@ -463,13 +568,14 @@ static int run_hmc(const NfmcNeutraHmcArgs& a, float* scratch, hipStream_t st) {
     A.gz = A.p + n * d;
     A.uz = A.gz + n * d;
     A.h0 = A.uz + n;
+    A.ck = A.h0 + n;
     int rc = launch_grad<TD, TH, NHL>(a.flow, a.pot, a.z, n, A.uz, A.gz, st);
     if (rc) return rc;
     const int64_t tiles = (n + kMfmaChains - 1) / kMfmaChains;
-    const int grid = (int)(tiles < kMaxGrid ? tiles : kMaxGrid);
+    const int grid = (int)(tiles < kCkMaxGrid ? tiles : kCkMaxGrid);   // one checkpoint area per workgroup slot
     const int dp = padded_d(d);
     auto kern = neutra_leapfrog_mfma_kernel<TD, TH, NHL>;
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMfmaLdsBytes);
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLeapLdsBytes);
     if (e != hipSuccess) return (int)e;
     int countdown = a.samples.countdown, srow = a.samples.row;   // one launch per transition: the store cursor runs here
     for (int s = 0; s < a.n_steps; ++s) {
@@ -484,7 +590,7 @@ static int run_hmc(const NfmcNeutraHmcArgs& a, float* scratch, hipStream_t st) {
                 countdown = a.samples.stride - 1;
             }
         }
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kMfmaBlock), kMfmaLdsBytes, st, A, tiles, dp);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kMfmaBlock), kLeapLdsBytes, st, A, tiles, dp);
         if (a.stats.sum_x) {
             hipLaunchKernelGGL(stats_finish_kernel<true>, dim3(stats_finish_grid(dp)), dim3(kFinishBlock), 0, st,
                                a.stats.scratch, grid, dp, d, a.stats, (unsigned long long)n);
@@ -531,7 +637,8 @@ int nfmc::nfmc_neutra_hmc_steps_mfma_f32(const NfmcNeutraHmcArgs* args, float* s
     if (!args || !scratch) return NFMC_EINVAL;
     const NfmcNeutraHmcArgs& a = *args;
     if (!nfmc_mfma_supported(a.flow.d, a.flow.n_hidden, a.flow.n_hidden_layers)) return NFMC_EUNSUPPORTED;
-    if (scratch_bytes < nfmc_neutra_scratch_bytes(a.n, a.flow.d, a.flow.n_hidden)) return NFMC_ESCRATCH;
+    if (scratch_bytes < nfmc_neutra_scratch_bytes(a.n, a.flow.d, a.flow.n_hidden, a.flow.n_hidden_layers, a.flow.n_coupling))
+        return NFMC_ESCRATCH;
     const int td = a.flow.d / 16, th = nfmc_realnvp_padded_hidden(a.flow.n_hidden) / 16, nhl = a.flow.n_hidden_layers;
     int rc = 0;
     NFMC_MFMA_DISPATCH(td, th, nhl, rc = (run_hmc<TD, TH, NHL>(a, scratch, (hipStream_t)stream)))

@@ -123,7 +123,7 @@ SYMBOLS = [
     ('nfmc_imh_parallel_supported_f32', C.c_int, [C.POINTER(NfmcFlowMhArgs)]),
     ('nfmc_imh_parallel_work_bytes', C.c_int64, [C.c_int64, C.c_int32, C.c_int32]),
     ('nfmc_imh_parallel_f32', C.c_int, [C.POINTER(NfmcFlowMhArgs), c_fp, C.c_int64, c_fp]),
-    ('nfmc_neutra_scratch_bytes', C.c_int64, [C.c_int64, C.c_int32, C.c_int32]),
+    ('nfmc_neutra_scratch_bytes', C.c_int64, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     ('nfmc_neutra_hmc_steps_f32', C.c_int, [C.POINTER(NfmcNeutraHmcArgs), c_fp]),
     ('nfmc_neutra_potential_grad_f32', C.c_int, [C.POINTER(NfmcRealNVP), C.POINTER(NfmcPotential), c_fp, C.c_int64,
                                                  c_fp, c_fp, c_fp]),

@@ -4,7 +4,7 @@
 for lib in "$@"; do
   echo "== $lib"
   NFMC_LIB=$PWD/$lib timeout -k 10 400 python -m pytest tests -x -q -m gpu -k "C4 or mfma or matrix_cores" 2>&1 | tail -1
-  for rep in 1 2; do
+  for rep in $(seq 1 ${AB_REPS:-2}); do
     NFMC_LIB=$PWD/$lib timeout -k 10 200 python bench.py --config C4 --no-cpu-baseline --steps 10 --reps 5 2>/dev/null | python3 -c "
 import json,sys
 l=json.loads(sys.stdin.read()); r=l['roofline']
