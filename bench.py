@@ -38,7 +38,7 @@ VALU issue (Philox4x32-10 + Box-Muller + the MALA arithmetic).  So:
   hbm_real_frac     PMC-measured HBM bytes per launch / launch time / 8 TB/s
   flops_algorithmic SURVEY 8d's 30*d flop per MALA transition vs the 157.3 TFLOP/s vector peak
 C4's dominant kernel (`neutra_leapfrog_mfma_kernel`) is bound by fp32 MFMA: achieved TFLOP/s of conditioner GEMMs
-(sustained: measured over the whole timed region) vs 157.3.
+(sustained: measured over the whole timed region; flops = the algorithm's minimum, C4_MACS_PER_GRADIENT) vs 157.3.
 
 parity.  moments / acceptance of the timed run vs the analytic N(0, I/2), and -- north_star's "vs the CPU path on
 the same seeds" -- a leg that runs ONE outer iteration of the first 8192 chains on the GPU and through the CPU
@@ -88,7 +88,12 @@ CONFIGS = {
                         'K=5 HMC trajectories of L=20 (h=0.05) per jump',
                metric='chain-steps/sec (n_chains x iters / s), jump_hmc + RealNVP, d=256'),
 }
-C4_MACS_PER_GRADIENT = 245760     # per chain: 2 couplings x (forward 3 GEMMs + reverse sweep) at d=128, H=128 x 2
+# per chain and gradient of the adjusted potential: 2 couplings x (the conditioner's 3 GEMMs of the inverse sweep, 40960
+# multiply-adds at d = 128, H = 128 x 2, + their 3 transposed products in the reverse sweep).  This is the minimum the
+# algorithm needs (SURVEY 8d's 'RealNVP pass' formula, backward with respect to the input = one more pass) and, since
+# the reverse sweep reads its activations back from checkpoints, also what the kernel executes (round 1 recomputed the
+# activations: 262144 executed against 245760 counted).
+C4_MACS_PER_GRADIENT = 163840
 PARITY_ROWS = 8192
 PMC_STEPS = 3                     # --steps of the PMC passes in tools/profile_bench.sh
 

@@ -50,6 +50,16 @@ constexpr int kMfmaWaves = NFMC_MFMA_WAVES;
 constexpr int kMfmaImages = NFMC_MFMA_IMAGES;
 constexpr int kMfmaBlock = 64 * kMfmaWaves;
 constexpr int kMfmaChains = 16 * kMfmaWaves;     // chains per workgroup
+// Threads that stage weight images.  Of the two waves of a SIMD the OLDER (waves 0..3 of an 8-wave workgroup) wins the
+// issue arbitration, finishes every GEMM phase first and then waits for its partner (timeline: tools/trace_c4.py: at the
+// C4 shape the old wave needs ~14.5k cycles for a 256-MFMA phase, the young one ~21.7k, the last third of it alone on
+// the SIMD).  So the whole copy belongs to the old waves -- it runs under the partner's MFMAs -- and the young waves
+// go from their last MFMA straight to the barrier: C4 2.66 -> 2.47 ms per trajectory.  -DNFMC_STAGE_ALL: every wave copies.
+#if defined(NFMC_STAGE_ALL) || NFMC_MFMA_WAVES != 8
+constexpr int kStageThreads = kMfmaBlock;
+#else
+constexpr int kStageThreads = kMfmaBlock / 2;
+#endif
 constexpr int kCkMaxGrid = 512;                  // workgroup slots of the NeuTra trajectory kernel (2 per CU); more chain tiles grid-stride
 
 struct MLayer {
@@ -90,14 +100,18 @@ __device__ __forceinline__ void stage_matrix(float* __restrict__ img, const floa
                                              bool rev_cols) {
     constexpr int ld = K + 4, k4 = K >> 2, N = ROWS * k4;
     static_assert((K & (K - 1)) == 0 && (RBLK & (RBLK - 1)) == 0 && (CBLK & (CBLK - 1)) == 0, "power-of-two extents");
-    static_assert(N % kMfmaBlock == 0, "whole passes of the workgroup");
-    constexpr int IT = N / kMfmaBlock;            // 128-bit pieces per thread: 8 for a 128 x 128 matrix and 512 threads
+    constexpr int kStagers = kStageThreads;       // threads that copy (see kStageThreads)
+    static_assert(N % kStagers == 0, "whole passes of the staging threads");
+    constexpr int IT = N / kStagers;              // 128-bit pieces per thread: 8 for a 128 x 128 matrix and 512 threads
     constexpr int BATCH = IT < NFMC_STAGE_BATCH ? IT : NFMC_STAGE_BATCH;   // loads in flight per thread (4 registers each)
     // The copy addresses depend only on the thread index, so LICM would hoist the address arithmetic of EVERY
     // staging call of the kernel above the tile loop and keep hundreds of VGPRs live through all the GEMMs
     // (measured: ~2 KB of scratch per lane).  An opaque copy of the index pins the arithmetic to the call.
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
+    if constexpr (kStagers < kMfmaBlock) {
+        if (__builtin_amdgcn_readfirstlane(tid) >= kStagers) return;
+    }
 #ifdef NFMC_X_NO_STAGE
     if (tid >= 0) return;   // ablation: no global -> LDS copy (barriers stay)
 #endif
@@ -110,12 +124,12 @@ __device__ __forceinline__ void stage_matrix(float* __restrict__ img, const floa
         f32x4 v[BATCH];
 #pragma unroll
         for (int b = 0; b < BATCH; ++b) {
-            const int idx = tid + (b0 + b) * kMfmaBlock;
+            const int idx = tid + (b0 + b) * kStagers;
             v[b] = *reinterpret_cast<const f32x4*>(W + (size_t)(idx / k4) * K + ((idx % k4) << 2));
         }
 #pragma unroll
         for (int b = 0; b < BATCH; ++b) {
-            const int idx = tid + (b0 + b) * kMfmaBlock;
+            const int idx = tid + (b0 + b) * kStagers;
             const int r = idx / k4, c = (idx % k4) << 2;
             const int rr = rev_rows ? (r / RBLK) * RBLK + (RBLK - 1 - (r % RBLK)) : r;
             if (!rev_cols) {
@@ -251,6 +265,34 @@ __device__ __forceinline__ void gemm_phase(Row row, Init init, Acc acc, Act act,
     // shorter look-ahead (16 MFMAs = 512 cycles still cover an LDS read).
     constexpr int CH = TK < NFMC_FRAG_CHUNK ? TK : NFMC_FRAG_CHUNK;
     static_assert(TK % CH == 0, "whole chunks");
+#ifdef NFMC_FRAG_PREFETCH
+    // Software pipeline over chunks: the reads of chunk k + 1 (and, when it opens a step, that step's init = its bias
+    // read) are issued BEFORE the MFMAs of chunk k, into the other fragment set.  init(i + 1) therefore runs before
+    // fin(i): callers double-buffer whatever both touch.  Same register count as one un-chunked tile (2 x 4 x CH).
+    {
+        constexpr int NCH = TK / CH;
+        f32x4 a[2][CH];
+        init(0);
+        frag_load<CH>(a[0], row(0));
+#pragma unroll
+        for (int k = 0; k < NSTEP * NCH; ++k) {
+            const int i = k / NCH, c0 = (k % NCH) * CH;
+            if (k + 1 < NSTEP * NCH) {
+                const int i1 = (k + 1) / NCH, c1 = ((k + 1) % NCH) * CH;
+                if (c1 == 0) init(i1);
+                frag_load<CH>(a[(k + 1) & 1], row(i1) + 16 * c1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mk = 0; mk < CH; ++mk)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    acc(i) = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k & 1][mk][r], act(i)[c0 + mk][r], acc(i), 0, 0, 0);
+            if (c0 + CH == TK) fin(i);
+        }
+        return;
+    }
+#endif
 #pragma unroll
     for (int i = 0; i < NSTEP; ++i) {   // one step at a time: reads, then MFMAs, then epilogue
         init(i);

@@ -185,6 +185,35 @@ def test_C4_neutra_hmc_65536x128_full_size_properties(dev):
     assert torch.equal(part.running_samples.last_sample, la[lo:hi])
 
 
+def test_C4_more_chain_tiles_than_workgroup_slots(dev):
+    """The trajectory kernel runs at most 512 workgroups (one activation-checkpoint area per workgroup slot and wave,
+    mfma_flow.hpp: CkLayout); with more than 512 x 128 chains a workgroup walks several chain tiles and reuses its
+    area.  70000 chains = 547 tiles: every chain must end where the same chain ends in a run that holds only its own
+    128-chain tile neighbourhood (chain-id keyed noise), bit for bit, and the counters must cover all chains."""
+    from nfmc_amd.dist import Shard
+    d, n, T, L, h = 128, 70000, 1, 10, 0.02
+    torch.manual_seed(11)
+    _of, f = _pair_flows(d, 13, 0.08, ck={'n_hidden': 128, 'n_layers': 2})
+    z0 = 0.5 * torch.randn(n, d, generator=torch.Generator().manual_seed(6))
+
+    def run(shard=None):
+        s = _c4_sampler(f, T, L, h)
+        _no_split(s)
+        s.params.store_samples = False
+        s.seed = 21
+        s.shard = shard
+        return s.sample(z0, show_progress=False)
+
+    full = run()
+    la = full.running_samples.last_sample
+    assert torch.isfinite(la).all() and full.statistics.n_attempted_trajectories == n * T
+    for rank in (0, 7):      # the first tiles and the tiles past the 512th
+        sh = Shard(rank=rank, world=8)
+        sh.merge_statistics = lambda s_: s_
+        lo, hi = sh.bounds(n)
+        assert torch.equal(run(sh).running_samples.last_sample, la[lo:hi])
+
+
 # ================================================================================================ C5
 def test_C5_jump_hmc_d256_k5_L20_matches_oracle(dev):
     """configs[4] at n = 100: jump_hmc, U = sum x^2, d = 256, K = 5 inner HMC trajectories (sample.py:161-162) of
