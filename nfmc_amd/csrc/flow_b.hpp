@@ -341,6 +341,128 @@ struct FlowB {
         }
     }
 
+    // ---- TWO chains per lane group (exact-fit, distributed hidden stack only): the same lanes carry the same
+    // coordinates of chains A and B, so every weight row read from LDS feeds both.  At d = 256 a coupling layer reads
+    // 14 KB of image per chain and the CU's 128 B/clk of LDS bandwidth, not VALU issue, bounded the one-chain kernel
+    // (C5 jump: ~30 us of LDS reads next to ~27 us of VALU issue); sharing the rows halves the reads at no extra
+    // instruction.  Per chain the arithmetic is the one-chain code's, operation for operation (bitwise equal results).
+    template <bool INVERSE, bool REV>
+    __device__ __forceinline__ void coupling2_impl(float (&xa)[CPL], float (&xb)[CPL], int l, float& lda, float& ldb) const {
+        static_assert(EXACT && Img::DIST, "two-chain evaluator: exact-fit layouts with a distributed hidden stack");
+        constexpr int S0 = REV ? CPL / 2 : 0, S1 = S0 + CPL / 2;
+        constexpr int T0 = REV ? 0 : CPL / 2, T1 = T0 + CPL / 2;
+        const float* W1 = img + l * lf + g * HP;
+        const float* b1 = img + l * lf + Img::ROWS * HP;
+        float ha[HP], hb[HP];
+        {
+            f2 pa[HP / 2], pb[HP / 2];
+#pragma unroll
+            for (int k = 0; k < HP / 2; ++k) pa[k] = pb[k] = (f2){0.f, 0.f};
+#pragma unroll
+            for (int i = S0; i < S1; ++i) {
+                float w[HP];
+                load_row16<HP>(w, W1 + (i - S0) * LPC * HP);
+#pragma unroll
+                for (int k = 0; k < HP / 2; ++k) {
+                    pa[k] = pk_fma((f2){w[2 * k], w[2 * k + 1]}, xa[i], pa[k]);
+                    pb[k] = pk_fma((f2){w[2 * k], w[2 * k + 1]}, xb[i], pb[k]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < HP / 2; ++k) {
+                ha[2 * k] = pa[k].x;
+                ha[2 * k + 1] = pa[k].y;
+                hb[2 * k] = pb[k].x;
+                hb[2 * k + 1] = pb[k].y;
+            }
+        }
+        {
+            const int ub = g & (HP - 1);
+            const float bias = b1[ub];
+            float va = fast_tanh(group_reduce_scatter<HP, LPC>(ha) + bias);
+            float vb = fast_tanh(group_reduce_scatter<HP, LPC>(hb) + bias);
+            group_all_gather<HP>(va, ha);
+            group_all_gather<HP>(vb, hb);
+            const float* Wh = b1 + HP + ub * Img::HROW;
+            for (int hl = 1; hl < n_hl; ++hl) {
+                float wr[Img::HROW];
+                load_row16<Img::HROW>(wr, Wh);
+                float ta = wr[HP], tb = wr[HP];
+#pragma unroll
+                for (int k = 0; k < HP; ++k) {
+                    ta = fmaf(wr[k], ha[k], ta);
+                    tb = fmaf(wr[k], hb[k], tb);
+                }
+                va = fast_tanh(ta);
+                vb = fast_tanh(tb);
+                group_all_gather<HP>(va, ha);
+                group_all_gather<HP>(vb, hb);
+                Wh += Img::HL;
+            }
+        }
+        const float* W3 = img + l * lf + Img::ROWS * HP + Img::mid_floats(n_hl) + g * Img::RS;
+        float sa = 0.f, sb = 0.f;
+#pragma unroll
+        for (int i = T0; i < T1; ++i) {
+            float w[Img::RS];
+            load_row16<Img::RS>(w, W3 + (i - T0) * LPC * Img::RS);
+            f2 ua = {w[2 * HP], w[2 * HP + 1]}, ub = ua;
+#pragma unroll
+            for (int k = 0; k < HP; ++k) {
+                ua = pk_fma((f2){w[2 * k], w[2 * k + 1]}, ha[k], ua);
+                ub = pk_fma((f2){w[2 * k], w[2 * k + 1]}, hb[k], ub);
+            }
+            const float alpha_a = fast_exp(fmaf(0.5f, ua.x, log1m)) + m, alpha_b = fast_exp(fmaf(0.5f, ub.x, log1m)) + m;
+            const float beta_a = 0.5f * ua.y, beta_b = 0.5f * ub.y;
+            sa += fast_ln(alpha_a);
+            sb += fast_ln(alpha_b);
+            xa[i] = INVERSE ? (xa[i] - beta_a) * __builtin_amdgcn_rcpf(alpha_a) : fmaf(alpha_a, xa[i], beta_a);
+            xb[i] = INVERSE ? (xb[i] - beta_b) * __builtin_amdgcn_rcpf(alpha_b) : fmaf(alpha_b, xb[i], beta_b);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        lda += INVERSE ? -sa : sa;
+        ldb += INVERSE ? -sb : sb;
+    }
+    template <bool INVERSE>
+    __device__ __forceinline__ void coupling2(float (&xa)[CPL], float (&xb)[CPL], int l, float& lda, float& ldb) const {
+        if ((l & 1) == 0) coupling2_impl<INVERSE, true>(xa, xb, l, lda, ldb);
+        else coupling2_impl<INVERSE, false>(xa, xb, l, lda, ldb);
+    }
+    __device__ __forceinline__ void forward2(float (&xa)[CPL], float (&xb)[CPL], float& lda, float& ldb) const {
+        const float* ea = img + n_coupling * lf + g;
+        lda = ldb = ea_ls;
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            const float e = ea[i * LPC], sh = ea[DP + i * LPC];
+            xa[i] = fmaf(e, xa[i], sh);
+            xb[i] = fmaf(e, xb[i], sh);
+        }
+        for (int l = 0; l < n_coupling; ++l) coupling2<false>(xa, xb, l, lda, ldb);
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            const float e = ea[4 * DP + i * LPC], sh = ea[5 * DP + i * LPC];
+            xa[i] = fmaf(e, xa[i], sh);
+            xb[i] = fmaf(e, xb[i], sh);
+        }
+    }
+    __device__ __forceinline__ void inverse2(float (&xa)[CPL], float (&xb)[CPL], float& lda, float& ldb) const {
+        const float* ea = img + n_coupling * lf + g;
+        lda = ldb = -ea_ls;
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            const float sh = ea[5 * DP + i * LPC], ei = ea[6 * DP + i * LPC];
+            xa[i] = (xa[i] - sh) * ei;
+            xb[i] = (xb[i] - sh) * ei;
+        }
+        for (int l = n_coupling - 1; l >= 0; --l) coupling2<true>(xa, xb, l, lda, ldb);
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            const float sh = ea[DP + i * LPC], ei = ea[2 * DP + i * LPC];
+            xa[i] = (xa[i] - sh) * ei;
+            xb[i] = (xb[i] - sh) * ei;
+        }
+    }
+
     // x -> z (z left in physical positions); returns this lane's share of logdet_forward.  The ElementwiseAffine
     // planes of the image carry e^ls and e^-ls (no transcendental per coordinate) and the lane's share of sum(ls) is a
     // constant of the flow (ea_ls, summed once in init()).

@@ -1307,6 +1307,33 @@ def test_fused_jump_tail_exact_fit_equals_separate_jump_launch(dev, strategy):
     assert a.statistics.n_attempted_jumps == b.statistics.n_attempted_jumps == 4 * 700
 
 
+@pytest.mark.parametrize('d,n,strategy', [(256, 1001, 'jump_hmc'), (64, 700, 'jump_mala'), (128, 333, 'imh'), (512, 130, 'jump_mala')])
+def test_two_chains_per_lane_group_equals_one_chain_kernel(dev, d, n, strategy, monkeypatch):
+    """flow_mh_b2_kernel (two chains per lane group share every weight row read from LDS; the production jump kernel
+    at d >= 256) against flow_mh_b_kernel: the same chains, bit for bit -- per chain the arithmetic and the Philox
+    stream are the same.  Odd chain counts leave the last lane group with one chain."""
+    from nfmc_amd.sample import create_sampler
+    from nfmc_amd.potentials import SumOfSquares
+    outs = []
+    for dual in ('0', '1'):
+        monkeypatch.setenv('NFMC_FLOWB_DUAL', dual)
+        torch.manual_seed(5)
+        kw = {'inner_param_kwargs': {'n_iterations': 3}} if strategy != 'imh' else {}
+        s = create_sampler(SumOfSquares((d,)), strategy=strategy, flow='realnvp',
+                           param_kwargs={'n_iterations': 4, 'store_samples': False}, **kw)
+        if hasattr(s, 'fuse_jump_tail'):
+            s.fuse_jump_tail = False
+        s.seed = 33
+        torch.manual_seed(6)
+        outs.append(s.sample(torch.randn(n, d) * 0.7, show_progress=False))
+    a, b = outs
+    assert torch.equal(a.running_samples.last_sample, b.running_samples.last_sample)
+    key = 'n_accepted_jumps' if strategy != 'imh' else 'n_accepted_trajectories'
+    assert getattr(a.statistics, key) == getattr(b.statistics, key)
+    np.testing.assert_allclose(a.mean.numpy(), b.mean.numpy(), atol=1e-5)
+    np.testing.assert_allclose(a.second_moment.numpy(), b.second_moment.numpy(), atol=1e-5)
+
+
 @pytest.mark.parametrize('d,nh,cl,strategy', [(64, 64, 1, 'imh'), (128, 128, 2, 'jump_mala'), (64, 40, 2, 'jump_hmc')])
 def test_wide_flow_metropolis_on_matrix_cores_equals_valu_kernels(dev, d, nh, cl, strategy, monkeypatch):
     """Wide conditioners at d = 64 / 128: forward / inverse / flow-MH run on the matrix cores (flow_mfma.hip); the
