@@ -399,7 +399,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--warmup', type=int, default=50,
+                    help='untimed steps before the timed repetitions; the default covers the ~30 ms the clocks take to ramp '
+                         'under load (with 2 the first two of five repetitions were 5-12 %% slower than the last)')
     ap.add_argument('--reps', type=int, default=5, help='timed repetitions of K steps; value = median (SURVEY 8d)')
     ap.add_argument('--config', choices=sorted(CONFIGS), default='C3')
     ap.add_argument('--fit-nf', action='store_true', help='jump strategies: refit the flow every outer iteration, so the '
@@ -477,13 +479,15 @@ def main():
     prime.seed = 0
     prime.sample(x_start[:n_local], show_progress=False)
     torch.cuda.synchronize(dev)
+    # CPython's cyclic collector must not fire inside a timed region (a generation-2 pass is ~35 ms with torch
+    # imported, several times one repetition): collect now, keep it off while timing.  BEFORE the warm-up steps: with
+    # the collection between warm-up and timing the GPU sat idle for those 35 ms, dropped its clocks, and the first
+    # repetitions ran 5-12 % slower than the last whatever W was (W = 2 ... 1000 measured).
+    gc.collect()
+    gc.disable()
     if args.warmup > 0:   # untimed; moves the state from x0 ~ N(0, I) to stationarity
         _dt, wout = run(args.warmup, x_start)
         x_start = carried(wout, x_start)
-    # CPython's cyclic collector must not fire inside a timed region (a generation-2 pass is ~35 ms with torch
-    # imported, several times one repetition): collect now, keep it off while timing.
-    gc.collect()
-    gc.disable()
     reps = []
     label = cfg['label']
     # R repetitions WITHOUT events give `value` (an event pair per launch costs ~6 us of stream time: 3-4 % of a C3 step,
