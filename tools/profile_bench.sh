@@ -16,5 +16,5 @@ for pass in "${PASSES[@]}"; do
   rocprofv3 --pmc $pass --output-format csv -d $O/pmc_$tag -- python3 bench.py --config $CFG --steps 3 --warmup 1 --reps 2 --no-cpu-baseline > $O/pmc_$tag.json 2> $O/pmc_$tag.err || echo "pass $tag failed"
 done
 python3 tools/summarize_pmc.py $O > $O/pmc_summary.json
-python3 bench.py --config $CFG --steps 20 --warmup 2 > $O/bench_line.json 2> $O/bench.err
+python3 bench.py --config $CFG > $O/bench_line.json 2> $O/bench.err
 echo done $CFG

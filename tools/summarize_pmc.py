@@ -4,12 +4,12 @@ from collections import defaultdict
 
 
 def short(name):
-    for key in ('mala_kernel', 'flow_mh_b_kernel', 'stats_finish_kernel', 'tune_finish_kernel', 'neutra_hmc_kernel', 'hmc_kernel',
+    for key in ('mala_kernel', 'flow_mh_b2_kernel', 'flow_mh_b_kernel', 'stats_finish_kernel', 'tune_finish_kernel', 'neutra_hmc_kernel', 'hmc_kernel',
                 'imh_eval_kernel', 'imh_scan_kernel', 'imh_replay_kernel', 'neutra_leapfrog_mfma_kernel',
                 'neutra_grad_mfma_kernel', 'flow_mh_mfma_kernel', 'flow_mh_kernel', 'realnvp_forward', 'realnvp_inverse'):
         if key in name:
             # the opt-in Philox4x32-7 instantiations (last template argument 7) are different kernels
-            return key + '_philox7' if (', 7>(' in name and key in ('mala_kernel', 'hmc_kernel', 'flow_mh_b_kernel')) else key
+            return key + '_philox7' if (', 7>(' in name and key in ('mala_kernel', 'hmc_kernel', 'flow_mh_b_kernel', 'flow_mh_b2_kernel')) else key
     return None
 
 
