@@ -63,28 +63,25 @@ __device__ __forceinline__ float potential_value_grad_c(const f32x4 (&x)[TD], f3
 // Register budget (two waves per SIMD, 256 VGPRs): x, g and at most THREE hidden-width tile sets are live at
 // any point (h_last, the du/dv tiles, dL/dh); with two hidden layers the first layer's activations are not kept
 // across the transposed products but rebuilt where tanh' is needed (+7 % multiply-adds instead of 32 registers).
-// What the reverse sweep reads back of one layer at its start (requested one GEMM ahead of its use: adjusted_grad_c)
-template <int TD, int TH>
-struct CkTiles {
-    f32x4 al[TD / 2], be[TD / 2], hl[TH];
+// alpha and beta of one layer, which the reverse sweep needs first (requested by adjusted_grad_c, possibly ahead of time)
+template <int TD>
+struct CkAffine {
+    f32x4 al[TD / 2], be[TD / 2];
 };
 template <int TD, int TH, int NHL>
-__device__ __forceinline__ void ck_request(CkTiles<TD, TH>& c, float* ck) {
+__device__ __forceinline__ void ck_request(CkAffine<TD>& c, float* ck) {
     using CL = CkLayout<TD, TH, NHL>;
 #pragma unroll
     for (int mt = 0; mt < TD / 2; ++mt) {
         c.al[mt] = *ck_tile(ck, CL::kAlpha + mt);
         c.be[mt] = *ck_tile(ck, CL::kBeta + mt);
     }
-#pragma unroll
-    for (int m = 0; m < TH; ++m) c.hl[m] = *ck_tile(ck, CL::kHl + m);
 }
 
-template <int TD, int TH, int NHL, bool REV, bool CK, class Ahead>
+template <int TD, int TH, int NHL, bool REV, bool CK>
 __device__ __forceinline__ void coupling_inverse_backward_c(f32x4 (&x)[TD], f32x4 (&g)[TD], const MLayer& L,
                                                             float mscale, float log1m, WeightPipe& wp, int col,
-                                                            int half, float* ck, const CkTiles<TD, TH>& kept,
-                                                            Ahead before_last_gemm) {
+                                                            int half, float* ck, const CkAffine<TD>& kept) {
     constexpr int TS = TD / 2, SRC0 = REV ? TS : 0, TGT0 = REV ? 0 : TS, D2 = 8 * TD, hp = 16 * TH;
     using CL = CkLayout<TD, TH, NHL>;
     f32x4 hl[TH];   // activations of the LAST hidden layer
@@ -108,8 +105,10 @@ __device__ __forceinline__ void coupling_inverse_backward_c(f32x4 (&x)[TD], f32x
         // everything the inverse sweep kept of this layer: no hidden stack, no W3 product
 #pragma unroll
         for (int mt = 0; mt < TS; ++mt) affine_backward(mt, kept.al[mt], kept.be[mt]);
+        // the last hidden layer's activations are needed in the epilogues of the next GEMM only: requested here, they
+        // arrive under its weight copy
 #pragma unroll
-        for (int m = 0; m < TH; ++m) hl[m] = kept.hl[m];
+        for (int m = 0; m < TH; ++m) hl[m] = *ck_tile(ck, CL::kHl + m);
         wp.mark(15);
     } else {
         {
@@ -210,7 +209,6 @@ __device__ __forceinline__ void coupling_inverse_backward_c(f32x4 (&x)[TD], f32x
                                });
         }
     }
-    before_last_gemm();
     wp.template stage<hp, D2, 1, 1, D2>(L.W1T, REV, false, nullptr, 0, false);
     const float* img = wp.img();
     gemm_phase<TH, TS>([&](int ms) { return img + (16 * ms + col) * (hp + 4) + 4 * half; }, [&](int) {},
@@ -233,14 +231,7 @@ __device__ __forceinline__ float adjusted_grad_c(f32x4 (&x)[TD], f32x4 (&g)[TD],
     wp.mark(10);
     float ldp = flow_inverse_sweep_c<TD, TH, NHL, CK, EAC>(x, f, wp, col, half, ck, eac);
     wp.mark(11);
-    // the first layer of the reverse sweep is the one the inverse sweep finished with: its tiles are requested before
-    // the potential so that the latency hides behind it
-    CkTiles<TD, TH> kept;
-#ifdef NFMC_T_EARLY
-    if constexpr (CK) {
-        if (f.n_coupling > 0) ck_request<TD, TH, NHL>(kept, ck);
-    }
-#endif
+    CkAffine<TD> kept;
     const float u = potential_value_grad_c<TD>(x, g, pot, half, lane);
     // reverse sweep
 #pragma unroll
@@ -260,30 +251,12 @@ __device__ __forceinline__ float adjusted_grad_c(f32x4 (&x)[TD], f32x4 (&g)[TD],
     for (int l = 0; l < f.n_coupling; ++l) {
         const MLayer L = mfma_layer(f.weights + l * f.layer_stride, d, hp, NHL);
         float* ckl = CK ? ck + (size_t)l * CL::kLayerFloats : nullptr;
-        CkTiles<TD, TH> next;
-        // the next layer's tiles are requested before this layer's last GEMM (x, g, one hidden-width tile set and the
-        // fragments are live there: room for them)
-        auto ahead = [&]() {
-            if constexpr (CK) {
-#ifdef NFMC_T_AHEAD
-                if (l + 1 < f.n_coupling) ck_request<TD, TH, NHL>(next, ckl + CL::kLayerFloats);
-#endif
-            }
-        };
-#ifndef NFMC_T_AHEAD
-#ifndef NFMC_T_EARLY
-        if constexpr (CK) { ck_request<TD, TH, NHL>(kept, ckl); }
-#else
-        if constexpr (CK) { if (l > 0) ck_request<TD, TH, NHL>(kept, ckl); }
-#endif
-#endif
-        if ((l & 1) == 0) coupling_inverse_backward_c<TD, TH, NHL, true, CK>(x, g, L, f.min_scale, log1m, wp, col, half, ckl, kept, ahead);
-        else coupling_inverse_backward_c<TD, TH, NHL, false, CK>(x, g, L, f.min_scale, log1m, wp, col, half, ckl, kept, ahead);
-#ifdef NFMC_T_AHEAD
-        if constexpr (CK) {
-            if (l + 1 < f.n_coupling) kept = next;
-        }
-#endif
+        // Requested HERE, not ahead of time: every attempt to hide this latency (the next layer's tiles before this layer's
+        // last GEMM, the first layer's before the potential, alpha / beta alone, the momentum tiles before the last GEMM)
+        // cost more in spills than it hid
+        if constexpr (CK) ck_request<TD, TH, NHL>(kept, ckl);
+        if ((l & 1) == 0) coupling_inverse_backward_c<TD, TH, NHL, true, CK>(x, g, L, f.min_scale, log1m, wp, col, half, ckl, kept);
+        else coupling_inverse_backward_c<TD, TH, NHL, false, CK>(x, g, L, f.min_scale, log1m, wp, col, half, ckl, kept);
     }
 #pragma unroll
     for (int m = 0; m < TD; ++m) {
@@ -337,9 +310,6 @@ struct LeapArgs {
     float* sample_row;         // store row this transition is kept in (NfmcSampleStore walked on the host), or NULL
 };
 
-#ifndef NFMC_T_EAC
-#define NFMC_T_EAC true
-#endif
 // LDS of the trajectory kernel: the matrix-core carve-up (mfma_device.hpp), then the EaPlanes constants
 constexpr size_t kLeapLdsBytes = kMfmaLdsBytes + EaPlanes::kFloats * sizeof(float);
 
@@ -426,12 +396,12 @@ __global__ void __launch_bounds__(kMfmaBlock, 2) neutra_leapfrog_mfma_kernel(Lea
             if (active) store_ctiles<TD>(p, A.p, row_in, d, half, rev);  // momentum is not live across the GEMMs
         }
         for (int l = 0; l < L; ++l) {
-        u = adjusted_grad_c<TD, TH, NHL, true, NFMC_T_EAC>(x, g, a.flow, a.pot, wp, col, half, lane, ck, eac);
+        f32x4 p[TD];
+        u = adjusted_grad_c<TD, TH, NHL, true, true>(x, g, a.flow, a.pot, wp, col, half, lane, ck, eac);
         // everything below addresses HBM by the row index: an opaque copy keeps that address arithmetic from
         // being computed before the gradient and held in registers through it (cf. stage_matrix)
         int64_t row = row_t, rrow = rrow_t;
         asm volatile("" : "+v"(row), "+v"(rrow));
-        f32x4 p[TD];
         load_ctiles<TD>(p, A.p, rrow, d, half, rev);
 #pragma unroll
         for (int m = 0; m < TD; ++m)
