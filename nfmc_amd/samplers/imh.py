@@ -113,7 +113,9 @@ class FixedIMH(AbstractIMH):
             done += k
             bar.update(k)
         bar.close()
-        run.sync()
+        # the final-state copy and the statistics fold go out right behind the last kernel; the one device-to-host
+        # copy of the totals is the only synchronisation of the call
+        last_sample = run.x.reshape(n, *event_shape).clone()
         sum_x, sum_x2, cnt, _jc = run.stats.host_totals()
         st = out.statistics
         st.update_counters(n_target_calls=2 * n * done, n_accepted_trajectories=int(cnt[hip.CNT_ACCEPTED]),
@@ -122,7 +124,7 @@ class FixedIMH(AbstractIMH):
         st.absorb_device_sums(sum_x.reshape(event_shape), sum_x2.reshape(event_shape), n * done)
         if store is not None:
             out.running_samples.adopt_store(store, getattr(self.params, 'spill_to_host', False))
-        out.running_samples.last_sample = run.x.reshape(n, *event_shape).clone()
+        out.running_samples.last_sample = last_sample
         st.update_elapsed_time(time.time() - t0)
         out.kernel = self.kernel
         out.kernel_events = run.kernel_events
@@ -235,7 +237,9 @@ class AdaptiveIMH(AbstractIMH):
                     flow.load_state_dict(weights)                                       # :170
             bar.update(1)
         bar.close()
-        run.sync()
+        # the final-state copy and the statistics fold go out right behind the last kernel; the one device-to-host
+        # copy of the totals is the only synchronisation of the call
+        last_sample = run.x.reshape(n, *event_shape).clone()
         sum_x, sum_x2, cnt, _jc = run.stats.host_totals()
         st = out.statistics
         # imh.py:140-144 books the 2n target evaluations as gradient calls; kept
@@ -245,7 +249,7 @@ class AdaptiveIMH(AbstractIMH):
         st.absorb_device_sums(sum_x.reshape(event_shape), sum_x2.reshape(event_shape), n * done)
         if done > 0:
             out.running_samples.add(buf[:done].reshape(done, n, *event_shape))
-        out.running_samples.last_sample = run.x.reshape(n, *event_shape).clone()
+        out.running_samples.last_sample = last_sample
         st.update_elapsed_time(time.time() - t0)
         self.n_refits = n_refits
         out.kernel = self.kernel

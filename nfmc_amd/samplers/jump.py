@@ -282,8 +282,6 @@ class JumpNFMC(Sampler):
             raise ValueError("Inner sampler in jump HMC must store samples")
         run = Run(self, x0)
         n, d, event_shape = run.n, run.d, run.event_shape
-        out = JumpNFMCOutput(event_shape, store_samples=self.params.store_samples,
-                             max_samples=getattr(self.params, 'max_samples', None))
         flow = self.kernel.flow
         T, K = int(self.params.n_iterations), int(inner.params.n_iterations)
         off = (False, 'never')
@@ -302,8 +300,19 @@ class JumpNFMC(Sampler):
                                   getattr(self.params, 'max_samples', None)) if (self.params.store_samples and T > 0) else None
         fit_buf = torch.empty(K, n, d, dtype=torch.float32, device=run.dev) if self.params.fit_nf else None
         logq = torch.empty(n, dtype=torch.float32, device=run.dev)
-        if fused and not flow_mh_supported(run, flow, pot, logq, self.params.adjusted_jumps):
-            fused = tail_ok = False   # the jump through the flow's own kernels (split_flow_mh)
+        # Can the jump run on the flow-MH kernels?  The answer needs the packed weights (host work, a small upload): asked
+        # before the first launch only when the jump is to ride behind the inner kernel, otherwise after the first inner
+        # launches are queued, so that the GPU already works while the host packs
+        probed = not fused
+
+        def probe():
+            nonlocal fused, tail_ok, probed
+            if not probed and not flow_mh_supported(run, flow, pot, logq, self.params.adjusted_jumps):
+                fused = tail_ok = False   # the jump through the flow's own kernels (split_flow_mh)
+            probed = True
+
+        if tail_ok:
+            probe()
 
         t0 = time.time()
         done = 0
@@ -337,6 +346,7 @@ class JumpNFMC(Sampler):
             else:
                 for off in range(K):
                     inner._split_step(run, base + off, fit_buf[off:off + 1] if dense else store)
+            probe()
             if dense and store is not None:
                 store.add_dense(fit_buf)
             # ---- optional refit on this iteration's inner samples (jump.py:193-201)
@@ -363,10 +373,15 @@ class JumpNFMC(Sampler):
                 run.sync()
                 bar.set_postfix_str(f'acc {int(run.stats.counters[hip.CNT_ACCEPTED])}/'
                                     f'{int(run.stats.counters[hip.CNT_ATTEMPTED])}')
-        run.sync()
+        # end of the call, ordered for the GPU: the copy of the final state and the statistics fold are enqueued right
+        # behind the last kernel, and the one device-to-host copy of the totals is the only synchronisation (with a
+        # synchronize first, then the fold, then host work, then the clone, the stream sat idle ~110 us per call)
+        last_sample = run.x.reshape(n, *event_shape).clone()
         inner._cur_run = None
         sum_x, sum_x2, cnt, jc = run.stats.host_totals()
         calls, grads = inner._counts(n, K * done)
+        out = JumpNFMCOutput(event_shape, store_samples=self.params.store_samples,
+                             max_samples=getattr(self.params, 'max_samples', None))
         st = out.statistics
         st.update_counters(n_accepted_trajectories=int(cnt[hip.CNT_ACCEPTED]),
                            n_attempted_trajectories=int(cnt[hip.CNT_ATTEMPTED]),
@@ -378,7 +393,7 @@ class JumpNFMC(Sampler):
         st.absorb_device_sums(sum_x.reshape(event_shape), sum_x2.reshape(event_shape), n * done * (K + 1))
         if store is not None:
             out.running_samples.adopt_store(store, getattr(self.params, 'spill_to_host', False))
-        out.running_samples.last_sample = run.x.reshape(n, *event_shape).clone()
+        out.running_samples.last_sample = last_sample
         st.update_elapsed_time(time.time() - t0)
         out.kernel = self.kernel
         out.kernel_events = run.kernel_events

@@ -250,7 +250,9 @@ class MCMCSampler(Sampler):
             done += k
             bar.update(k)
         bar.close()
-        run.sync()
+        # the final-state copy and the statistics fold go out right behind the last kernel; the one device-to-host
+        # copy of the totals is the only synchronisation of the call
+        last_sample = run.x.reshape(n, *event_shape).clone()
         if tune is not None:
             tune.download(self.kernel)
         sum_x, sum_x2, cnt, _jc = run.stats.host_totals()
@@ -265,7 +267,7 @@ class MCMCSampler(Sampler):
         rs = out.running_samples
         if store is not None:
             rs.adopt_store(store, getattr(self.params, 'spill_to_host', False))
-        rs.last_sample = run.x.reshape(n, *event_shape).clone()
+        rs.last_sample = last_sample
         out.statistics.update_elapsed_time(time.time() - t0)
         out.kernel = self.kernel
         out.kernel_events = run.kernel_events

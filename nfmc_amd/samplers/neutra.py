@@ -199,7 +199,9 @@ class NeuTra(Sampler):
             done += k
             bar.update(k)
         bar.close()
-        run.sync()
+        # the final-state copy and the statistics fold go out right behind the last kernel; the one device-to-host
+        # copy of the totals is the only synchronisation of the call
+        last_sample = run.x.reshape(n, *event_shape).clone()
         sum_x, sum_x2, cnt, _jc = run.stats.host_totals()
         calls, grads = inner._counts(n, done)
         st = out.statistics
@@ -210,7 +212,7 @@ class NeuTra(Sampler):
         st.absorb_device_sums(sum_x.reshape(event_shape), sum_x2.reshape(event_shape), n * done)
         if store is not None:
             out.running_samples.adopt_store(store, getattr(self.params, 'spill_to_host', False))
-        out.running_samples.last_sample = run.x.reshape(n, *event_shape).clone()
+        out.running_samples.last_sample = last_sample
         st.update_elapsed_time(time.time() - t0)
         out.kernel = inner.kernel
         out.kernel.flow = self.kernel.flow  # neutra.py:128
