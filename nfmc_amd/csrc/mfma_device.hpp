@@ -236,28 +236,6 @@ __device__ __forceinline__ void gemm_phase(Row row, Init init, Acc acc, Act act,
     return;
 #endif
 #if !defined(NFMC_MFMA_PAIRS) && !defined(NFMC_MFMA_PREFETCH) && !defined(NFMC_MFMA_EPI)
-#ifdef NFMC_SKEW_SPLIT
-    // Experiment: the partner waves of a SIMD run the SAME steps one epilogue apart -- these waves do MFMAs(i) and then
-    // the epilogue of step i - 1, the others MFMAs(i), epilogue(i) -- so that one wave's elementwise work falls under
-    // the other's MFMAs instead of both running it together with the matrix pipe idle.
-    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & NFMC_SKEW_SPLIT) {
-#pragma unroll
-        for (int i = 0; i < NSTEP; ++i) {
-            f32x4 a[TK];
-            frag_load<TK>(a, row(i));
-            init(i);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int mk = 0; mk < TK; ++mk)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc(i) = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mk][r], act(i)[mk][r], acc(i), 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (i > 0) fin(i - 1);
-        }
-        fin(NSTEP - 1);
-        return;
-    }
-#endif
     // DEFAULT (fastest measured, see the table above).  A step's A fragments are read in chunks of at most kFragChunk
     // k-tiles (4 registers each): the scheduler may move the NEXT chunk's reads above this chunk's MFMAs (the fence
     // stops anything further), so the fragments cost 2 x 4 x kFragChunk registers at the peak -- 32 instead of 64 for
@@ -265,34 +243,6 @@ __device__ __forceinline__ void gemm_phase(Row row, Init init, Acc acc, Act act,
     // shorter look-ahead (16 MFMAs = 512 cycles still cover an LDS read).
     constexpr int CH = TK < NFMC_FRAG_CHUNK ? TK : NFMC_FRAG_CHUNK;
     static_assert(TK % CH == 0, "whole chunks");
-#ifdef NFMC_FRAG_PREFETCH
-    // Software pipeline over chunks: the reads of chunk k + 1 (and, when it opens a step, that step's init = its bias
-    // read) are issued BEFORE the MFMAs of chunk k, into the other fragment set.  init(i + 1) therefore runs before
-    // fin(i): callers double-buffer whatever both touch.  Same register count as one un-chunked tile (2 x 4 x CH).
-    {
-        constexpr int NCH = TK / CH;
-        f32x4 a[2][CH];
-        init(0);
-        frag_load<CH>(a[0], row(0));
-#pragma unroll
-        for (int k = 0; k < NSTEP * NCH; ++k) {
-            const int i = k / NCH, c0 = (k % NCH) * CH;
-            if (k + 1 < NSTEP * NCH) {
-                const int i1 = (k + 1) / NCH, c1 = ((k + 1) % NCH) * CH;
-                if (c1 == 0) init(i1);
-                frag_load<CH>(a[(k + 1) & 1], row(i1) + 16 * c1);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int mk = 0; mk < CH; ++mk)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    acc(i) = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k & 1][mk][r], act(i)[c0 + mk][r], acc(i), 0, 0, 0);
-            if (c0 + CH == TK) fin(i);
-        }
-        return;
-    }
-#endif
 #pragma unroll
     for (int i = 0; i < NSTEP; ++i) {   // one step at a time: reads, then MFMAs, then epilogue
         init(i);
