@@ -119,8 +119,8 @@ __global__ void __launch_bounds__(kBlock) imh_eval_kernel(NfmcFlowMhArgs a, ImhW
 // One WAVE per chain: the Metropolis scan over the k proposals (imh.py:223-233).  Everything expensive (proposal,
 // uniform, logarithm) was done in parallel by imh_eval_kernel.  The scan is sequential only through acceptances: the
 // 64 lanes test the next 64 steps against the current state at once, the first accepting lane (ballot + ffs) becomes
-// the state and the scan resumes right after it -- k / 64 rounds when nothing is accepted, one round per acceptance
-// otherwise, each a few hundred cycles.
+// the state and the scan resumes right after it, on the same 64 steps held in registers -- k / 64 memory round trips per
+// chain, plus a few dozen cycles per acceptance.
 __global__ void __launch_bounds__(256) imh_scan_kernel(NfmcFlowMhArgs a, ImhWork w) {
     const int64_t n = a.n;
     const int d = a.flow.d;
@@ -132,38 +132,62 @@ __global__ void __launch_bounds__(256) imh_scan_kernel(NfmcFlowMhArgs a, ImhWork
     for (int64_t i = wave0; i < n; i += nwaves) {
         float u_x = potential_row(w.x0 + i * d, a.pot, d);   // imh.py:224 (every lane: uniform addresses)
         float f_x = a.logq[i];                                // imh.py:214 (filled by the caller when not cached)
-        int cur = -1, pos = 0;
-        while (pos < k) {
-            const int s = pos + lane;
+        int cur = -1;
+        // A window of 64 steps is read ONCE (and the next one requested ahead); every acceptance inside it re-tests the
+        // remaining lanes against the new state from registers.  The first version re-read the window shifted past each
+        // acceptance and wrote one scattered dwell word per acceptance (~600 per chain at C2's acceptance rate): 215 us
+        // of a 1.5 ms call; 173 us now.  What is left is instruction issue: 8192 waves x ~600 acceptances x ~30
+        // instructions of a loop that is sequential per chain.
+        float nu, nf, nl;   // the next window, requested one window ahead
+        {
+            const int64_t r0 = i * k + (lane < k ? lane : k - 1);
+            nu = w.u[r0], nf = w.f[r0], nl = w.logu[r0];
+        }
+        for (int base = 0; base < k; base += 64) {
+            const int s = base + lane;
             const bool valid = s < k;
             const int sv = valid ? s : k - 1;
             const int64_t r = i * k + sv, ro = (int64_t)sv * n + i;   // work arrays (n, k); outputs (k, n)
-            const float pu = w.u[r], pf = w.f[r], pl = w.logu[r];
-            const float lr = (-pu) - (-u_x) + f_x - pf;      // util.py:392
-            const bool acc = valid && pl < lr;                // imh.py:229-230; NaN -> reject
-            const bool bad = valid && !(fabsf(lr) <= 3.0e38f);
-            const unsigned long long am = __ballot(acc), bm = __ballot(bad);
-            const int j = am ? __ffsll((long long)am) - 1 : 63;          // lanes 0..j are decided by this round
-            const unsigned long long decided = j == 63 ? ~0ull : ((2ull << j) - 1ull);
-            bad_total += (unsigned long long)__popcll(bm & decided);
-            if (valid && lane <= j) {
-                if (a.masks_out) a.masks_out[ro] = (acc && lane == j) ? 1 : 0;
-                if (a.log_ratio_out) a.log_ratio_out[ro] = lr;
+            const float pu = nu, pf = nf, pl = nl;
+            if (base + 64 < k) {
+                const int sn = base + 64 + lane;
+                const int64_t rn = i * k + (sn < k ? sn : k - 1);
+                nu = w.u[rn], nf = w.f[rn], nl = w.logu[rn];
             }
-            if (am) {
-                const int s_acc = pos + j;
-                if (lane == 0) {
+            int start = 0;                                            // lanes below are decided already
+            int dw = 0;   // dwell time of this lane's proposal when it is accepted AND replaced within this window
+            while (start < 64) {
+                const float lr = (-pu) - (-u_x) + f_x - pf;          // util.py:392
+                const bool open = valid && lane >= start;
+                const bool acc = open && pl < lr;                     // imh.py:229-230; NaN -> reject
+                const bool bad = open && !(fabsf(lr) <= 3.0e38f);
+                const unsigned long long am = __ballot(acc), bm = __ballot(bad);
+                const int j = am ? __ffsll((long long)am) - 1 : 63;  // lanes start..j are decided by this round
+                const unsigned long long decided = j == 63 ? ~0ull : ((2ull << j) - 1ull);
+                bad_total += (unsigned long long)__popcll(bm & decided);
+                if (open && lane <= j) {
+                    if (a.masks_out) a.masks_out[ro] = (acc && lane == j) ? 1 : 0;
+                    if (a.log_ratio_out) a.log_ratio_out[ro] = lr;
+                }
+                if (!am) break;
+                const int s_acc = base + j;
+                // steps the previous state stayed: into the owning lane's register when that proposal sits in this window
+                // (written with the window, one coalesced store), else one store by lane 0 -- at most one per window
+                // instead of one scattered 4-byte store per acceptance (~600 per chain at C2)
+                if (cur >= base) {
+                    if (lane == cur - base) dw = s_acc - cur;
+                } else if (lane == 0) {
                     if (cur < 0) w.dwell0[i] = s_acc;                    // steps before the first acceptance
                     else w.dwell[i * k + cur] = s_acc - cur;             // steps this proposal stayed the state
                 }
-                u_x = __shfl(pu, j, kWave);
-                f_x = __shfl(pf, j, kWave);
+                // j is wave-uniform (from the ballot): v_readlane, not a ds_bpermute round trip through the LDS per acceptance
+                u_x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pu), j));
+                f_x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pf), j));
                 cur = s_acc;
                 acc_total++;
-                pos = s_acc + 1;
-            } else {
-                pos += 64;
+                start = j + 1;
             }
+            if (valid) w.dwell[r] = dw;   // 0: rejected, or still the state at the end of the window (patched later by lane 0)
         }
         if (lane == 0) {
             if (cur < 0) w.dwell0[i] = k;
