@@ -179,6 +179,27 @@ __device__ __forceinline__ void gemm_tile(f32x4& acc, const float* __restrict__ 
 #endif
 }
 
+#ifdef NFMC_TRACE_STEPS
+// Diagnostic build (tools/trace_c4.py, with NFMC_TRACE): per-step marks of workgroup 0 of the trajectory kernel, one
+// stream per wave behind the phase marks (30 = a step's reads begin, 31 = its MFMAs are issued, the epilogue follows).
+// The kernel arms it (pointers + magic in static LDS); other kernels of the build leave the magic unset or stale -- the
+// buffer they would then write to is the still-allocated trace area.
+__shared__ unsigned long long* g_step_buf[8];
+__shared__ int g_step_cnt[8];
+__shared__ unsigned g_step_magic;
+__device__ __forceinline__ void step_mark(int id) {
+    if ((threadIdx.x & 63) == 0 && g_step_magic == 0x5A17C0DEu) {
+        const int w = threadIdx.x >> 6;
+        unsigned long long* b = g_step_buf[w];
+        const int k = g_step_cnt[w];
+        if (b && k < 8192) {
+            b[k] = ((unsigned long long)id << 48) | (__builtin_amdgcn_s_memtime() & 0xFFFFFFFFFFFFull);
+            g_step_cnt[w] = k + 1;
+        }
+    }
+}
+#endif
+
 // ---- a GEMM phase = NSTEP steps, each: read this lane's A fragments of one 16-row output block from the LDS image,
 // 4 * TK MFMAs into one accumulator quad, an elementwise epilogue.
 //   row(i)   LDS address of the A fragments of step i (this lane's row / column group)
@@ -245,6 +266,9 @@ __device__ __forceinline__ void gemm_phase(Row row, Init init, Acc acc, Act act,
     static_assert(TK % CH == 0, "whole chunks");
 #pragma unroll
     for (int i = 0; i < NSTEP; ++i) {   // one step at a time: reads, then MFMAs, then epilogue
+#ifdef NFMC_TRACE_STEPS
+        step_mark(30);
+#endif
         init(i);
 #pragma unroll
         for (int c0 = 0; c0 < TK; c0 += CH) {
@@ -262,6 +286,9 @@ __device__ __forceinline__ void gemm_phase(Row row, Init init, Acc acc, Act act,
                     acc(i) = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mk][r], act(i)[c0 + mk][r], acc(i), 0, 0, 0);
 #endif
         }
+#ifdef NFMC_TRACE_STEPS
+        step_mark(31);
+#endif
         fin(i);
     }
     return;

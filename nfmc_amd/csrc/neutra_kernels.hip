@@ -439,7 +439,7 @@ extern "C" int64_t nfmc_neutra_scratch_bytes(int64_t n, int32_t d, int32_t n_hid
     const int64_t slots = tiles < kCkMaxGrid ? tiles : kCkMaxGrid;
     int64_t floats = 2 * n * (int64_t)d + 2 * n + slots * kMfmaWaves * n_coupling * layer_floats;
 #ifdef NFMC_TRACE
-    floats += 2 * kMfmaWaves * 4096;   // diagnostic build: the mark streams of workgroup 0
+    floats += 2 * kMfmaWaves * (4096 + 8192);   // diagnostic build: the phase and step mark streams of workgroup 0
 #endif
     return floats * (int64_t)sizeof(float);
 }

@@ -338,9 +338,19 @@ __global__ void __launch_bounds__(kMfmaBlock, 2) neutra_leapfrog_mfma_kernel(Lea
     __syncthreads();
     const int L = a.n_leapfrog;
 #ifdef NFMC_TRACE
-    if (blockIdx.x == 0)
-        wp.tr = reinterpret_cast<unsigned long long*>(A.ck + (size_t)gridDim.x * kMfmaWaves * a.flow.n_coupling *
-                                                                 CkLayout<TD, TH, NHL>::kLayerFloats) + wave * 4096;
+    {
+        unsigned long long* tbase = reinterpret_cast<unsigned long long*>(
+            A.ck + (size_t)gridDim.x * kMfmaWaves * a.flow.n_coupling * CkLayout<TD, TH, NHL>::kLayerFloats);
+        if (blockIdx.x == 0) wp.tr = tbase + wave * 4096;
+#ifdef NFMC_TRACE_STEPS
+        if (threadIdx.x < kMfmaWaves) {
+            g_step_buf[threadIdx.x] = blockIdx.x == 0 ? tbase + kMfmaWaves * 4096 + threadIdx.x * 8192 : nullptr;
+            g_step_cnt[threadIdx.x] = 0;
+        }
+        if (threadIdx.x == 0) g_step_magic = 0x5A17C0DEu;
+        __syncthreads();
+#endif
+    }
 #endif
 
     for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {

@@ -25,7 +25,9 @@ t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=T
 s = bench.build_sampler(cfg, 1)
 t0.record(); s.sample(x0, show_progress=False); t1.record(); torch.cuda.synchronize()
 print('sample() of one trajectory: %.3f ms' % t0.elapsed_time(t1))
-marks = s._scratch[-2 * 8 * 4096:].view(torch.int64).view(8, 4096).cpu()
+tail = s._scratch[-2 * 8 * (4096 + 8192):].view(torch.int64).cpu()
+marks = tail[:8 * 4096].view(8, 4096)
+steps = tail[8 * 4096:].view(8, 8192)
 names = {(1, 2): 'stage copy', (2, 3): 'barrier wait', (3, 1): 'GEMM phase', (3, 11): 'GEMM phase (last of inverse sweep)',
          (3, 12): 'GEMM phase + EA (last of reverse sweep)', (3, 15): '??', (11, 15): 'potential grad + ckpt loads + affine bwd',
          (1, 15): 'x', (15, 1): 'affine->stage', (10, 1): 'EA inverse', (12, 10): 'leapfrog glue (momentum round trip)',
@@ -47,3 +49,15 @@ for w in (0, 4, 1, 5):
         i0 = tens[5]
         i1 = next(i for i in range(i0, len(ev)) if ev[i][0] == 12)
         print('   gradient 5:', ' '.join('%d:%d' % (ev[i][0], ev[i + 1][1] - ev[i][1]) for i in range(i0, i1)))
+
+# per-step marks (a -DNFMC_TRACE_STEPS build): 30 = a step's reads begin, 31 = its MFMAs are issued (epilogue follows)
+for w in (0, 4):
+    ev = [(int(v) >> 48, int(v) & ((1 << 48) - 1)) for v in steps[w].tolist() if v != 0]
+    if len(ev) < 400:
+        continue
+    # steps of gradient 5: 84 steps (168 marks) per gradient
+    seg = ev[5 * 168:6 * 168 + 1]
+    mf = [seg[i + 1][1] - seg[i][1] for i in range(0, len(seg) - 1, 2)]       # 30 -> 31: reads + MFMAs
+    ep = [seg[i + 1][1] - seg[i][1] for i in range(1, len(seg) - 1, 2)]       # 31 -> next 30: epilogue (+ phase boundary)
+    print('wave %d gradient 5, per step: reads+MFMAs %s' % (w, mf))
+    print('wave %d gradient 5, per step: epilogue (+boundary) %s' % (w, ep))
