@@ -21,6 +21,13 @@ struct CkLayout {
 };
 // `ck` already carries this lane's offset (4 * lane floats)
 __device__ __forceinline__ f32x4* ck_tile(float* ck, int tile) { return reinterpret_cast<f32x4*>(ck + tile * 256); }
+// The layer the inverse sweep finishes with is the one the reverse sweep starts with: its last-hidden-layer activations,
+// alpha and beta stay in REGISTERS across the potential (nothing else is live there but x and g) instead of going
+// through the checkpoint area -- a third of the checkpoint traffic of a two-layer flow and one exposed load latency.
+template <int TD, int TH>
+struct CkKeep {
+    f32x4 hl[TH], al[TD / 2], be[TD / 2];
+};
 
 // ---- the two ElementwiseAffine layers and the mass diagonal as LDS planes in TILE-POSITION order (plane stride 128
 // floats): log_scale, exp(log_scale), exp(-log_scale), shift of EA0 and of EA1, then inv_mass_diag (or ones).  NeuTra's
@@ -68,9 +75,10 @@ __device__ __forceinline__ void ea_tile(f32x4& ls, f32x4& e, f32x4& sh, const fl
 // Returns this lane's share of the layer's logdet in THAT direction.  Three steps of the weight pipeline.
 // CK: keep what NeuTra's reverse sweep needs of this layer (hidden activations, alpha, beta) in the wave's checkpoint
 // area `ck` (layout: ck_tile) instead of having the reverse sweep recompute it.
-template <int TD, int TH, int NHL, bool REV, bool INVERSE, bool CK = false>
+template <int TD, int TH, int NHL, bool REV, bool INVERSE, bool CK = false, bool KEEP = false>
 __device__ __forceinline__ float coupling_c(f32x4 (&x)[TD], const MLayer& L, float mscale, float log1m,
-                                            WeightPipe& wp, int col, int half, float* ck = nullptr) {
+                                            WeightPipe& wp, int col, int half, float* ck = nullptr,
+                                            CkKeep<TD, TH>* keep = nullptr) {
     constexpr int TS = TD / 2, SRC0 = REV ? TS : 0, TGT0 = REV ? 0 : TS, D2 = 8 * TD, hp = 16 * TH;
     f32x4 hl[TH];   // activations of the last hidden layer
     {
@@ -82,7 +90,8 @@ __device__ __forceinline__ float coupling_c(f32x4 (&x)[TD], const MLayer& L, flo
         if constexpr (CK) {
 #pragma unroll
             for (int m = 0; m < TH; ++m) {
-                *ck_tile(ck, CkLayout<TD, TH, NHL>::kHl + m) = hl[m];
+                if constexpr (KEEP) keep->hl[m] = hl[m];
+                else *ck_tile(ck, CkLayout<TD, TH, NHL>::kHl + m) = hl[m];
                 if constexpr (NHL > 1) *ck_tile(ck, CkLayout<TD, TH, NHL>::kH1 + m) = h1[m];
             }
         }
@@ -117,7 +126,10 @@ __device__ __forceinline__ float coupling_c(f32x4 (&x)[TD], const MLayer& L, flo
                     ld += la;
                 }
             }
-            if constexpr (CK) {
+            if constexpr (CK && KEEP) {
+                keep->al[mt] = al;
+                keep->be[mt] = be;
+            } else if constexpr (CK) {
                 *ck_tile(ck, CkLayout<TD, TH, NHL>::kAlpha + mt) = al;
                 *ck_tile(ck, CkLayout<TD, TH, NHL>::kBeta + mt) = be;
             }
@@ -129,7 +141,8 @@ __device__ __forceinline__ float coupling_c(f32x4 (&x)[TD], const MLayer& L, flo
 // `eac`: the elementwise-affine constants in LDS (EaPlanes, filled once per kernel by ea_planes_fill) or null (global reads)
 template <int TD, int TH, int NHL, bool CK = false, bool EAC = false>
 __device__ __forceinline__ float flow_inverse_sweep_c(f32x4 (&x)[TD], const NfmcRealNVP& f, WeightPipe& wp, int col,
-                                                      int half, float* ck = nullptr, const float* eac = nullptr) {
+                                                      int half, float* ck = nullptr, const float* eac = nullptr,
+                                                      CkKeep<TD, TH>* keep = nullptr) {
     constexpr int d = 16 * TD, hp = 16 * TH;
     const bool rev_last = (f.n_coupling & 1) != 0;
     const float log1m = __logf(1.f - f.min_scale);
@@ -144,11 +157,17 @@ __device__ __forceinline__ float flow_inverse_sweep_c(f32x4 (&x)[TD], const Nfmc
             ldp -= ls[t];
         }
     }
-    for (int l = f.n_coupling - 1; l >= 0; --l) {
+    for (int l = f.n_coupling - 1; l >= (CK ? 1 : 0); --l) {
         const MLayer L = mfma_layer(f.weights + l * f.layer_stride, d, hp, NHL);
         float* ckl = CK ? ck + (size_t)l * CkLayout<TD, TH, NHL>::kLayerFloats : nullptr;
         if ((l & 1) == 0) ldp += coupling_c<TD, TH, NHL, true, true, CK>(x, L, f.min_scale, log1m, wp, col, half, ckl);
         else ldp += coupling_c<TD, TH, NHL, false, true, CK>(x, L, f.min_scale, log1m, wp, col, half, ckl);
+    }
+    if constexpr (CK) {   // layer 0 (even: reversed), the reverse sweep's first: kept in registers (CkKeep)
+        if (f.n_coupling > 0) {
+            const MLayer L = mfma_layer(f.weights, d, hp, NHL);
+            ldp += coupling_c<TD, TH, NHL, true, true, true, true>(x, L, f.min_scale, log1m, wp, col, half, ck, keep);
+        }
     }
 #pragma unroll
     for (int m = 0; m < TD; ++m) {  // EA0^-1

@@ -78,10 +78,11 @@ __device__ __forceinline__ void ck_request(CkAffine<TD>& c, float* ck) {
     }
 }
 
-template <int TD, int TH, int NHL, bool REV, bool CK>
+template <int TD, int TH, int NHL, bool REV, bool CK, bool FROMREG = false>
 __device__ __forceinline__ void coupling_inverse_backward_c(f32x4 (&x)[TD], f32x4 (&g)[TD], const MLayer& L,
                                                             float mscale, float log1m, WeightPipe& wp, int col,
-                                                            int half, float* ck, const CkAffine<TD>& kept) {
+                                                            int half, float* ck, const CkAffine<TD>& kept,
+                                                            const f32x4 (*hl_kept)[TH] = nullptr) {
     constexpr int TS = TD / 2, SRC0 = REV ? TS : 0, TGT0 = REV ? 0 : TS, D2 = 8 * TD, hp = 16 * TH;
     using CL = CkLayout<TD, TH, NHL>;
     f32x4 hl[TH];   // activations of the LAST hidden layer
@@ -108,7 +109,10 @@ __device__ __forceinline__ void coupling_inverse_backward_c(f32x4 (&x)[TD], f32x
         // the last hidden layer's activations are needed in the epilogues of the next GEMM only: requested here, they
         // arrive under its weight copy
 #pragma unroll
-        for (int m = 0; m < TH; ++m) hl[m] = *ck_tile(ck, CL::kHl + m);
+        for (int m = 0; m < TH; ++m) {
+            if constexpr (FROMREG) hl[m] = (*hl_kept)[m];
+            else hl[m] = *ck_tile(ck, CL::kHl + m);
+        }
         wp.mark(15);
     } else {
         {
@@ -229,7 +233,8 @@ __device__ __forceinline__ float adjusted_grad_c(f32x4 (&x)[TD], f32x4 (&g)[TD],
     const bool rev_last = (f.n_coupling & 1) != 0;
     const float log1m = __logf(1.f - f.min_scale);
     wp.mark(10);
-    float ldp = flow_inverse_sweep_c<TD, TH, NHL, CK, EAC>(x, f, wp, col, half, ck, eac);
+    CkKeep<TD, TH> keep;   // layer 0's activations, alpha, beta: in registers from the inverse sweep to the reverse sweep
+    float ldp = flow_inverse_sweep_c<TD, TH, NHL, CK, EAC>(x, f, wp, col, half, ck, eac, &keep);
     wp.mark(11);
     CkAffine<TD> kept;
     const float u = potential_value_grad_c<TD>(x, g, pot, half, lane);
@@ -248,12 +253,22 @@ __device__ __forceinline__ float adjusted_grad_c(f32x4 (&x)[TD], f32x4 (&g)[TD],
             x[m][t] = fmaf(e[t], x[m][t], sh[t]);
         }
     }
-    for (int l = 0; l < f.n_coupling; ++l) {
+    if constexpr (CK) {   // layer 0 first, from the registers the inverse sweep left (CkKeep); they die here
+        if (f.n_coupling > 0) {
+            const MLayer L = mfma_layer(f.weights, d, hp, NHL);
+#pragma unroll
+            for (int mt = 0; mt < TD / 2; ++mt) {
+                kept.al[mt] = keep.al[mt];
+                kept.be[mt] = keep.be[mt];
+            }
+            coupling_inverse_backward_c<TD, TH, NHL, true, true, true>(x, g, L, f.min_scale, log1m, wp, col, half, ck, kept, &keep.hl);
+        }
+    }
+    for (int l = CK ? 1 : 0; l < f.n_coupling; ++l) {
         const MLayer L = mfma_layer(f.weights + l * f.layer_stride, d, hp, NHL);
         float* ckl = CK ? ck + (size_t)l * CL::kLayerFloats : nullptr;
         // Requested HERE, not ahead of time: every attempt to hide this latency (the next layer's tiles before this layer's
-        // last GEMM, the first layer's before the potential, alpha / beta alone, the momentum tiles before the last GEMM)
-        // cost more in spills than it hid
+        // last GEMM, alpha / beta alone, the momentum tiles before the last GEMM) cost more in spills than it hid
         if constexpr (CK) ck_request<TD, TH, NHL>(kept, ckl);
         if ((l & 1) == 0) coupling_inverse_backward_c<TD, TH, NHL, true, CK>(x, g, L, f.min_scale, log1m, wp, col, half, ckl, kept);
         else coupling_inverse_backward_c<TD, TH, NHL, false, CK>(x, g, L, f.min_scale, log1m, wp, col, half, ckl, kept);
