@@ -12,7 +12,7 @@ from tqdm import tqdm
 
 from .. import hip
 from ..containers import DeviceSampleStore, MCMCOutput, NFMCKernel, NFMCParameters, Sampler
-from .common import Run, chunks, resolve_target
+from .common import Run, chunks, progress, resolve_target
 from .jump import (flow_is_native, flow_mh_supported, imh_parallel_ok, launch_flow_mh, launch_imh_parallel,
                    split_flow_mh)
 
@@ -90,7 +90,7 @@ class FixedIMH(AbstractIMH):
         unlimited = time_limit_seconds is None and not show_progress
         limit = hip.MAX_STEPS_PER_CALL if unlimited else 16
         parallel = fused and imh_parallel_ok(run, flow, pot, logq)
-        bar = tqdm(total=T, desc=self.name, disable=not show_progress)
+        bar = progress(show_progress, total=T, desc=self.name)
         if not fused:
             logq.copy_(flow.log_prob(run.x.reshape(n, *event_shape)).detach().to(run.dev, torch.float32))  # imh.py:214
         while done < T:
@@ -205,7 +205,7 @@ class AdaptiveIMH(AbstractIMH):
         fused = fused and flow_mh_supported(run, flow, pot, logq)
         t0 = time.time()
         done, n_refits = 0, 0
-        bar = tqdm(total=T, desc=self.name, disable=not show_progress)
+        bar = progress(show_progress, total=T, desc=self.name)
         for i in range(T):
             if run.time_is_up(t0, time_limit_seconds):
                 break

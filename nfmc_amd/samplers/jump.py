@@ -20,7 +20,7 @@ from ..containers import (DeviceSampleStore, MCMCKernel, MCMCOutput, MCMCParamet
 from ..flows import Flow, RealNVP
 from ..tuning import train_val_split
 from ..util import metropolis_acceptance_log_ratio
-from .common import Run, chunks, resolve_target
+from .common import Run, chunks, progress, resolve_target
 from .mcmc import HMC, MALA, MH, UHMC, ULA, TargetFailure, _guarded
 
 
@@ -316,7 +316,7 @@ class JumpNFMC(Sampler):
 
         t0 = time.time()
         done = 0
-        bar = tqdm(range(T), desc='Jump MCMC', disable=not show_progress)
+        bar = progress(show_progress, range(T), desc='Jump MCMC')
         for i in bar:
             if run.time_is_up(t0, time_limit_seconds):
                 break

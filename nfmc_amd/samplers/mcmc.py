@@ -20,7 +20,7 @@ from tqdm import tqdm
 from .. import hip
 from ..containers import DeviceSampleStore, MCMCKernel, MCMCOutput, MCMCParameters, Sampler
 from ..tuning import DualAveraging, DualAveragingParams
-from .common import Run, chunks, imd_tensor, resolve_target
+from .common import Run, chunks, imd_tensor, progress, resolve_target
 
 
 @dataclass
@@ -219,7 +219,7 @@ class MCMCSampler(Sampler):
         t0 = time.time()
         done = 0
         label = f'{self.name} (tuning)' if self.params.tuning else self.name
-        bar = tqdm(total=K, desc=label, disable=not show_progress)
+        bar = progress(show_progress, total=K, desc=label)
         stepwise = self.params.tuning or pot is None
         limit = 1 if stepwise else (hip.MAX_STEPS_PER_CALL if time_limit_seconds is None and not show_progress else 32)
         # warmup of a fused sampler on one GPU: kernel state and controller on the device, no host round trip per step

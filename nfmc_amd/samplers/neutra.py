@@ -18,7 +18,7 @@ from tqdm import tqdm
 
 from .. import hip
 from ..containers import DeviceSampleStore, MCMCOutput, NFMCKernel, NFMCParameters, Sampler
-from .common import Run, chunks, imd_tensor, resolve_target
+from .common import Run, chunks, imd_tensor, progress, resolve_target
 from .mcmc import (HMC, MH, HMCKernel, HMCParameters, MHKernel, MHParameters, MetropolisKernel, MetropolisParameters,
                    MetropolisSampler)
 
@@ -168,7 +168,7 @@ class NeuTra(Sampler):
         t0 = time.time()
         done = 0
         limit = hip.MAX_STEPS_PER_CALL if (time_limit_seconds is None and not show_progress) else 4
-        bar = tqdm(total=T, desc='NeuTra HMC', disable=not show_progress)
+        bar = progress(show_progress, total=T, desc='NeuTra HMC')
         while done < T:
             if run.time_is_up(t0, time_limit_seconds):
                 break

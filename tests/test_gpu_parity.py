@@ -1198,6 +1198,24 @@ def test_edge_nonfinite_states_are_rejected_and_counted(dev):
     assert torch.isfinite(last[ok]).all() and out.statistics.n_accepted_trajectories > 0
 
 
+@pytest.mark.parametrize('strategy', ['mala', 'jump_mala', 'imh', 'neutra_hmc'])
+def test_progress_bar_on_and_off_give_the_same_run(dev, strategy):
+    """show_progress=True drives a tqdm bar (and, for the jump samplers, reads the counters every outer step);
+    show_progress=False uses a no-op stand-in.  Same chains either way."""
+    from nfmc_amd import sample
+    outs = []
+    for show in (False, True):
+        torch.manual_seed(3)
+        kw = dict(inner_param_kwargs={'n_iterations': 5}) if strategy == 'jump_mala' else {}
+        if strategy in ('jump_mala', 'imh', 'neutra_hmc'):
+            kw['flow'] = 'realnvp'
+        outs.append(sample(_sumsq, event_shape=(8,), strategy=strategy, n_chains=40, n_iterations=6, show_progress=show,
+                           seed=5, **kw))
+    a, b = outs
+    assert torch.equal(a.samples, b.samples)
+    assert a.statistics.n_accepted_trajectories == b.statistics.n_accepted_trajectories
+
+
 def test_edge_c_abi_argument_errors(dev):
     """Negative status -> ValueError with the library's message; nothing is launched."""
     import ctypes as C
