@@ -8,6 +8,7 @@ Tolerances (fp32 path; kernels contract to FMA and use the gfx950 hardware log/e
   counters           exact, except chains whose |log u - log ratio| < 1e-4 (accept decision ill-conditioned)
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -1952,8 +1953,10 @@ def test_randomized_neutra_and_jump_parity(dev):
     from nfmc_amd.flows import Flow, RealNVP
     from nfmc_amd.potentials import SumOfSquares, Funnel
     from oracle import flow as oflow, potentials as opot, samplers as osamp
-    rng = random.Random(5)
-    for trial in range(24):
+    # NFMC_TEST_SWEEP="<seed>,<trials>" runs a longer sweep from another seed (used after kernel changes)
+    sweep_seed, trials = (int(v) for v in os.environ.get('NFMC_TEST_SWEEP', '5,24').split(','))
+    rng = random.Random(sweep_seed)
+    for trial in range(trials):
         which = rng.choice(['neutra', 'neutra', 'jump_mala', 'jump_hmc'])
         d = rng.choice([2, 5, 12, 33, 64, 64, 100, 128, 128, 150, 200])
         H, cl, nl = rng.choice([3, 8, 16, 32, 40, 64, 128]), rng.choice([1, 2]), rng.choice([1, 2, 3])
