@@ -164,7 +164,8 @@ class NeuTra(Sampler):
         sbytes = int(hip.lib().nfmc_neutra_scratch_bytes(n, d, max(bij.n_hidden, self._min_hidden()), int(st_flow.n_hidden_layers),
                                                          int(st_flow.n_coupling)))
         scratch = torch.empty(max(sbytes // 4, 1), dtype=torch.float32, device=run.dev)
-        self._scratch = scratch   # kept for diagnostics (tools/trace_c4.py reads the marks of a trace build from its tail)
+        if os.environ.get('NFMC_KEEP_SCRATCH'):   # diagnostics only (tools/trace_c4.py reads the marks of a trace build from its tail)
+            self._scratch = scratch
         t0 = time.time()
         done = 0
         limit = hip.MAX_STEPS_PER_CALL if (time_limit_seconds is None and not show_progress) else 4

@@ -9,6 +9,7 @@ begins / inverse sweep done / gradient done, 15 = checkpoint loads + affine back
 Prints, per wave, the segments of ONE gradient in the middle of the trajectory and the totals by segment kind."""
 import os
 import sys
+os.environ['NFMC_KEEP_SCRATCH'] = '1'
 import collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
