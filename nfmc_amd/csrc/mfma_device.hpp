@@ -119,30 +119,43 @@ __device__ __forceinline__ void stage_matrix(float* __restrict__ img, const floa
     // store (8 dependent L2 round trips per 128 x 128 operand, ~10k cycles in which both waves of every SIMD sat idle:
     // the largest single loss of the first version, MFMA pipe busy 59 %).  Loads are issued BATCH at a time before
     // the first store.
+    // Index arithmetic once per call, in unsigned 32 bits: the staging threads are a whole number of image rows
+    // (kStagers % k4 == 0), so a thread keeps its column and walks down RSTEP rows per piece -- the global offset and
+    // the LDS offset of piece j are the thread's base plus a compile-time constant.  (With signed `idx / k4`,
+    // `idx % k4` and 64-bit addresses per piece the copy cost ~16 VALU instructions per 16-byte piece: more VALU work
+    // per gradient on the staging waves than all the elementwise epilogues together.)
+    static_assert(kStagers % k4 == 0, "staging threads cover whole rows");
+    constexpr uint32_t RSTEP = kStagers / k4;
+    const uint32_t t = (uint32_t)tid;
+    const uint32_t c = (t % (uint32_t)k4) << 2, r0 = t / (uint32_t)k4;          // r0 < RSTEP
+    const uint32_t g0 = r0 * (uint32_t)K + c;
+    uint32_t cc = c;
+    if (rev_cols) cc = (c / CBLK) * CBLK + (CBLK - 4 - (c % CBLK));
 #pragma unroll
     for (int b0 = 0; b0 < IT; b0 += BATCH) {
         f32x4 v[BATCH];
 #pragma unroll
-        for (int b = 0; b < BATCH; ++b) {
-            const int idx = tid + (b0 + b) * kStagers;
-            v[b] = *reinterpret_cast<const f32x4*>(W + (size_t)(idx / k4) * K + ((idx % k4) << 2));
-        }
+        for (int b = 0; b < BATCH; ++b) v[b] = *reinterpret_cast<const f32x4*>(W + (g0 + (uint32_t)((b0 + b) * RSTEP * K)));
 #pragma unroll
         for (int b = 0; b < BATCH; ++b) {
-            const int idx = tid + (b0 + b) * kStagers;
-            const int r = idx / k4, c = (idx % k4) << 2;
-            const int rr = rev_rows ? (r / RBLK) * RBLK + (RBLK - 1 - (r % RBLK)) : r;
-            if (!rev_cols) {
-                *reinterpret_cast<f32x4*>(img + rr * ld + c) = v[b];
+            constexpr uint32_t kR = RBLK;
+            const uint32_t rj = (uint32_t)(b0 + b) * RSTEP;                        // compile-time after unrolling
+            uint32_t rr;
+            if constexpr (kR % RSTEP == 0) {
+                // reversal inside blocks of RBLK rows: (rj + r0) % RBLK = rj % RBLK + r0 (no carry: r0 < RSTEP | RBLK)
+                rr = rev_rows ? (rj / kR) * kR + (kR - 1 - (rj % kR)) - r0 : rj + r0;
             } else {
-                const int cc = (c / CBLK) * CBLK + (CBLK - 4 - (c % CBLK));
-                f32x4 w;
+                const uint32_t r = rj + r0;
+                rr = rev_rows ? (r / kR) * kR + (kR - 1 - (r % kR)) : r;
+            }
+            f32x4 w = v[b];
+            if (rev_cols) {
                 w[0] = v[b][3];
                 w[1] = v[b][2];
                 w[2] = v[b][1];
                 w[3] = v[b][0];
-                *reinterpret_cast<f32x4*>(img + rr * ld + cc) = w;
             }
+            *reinterpret_cast<f32x4*>(img + (rr * (uint32_t)ld + cc)) = w;
         }
     }
 }
