@@ -135,7 +135,10 @@ __device__ __forceinline__ void stage_matrix(float* __restrict__ img, const floa
     for (int b0 = 0; b0 < IT; b0 += BATCH) {
         f32x4 v[BATCH];
 #pragma unroll
-        for (int b = 0; b < BATCH; ++b) v[b] = *reinterpret_cast<const f32x4*>(W + (g0 + (uint32_t)((b0 + b) * RSTEP * K)));
+        for (int b = 0; b < BATCH; ++b) {   // 32-bit BYTE offset from the uniform base: scalar-base addressing, one add per piece
+            const uint32_t gb = (g0 << 2) + (uint32_t)((b0 + b) * RSTEP * K * 4);
+            v[b] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(W) + gb);
+        }
 #pragma unroll
         for (int b = 0; b < BATCH; ++b) {
             constexpr uint32_t kR = RBLK;
