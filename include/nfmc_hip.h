@@ -326,7 +326,7 @@ typedef struct {
 
 /* 0 for the VALU path (n_hidden <= 32).  Matrix-core path: 2 (n, d) tiles + 2 (n,) vectors, plus the activation
  * checkpoints of the resident workgroups (hidden activations, alpha, beta of every coupling layer: the reverse sweep
- * reads them back instead of recomputing them) -- at most 512 workgroups x 128 chains, whatever n. */
+ * reads them back instead of recomputing them) -- at most 256 workgroups x 128 chains, whatever n. */
 int64_t nfmc_neutra_scratch_bytes(int64_t n, int32_t d, int32_t n_hidden, int32_t n_hidden_layers, int32_t n_coupling);
 
 int nfmc_neutra_hmc_steps_f32(const NfmcNeutraHmcArgs* args, nfmc_stream_t stream);

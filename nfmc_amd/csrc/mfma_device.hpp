@@ -60,7 +60,10 @@ constexpr int kStageThreads = kMfmaBlock;
 #else
 constexpr int kStageThreads = kMfmaBlock / 2;
 #endif
-constexpr int kCkMaxGrid = 512;                  // workgroup slots of the NeuTra trajectory kernel (2 per CU); more chain tiles grid-stride
+#ifndef NFMC_CK_MAX_GRID
+#define NFMC_CK_MAX_GRID 256
+#endif
+constexpr int kCkMaxGrid = NFMC_CK_MAX_GRID;     // workgroup slots of the NeuTra trajectory kernel (1 per CU: 256 vs 512 measured +0.7 %, half the scratch); more chain tiles grid-stride
 
 struct MLayer {
     const float *W1, *W1T, *b1, *Wh, *WhT, *bh, *W3, *W3T, *b3;

@@ -186,9 +186,9 @@ def test_C4_neutra_hmc_65536x128_full_size_properties(dev):
 
 
 def test_C4_more_chain_tiles_than_workgroup_slots(dev):
-    """The trajectory kernel runs at most 512 workgroups (one activation-checkpoint area per workgroup slot and wave,
-    mfma_flow.hpp: CkLayout); with more than 512 x 128 chains a workgroup walks several chain tiles and reuses its
-    area.  70000 chains = 547 tiles: every chain must end where the same chain ends in a run that holds only its own
+    """The trajectory kernel runs at most 256 workgroups (one activation-checkpoint area per workgroup slot and wave,
+    mfma_flow.hpp: CkLayout); with more than 256 x 128 chains a workgroup walks several chain tiles and reuses its
+    area.  70000 chains = 547 tiles (two or three per workgroup): every chain must end where the same chain ends in a run that holds only its own
     128-chain tile neighbourhood (chain-id keyed noise), bit for bit, and the counters must cover all chains."""
     from nfmc_amd.dist import Shard
     d, n, T, L, h = 128, 70000, 1, 10, 0.02
@@ -207,7 +207,7 @@ def test_C4_more_chain_tiles_than_workgroup_slots(dev):
     full = run()
     la = full.running_samples.last_sample
     assert torch.isfinite(la).all() and full.statistics.n_attempted_trajectories == n * T
-    for rank in (0, 7):      # the first tiles and the tiles past the 512th
+    for rank in (0, 4, 7):   # first, second and third tiles of the workgroups
         sh = Shard(rank=rank, world=8)
         sh.merge_statistics = lambda s_: s_
         lo, hi = sh.bounds(n)

@@ -29,13 +29,13 @@ def test_library_exports_every_declared_symbol():
     assert hip.lib().nfmc_realnvp_padded_hidden(5) == 8 and hip.lib().nfmc_realnvp_padded_hidden(100) == 128
     assert hip.lib().nfmc_realnvp_layer_floats(64, 4, 2) == 32 * 4 + 4 + 16 + 4 + 64 * 4 + 64
     # NeuTra scratch of the matrix-core path: momentum + gradient (n, d), U~ + H0 (n,), and one activation-checkpoint
-    # area per resident (workgroup slot <= 512, wave) of 24 KB per coupling layer at d = 128, H = 128 x 2 -- bounded in n
+    # area per resident (workgroup slot <= 256, wave) of 24 KB per coupling layer at d = 128, H = 128 x 2 -- bounded in n
     sb = hip.lib().nfmc_neutra_scratch_bytes
     assert sb(1000, 64, 8, 2, 2) == 0                                        # VALU path: no scratch
-    assert sb(65536, 128, 128, 2, 2) == 4 * (2 * 65536 * 128 + 2 * 65536 + 512 * 8 * 2 * 24 * 256)
+    assert sb(65536, 128, 128, 2, 2) == 4 * (2 * 65536 * 128 + 2 * 65536 + 256 * 8 * 2 * 24 * 256)
     assert sb(128, 128, 128, 2, 2) == 4 * (2 * 128 * 128 + 2 * 128 + 1 * 8 * 2 * 24 * 256)
     assert sb(10 ** 6, 128, 128, 2, 2) - sb(65536, 128, 128, 2, 2) == 4 * (10 ** 6 - 65536) * (2 * 128 + 2)
-    assert sb(65536, 64, 40, 1, 3) == 4 * (2 * 65536 * 64 + 2 * 65536 + 512 * 8 * 3 * (4 + 4) * 256)   # H = 40 -> 64: 4 + 4 tiles
+    assert sb(65536, 64, 40, 1, 3) == 4 * (2 * 65536 * 64 + 2 * 65536 + 256 * 8 * 3 * (4 + 4) * 256)   # H = 40 -> 64: 4 + 4 tiles
 
 
 def test_struct_sizes_match_the_header():
