@@ -26,17 +26,26 @@ step, so it is not one of the R).
 
 roofline.  The dominant kernel of C3 is `mala_kernel`: it keeps the state in VGPRs for the 100 transitions of a
 launch, so its HBM traffic is ~1 % of the per-transition algorithmic bytes of SURVEY 8d and the roof that BINDS is
-VALU issue (Philox4x32-10 + Box-Muller + the MALA arithmetic).  So:
+the fp32 vector pipe (Philox4x32-10 + Box-Muller + the MALA arithmetic).  So:
   bound     "valu"
-  achieved  VALU wave-instructions per second = SQ_INSTS_VALU per launch (committed rocprofv3 --pmc pass of this
-            same command, profiles/) / mean launch duration measured live here with HIP events on the launch stream
-  peak      1024 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction = 614.4 G wave-inst/s (the rate behind the
-            157.3 TFLOP/s fp32 vector peak of MI355X_MICROARCH.md, which counts packed FMAs: 2 x 2 flop per lane)
-  frac      achieved / peak  (<= 1)
-  hbm_algorithmic   SURVEY 8d's 8*d bytes per chain-transition x transitions per launch / launch time vs 8 TB/s --
-                    can exceed 1 for a kernel that fuses K transitions per launch; reported, not the bound
-  hbm_real_frac     PMC-measured HBM bytes per launch / launch time / 8 TB/s
-  flops_algorithmic SURVEY 8d's 30*d flop per MALA transition vs the 157.3 TFLOP/s vector peak
+  achieved  ALGORITHMIC TFLOP/s: SURVEY 8d's flops per chain-transition (30*d for a Gaussian MALA step; `algorithmic_flops`
+            below states the figure of every config) x the chain-transitions of one launch / the mean launch duration
+            measured live here with HIP events on the launch stream
+  peak      157.3 TFLOP/s, the fp32 vector peak of MI355X_MICROARCH.md (1024 SIMD-32 x 32 lanes x 2 flop x 2.4 GHz:
+            one wave64 `v_fma_f32` per SIMD every 2 cycles, no packing)
+  frac      achieved / peak
+  valu_issue          VALU wave-instructions per second (SQ_INSTS_VALU per launch from the committed rocprofv3 --pmc
+                      pass of this same command / live launch time) vs 1024 SIMDs x 2.4 GHz / 2 cycles = 1228.8 G/s
+  valu_cost_weighted  the same instructions priced by class: sum over the PMC instruction classes (ADD/MUL/FMA/TRANS_F32,
+                      INT32, INT64, CVT, other) of count x the measured issue time of that class on gfx950
+                      (tools/ubench.hip, profiles/r03_instruction_cost_ubench.txt), / 1024 SIMDs / launch time: the
+                      share of the launch that is pure issue of THIS instruction mix (1 = nothing left but a cheaper mix)
+  valu_busy_frac_pmc  SQ_ACTIVE_INST_VALU / 4 per CU vs GRBM_GUI_ACTIVE: the pipe's own busy counter
+  hbm_algorithmic     SURVEY 8d's 8*d bytes per chain-transition x transitions per launch / launch time vs 8 TB/s --
+                      can exceed 1 for a kernel that fuses K transitions per launch; reported, not the bound
+  hbm_real_frac       PMC-measured HBM bytes per launch / launch time / 8 TB/s
+  pmc_stale           true when the committed PMC summary was profiled on another build of the library than the one
+                      loaded now (source digests differ): the counter-derived fields are then from other code
 C4's dominant kernel (`neutra_leapfrog_mfma_kernel`) is bound by fp32 MFMA: achieved TFLOP/s of conditioner GEMMs
 (sustained: measured over the whole timed region; flops = the algorithm's minimum, C4_MACS_PER_GRADIENT) vs 157.3.
 
@@ -63,7 +72,16 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0
 FP32_PEAK_TFLOPS = 157.3
-VALU_PEAK_GINST = 1024 * 2.4 / 4.0   # G wave64-instructions / s: 256 CUs x 4 SIMDs, 4 cycles per instruction, 2.4 GHz
+# G wave64-instructions / s: 256 CUs x 4 SIMD-32, one wave64 VALU instruction per 2 cycles (MI355X_MICROARCH.md: `v_fma_f32`
+# wave64 = 2 cycles of throughput, the rate behind the 157.3 TFLOP/s vector peak), 2.4 GHz
+VALU_PEAK_GINST = 1024 * 2.4 / 2.0
+N_SIMD = 1024
+# issue time per wave-instruction and SIMD at full occupancy on gfx950, ns, by PMC instruction class
+# (profiles/r03_instruction_cost_ubench.txt, tools/ubench.hip; the class's representative instructions in the sampler
+# kernels: v_add_f32 / v_mul_f32 / v_fma(c)_f32 / v_log,v_sqrt,v_sin,v_cos,v_exp,v_rcp / v_bitop3,v_add_u32,v_and_or /
+# v_mad_u64_u32 / v_cvt_f32_u32 / v_cndmask (VOP3), v_mov, DPP moves)
+CLASS_NS = {'ADD_F32': 1.17, 'MUL_F32': 0.96, 'FMA_F32': 1.45, 'TRANS_F32': 3.40, 'INT32': 1.68, 'INT64': 2.08,
+            'CVT': 1.76, 'OTHER': 1.80}
 
 # ---------------------------------------------------------------------------------------------------- workloads
 CONFIGS = {
@@ -335,23 +353,64 @@ def rehearse(args, rank, world):
 
 # ---------------------------------------------------------------------------------------------------- measurement
 def _pmc(cfg_name, kernel):
-    """Per-launch counter means of the dominant kernel from the committed rocprofv3 --pmc passes of this command."""
-    for name in ('r02_%s_pmc_summary.json' % cfg_name.lower(), 'r02_bench_pmc_summary.json', 'r01_bench_pmc_summary.json'):
+    """Per-launch counter means of the dominant kernel from the committed rocprofv3 --pmc passes of this command, the
+    summary's file name, and whether it is STALE: profiled on a library whose source digest (`nfmc_build_digest()`)
+    differs from the one loaded now (None: the summary predates the digest)."""
+    from nfmc_amd import hip
+    for name in ('r03_%s_pmc_summary.json' % cfg_name.lower(), 'r02_%s_pmc_summary.json' % cfg_name.lower(),
+                 'r02_bench_pmc_summary.json', 'r01_bench_pmc_summary.json'):
         p = os.path.join(ROOT, 'profiles', name)
         if os.path.exists(p):
             try:
-                pm = json.load(open(p)).get(kernel)
+                doc = json.load(open(p))
+                pm = doc.get(kernel)
             except Exception:
-                pm = None
+                doc, pm = {}, None
             if pm:
-                return pm, 'profiles/' + name
-    return None, None
+                dig = (doc.get('_meta') or {}).get('library_digest')
+                stale = (dig != hip.build_digest()) if dig else None
+                return pm, 'profiles/' + name, stale
+    return None, None, None
+
+
+def algorithmic_flops(cfg):
+    """ALGORITHMIC flops per chain-transition of the dominant kernel's work ('ALGORITHMIC flops per
+    chain-step'), per config.  d = event size.
+      jump_mala  Gaussian MALA step: 30*d (SURVEY's figure: proposal, two potentials + gradients, two proposal densities).
+      jump_hmc   one HMC trajectory on U = sum x^2 (hmc.py:61-77,96-126): per leapfrog two gradient evaluations (d
+                 multiplies each) + three axpys (2d each) = 8d; two Hamiltonians (U: 2d, kinetic: 3d each) = 10d; the
+                 momentum draw's scaling d  ->  (8 L + 11) * d, L = 20.
+      imh        one independence-MH transition: a RealNVP inverse pass, L_c * 2 * (d_a H + (n_hl - 1) H^2 + 2 H d_b) + 10 d
+                 (SURVEY's 'RealNVP pass', default flow at d = 64: L_c = 2, H = 4, n_hl = 2), + U(x') 2d + base density 2d."""
+    d, st = cfg['d'], cfg['strategy']
+    if st == 'jump_mala':
+        return 30.0 * d
+    if st == 'jump_hmc':
+        return (8.0 * 20 + 11.0) * d
+    if st == 'imh':
+        da, db, H, nhl, lc = d // 2, d - d // 2, 4, 2, 2
+        return lc * 2.0 * (da * H + (nhl - 1) * H * H + 2 * H * db) + 10.0 * d + 4.0 * d
+    return None
+
+
+def _cost_weighted(pm, secs):
+    """Share of the launch that is pure issue of the kernel's own instruction mix: per-class counts (PMC) x measured
+    issue time per class (CLASS_NS) / 1024 SIMDs / launch time."""
+    keys = ['ADD_F32', 'MUL_F32', 'FMA_F32', 'TRANS_F32', 'INT32', 'INT64', 'CVT']
+    if not (pm and secs and all(('SQ_INSTS_VALU_' + k) in pm for k in keys) and pm.get('SQ_INSTS_VALU')):
+        return None
+    counts = {k: pm['SQ_INSTS_VALU_' + k] for k in keys}
+    counts['OTHER'] = max(0.0, pm['SQ_INSTS_VALU'] - sum(counts.values()))
+    ns = sum(counts[k] * CLASS_NS[k] for k in counts) / N_SIMD
+    return {'wave_insts_per_launch_by_class': counts, 'ns_per_wave_inst_by_class': CLASS_NS,
+            'issue_ms_per_launch': ns * 1e-6, 'frac_of_launch': ns * 1e-9 / secs,
+            'mean_ns_per_wave_inst': ns * N_SIMD / pm['SQ_INSTS_VALU']}
 
 
 def roofline(cfg_name, cfg, n_local, mean_ms, launches, transitions_per_launch):
-    pm, src = _pmc(cfg_name, cfg['kernel'])
+    pm, src, stale = _pmc(cfg_name, cfg['kernel'])
     d = cfg['d']
-    r = {'kernel': cfg['kernel'], 'mean_launch_ms': mean_ms, 'launches': launches, 'pmc_source': src}
+    r = {'kernel': cfg['kernel'], 'mean_launch_ms': mean_ms, 'launches': launches, 'pmc_source': src, 'pmc_stale': stale}
     secs = mean_ms * 1e-3 if mean_ms else None
     traffic = None
     if pm and 'FETCH_SIZE' in pm and 'WRITE_SIZE' in pm:
@@ -362,6 +421,7 @@ def roofline(cfg_name, cfg, n_local, mean_ms, launches, transitions_per_launch):
         r.update(bound='mfma', achieved=ach, peak=FP32_PEAK_TFLOPS, unit='TFLOP/s',
                  frac=(ach / FP32_PEAK_TFLOPS) if ach else None, traffic=traffic,
                  algorithmic_flops_per_launch=flops,
+                 hbm_real_frac=(traffic / secs / 1e9 / HBM_PEAK_GBS) if (traffic and secs) else None,
                  note='mean over EVERY launch of the timed repetitions (sustained clocks, not a from-idle burst); one '
                       'event pair brackets a whole nfmc_neutra_hmc_steps_f32 call (K trajectory launches + one '
                       'gradient launch + K statistics folds), so the per-launch mean is <= 2 % pessimistic')
@@ -370,28 +430,35 @@ def roofline(cfg_name, cfg, n_local, mean_ms, launches, transitions_per_launch):
         return r
     per_launch_transitions = n_local * transitions_per_launch
     alg_bytes = (8 * d + (8 if cfg['strategy'] == 'imh' else 0)) * per_launch_transitions
+    fl = algorithmic_flops(cfg) * per_launch_transitions
+    ach = fl / secs / 1e12 if secs else None
     insts = pm.get('SQ_INSTS_VALU') if pm else None
-    if insts and cfg['strategy'] == 'imh':
+    scale = 1.0
+    if pm and cfg['strategy'] == 'imh':
         # one nfmc_imh_parallel_f32 call covers ALL steps of a run: the PMC passes (tools/profile_bench.sh: --steps 3)
         # counted 3 * 50 transitions per call, the live call has transitions_per_launch of them
-        insts = insts * transitions_per_launch / (PMC_STEPS * cfg['inner'])
-    ach = insts / secs / 1e9 if (insts and secs) else None
-    r.update(bound='valu', achieved=ach, peak=VALU_PEAK_GINST, unit='G wave-inst/s',
-             frac=(ach / VALU_PEAK_GINST) if ach else None, traffic=traffic,
-             valu_wave_insts_per_launch=insts,
-             valu_insts_per_coordinate_transition=(insts * 64 / (per_launch_transitions * d)) if insts else None,
+        scale = transitions_per_launch / (PMC_STEPS * cfg['inner'])
+        pm = {k: (v * scale if isinstance(v, (int, float)) and k.startswith('SQ_INSTS') else v) for k, v in pm.items()}
+        insts = pm.get('SQ_INSTS_VALU')
+    issue = insts / secs / 1e9 if (insts and secs) else None
+    r.update(bound='valu', achieved=ach, peak=FP32_PEAK_TFLOPS, unit='TFLOP/s',
+             frac=(ach / FP32_PEAK_TFLOPS) if ach else None, traffic=traffic,
+             algorithmic_flops_per_launch=fl, algorithmic_flops_per_chain_transition=algorithmic_flops(cfg),
+             valu_issue={'achieved_G_wave_inst_per_s': issue, 'peak_G_wave_inst_per_s': VALU_PEAK_GINST,
+                         'frac': (issue / VALU_PEAK_GINST) if issue else None,
+                         'wave_insts_per_launch': insts,
+                         'insts_per_coordinate_transition': (insts * 64 / (per_launch_transitions * d)) if insts else None},
+             valu_cost_weighted=_cost_weighted(pm, secs),
              hbm_algorithmic={'bytes_per_launch': alg_bytes,
                               'achieved_GBps': alg_bytes / secs / 1e9 if secs else None,
                               'frac_of_8TBps': alg_bytes / secs / 1e9 / HBM_PEAK_GBS if secs else None},
              hbm_real_frac=(traffic / secs / 1e9 / HBM_PEAK_GBS) if (traffic and secs) else None,
              note='state stays in VGPRs for the transitions of a launch: HBM traffic << algorithmic bytes; the kernel is '
-                  'bound by VALU issue (generator + transition arithmetic); peak = 1024 SIMDs x 2.4 GHz / 4 cycles')
+                  'bound by the fp32 vector pipe, and most of its instructions are the noise generator (integer multiplies, '
+                  'bit ops, transcendentals), which the algorithmic flop count does not contain: frac = algorithmic flops '
+                  '/ 157.3 TF; valu_issue.frac = wave-instructions / (1024 SIMDs x 2.4 GHz / 2 cycles)')
     if pm and pm.get('SQ_ACTIVE_INST_VALU') and pm.get('GRBM_GUI_ACTIVE'):
         r['valu_busy_frac_pmc'] = (pm['SQ_ACTIVE_INST_VALU'] / 256) / (pm['GRBM_GUI_ACTIVE'] / 8)
-    if cfg['strategy'] == 'jump_mala' and secs:
-        fl = 30.0 * d * per_launch_transitions
-        r['flops_algorithmic'] = {'flop_per_launch': fl, 'achieved_TFLOPs': fl / secs / 1e12,
-                                  'frac_of_fp32_vector_peak': fl / secs / 1e12 / FP32_PEAK_TFLOPS}
     return r
 
 

@@ -385,6 +385,9 @@ typedef struct {
 
 int nfmc_limits(NfmcLimits* out);
 const char* nfmc_error_string(int code);
+/* sha256 (hex) of the sources and flags this library was built from (nfmc_amd/build.py: _digest): profiles record it
+ * so that counter-derived figures can be tied to the code that was measured.  Static storage; never NULL. */
+const char* nfmc_build_digest(void);
 
 #ifdef __cplusplus
 }

@@ -73,6 +73,15 @@ def build(force=False, verbose=True):
         print('[nfmc_amd.build] compiling %d translation units for gfx950' % len(srcs), flush=True)
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
         objs = list(ex.map(_compile, srcs))
+    # the library reports the digest of what it was built from (nfmc_build_digest): generated unit, not part of the digest
+    dsrc = os.path.join(OBJ, 'build_digest.cpp')
+    with open(dsrc, 'w') as fh:
+        fh.write('extern "C" const char* nfmc_build_digest(void) { return "%s"; }\n' % dig)
+    dobj = os.path.join(OBJ, 'build_digest.o')
+    r = subprocess.run([HIPCC, '-O1', '-fPIC', '-c', dsrc, '-o', dobj], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError('hipcc failed for build_digest.cpp:\n' + r.stderr[-2000:])
+    objs.append(dobj)
     cmd = [HIPCC, '-shared', '-fPIC', '--offload-arch=gfx950', '-o', LIB] + objs
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:

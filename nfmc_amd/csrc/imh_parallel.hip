@@ -187,7 +187,10 @@ __global__ void __launch_bounds__(256) imh_scan_kernel(NfmcFlowMhArgs a, ImhWork
                 acc_total++;
                 start = j + 1;
             }
-            if (valid) w.dwell[r] = dw;   // 0: rejected, or still the state at the end of the window (patched later by lane 0)
+            // single writer per element: the proposal that is still the state at the end of the window gets its dwell time
+            // from lane 0 later (a later window's `else` branch above, or the tail below); every other element of the
+            // window -- rejected (0) or accepted and replaced inside it (dw) -- is written here, one coalesced store
+            if (valid && !(cur >= base && lane == cur - base)) w.dwell[r] = dw;
         }
         if (lane == 0) {
             if (cur < 0) w.dwell0[i] = k;

@@ -148,7 +148,11 @@ __global__ void __launch_bounds__(kFinishBlock) tune_finish_kernel(double* __res
         const double beta = tn.state[NFMC_TUNE_IMD_ADJUSTMENT];
         for (int j = threadIdx.x; j < d; j += kFinishBlock) {
             const double sx = totals[j], sxx = totals[dp + j];
-            const double var = (sxx - sx * sx / n_tot) / (n_tot - 1.0);           // torch.var: unbiased
+            // torch.var (unbiased) from one-pass sums: for chains far from the origin relative to their spread the
+            // subtraction cancels (fp32 per-lane partials of x^2), so the result is held at >= 0 -- the next launch takes
+            // 1 / inv_mass_diag^2 and its square root
+            double var = (sxx - sx * sx / n_tot) / (n_tot - 1.0);
+            var = var > 0.0 ? var : 0.0;
             tn.inv_mass_diag[j] = (float)(beta * var + (1.0 - beta) * (double)tn.inv_mass_diag[j]);
         }
     }

@@ -21,6 +21,7 @@ MAX_STEPS_PER_CALL = 512
 IMH_PARALLEL_MAX_STEPS = 65536
 
 c_fp = C.c_void_p  # all device pointers travel as void*
+NFMC_ABI_VERSION = 2   # include/nfmc_hip.h
 
 
 class NfmcPotential(C.Structure):
@@ -138,6 +139,7 @@ SYMBOLS = [
     ('nfmc_philox_uniforms_f32', C.c_int, [C.POINTER(NfmcRng), C.c_int32, C.c_int64, c_fp, c_fp]),
     ('nfmc_limits', C.c_int, [C.POINTER(NfmcLimits)]),
     ('nfmc_error_string', C.c_char_p, [C.c_int]),
+    ('nfmc_build_digest', C.c_char_p, []),
 ]
 
 _lib = None
@@ -152,6 +154,17 @@ def lib():
                 'nfmc_amd: %s is missing. Build it with `python -m nfmc_amd.build` (needs hipcc); the MI355X '
                 'path has no CPU/eager fallback.' % LIB_PATH)
         handle = C.CDLL(LIB_PATH)
+        # the structs below are ABI version NFMC_ABI_VERSION: a stale or side-built library (NFMC_LIB, tools/ab_*.sh
+        # variants) under them would read pointers at the wrong offsets -- refuse it before binding anything else
+        probe = getattr(handle, 'nfmc_limits', None)
+        if probe is None:
+            raise RuntimeError('nfmc_amd: %s does not export nfmc_limits (not an nfmc_hip library?)' % LIB_PATH)
+        probe.restype, probe.argtypes = C.c_int, [C.POINTER(NfmcLimits)]
+        lim = NfmcLimits()
+        rc = probe(C.byref(lim))
+        if rc != 0 or lim.abi_version != NFMC_ABI_VERSION:
+            raise RuntimeError('nfmc_amd: %s has ABI version %d (status %d); this package binds version %d. Rebuild it '
+                               'with `python -m nfmc_amd.build --force`.' % (LIB_PATH, lim.abi_version, rc, NFMC_ABI_VERSION))
         for name, restype, argtypes in SYMBOLS:
             fn = getattr(handle, name)
             fn.restype = restype
@@ -214,6 +227,11 @@ def stream():
     if _raw_stream is not None:
         return C.c_void_p(_raw_stream(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def build_digest():
+    """Source digest the loaded library was built from (nfmc_build_digest)."""
+    return lib().nfmc_build_digest().decode()
 
 
 def limits():

@@ -133,6 +133,7 @@ def sample(target: Union[callable, Potential],
       rng_rounds  10 (default): Philox4x32-10, the library's noise stream.  7: Philox4x32-7 -- an opt-in stream (the fewest
              rounds Random123 reports as passing BigCrush) with 30 % fewer generator instructions, available on the exact-fit
              kernels of mala / hmc / jump_* with a closed-form quadratic target; other launches raise ValueError.
+             Warmup (tuning) launches always draw from the 10-round stream, with the device- and the host-side controller alike.
       fuse   'auto' (default): a plain callable `target` that probing reproduces exactly as
              U = sum_j a_j (x_j - b_j)^2 + c (potentials.recognize: an inference from finitely many evaluations,
              logged once) is evaluated in closed form inside the HIP kernels; 'never' / False: always call the Python

@@ -225,10 +225,14 @@ class MCMCSampler(Sampler):
         # warmup of a fused sampler on one GPU: kernel state and controller on the device, no host round trip per step
         # (sharded chains keep the host controller: its statistics are all-reduced over the ranks every step)
         tune = None
+        if self.params.tuning:
+            # warmup ALWAYS draws from the default Philox4x32-10 stream, whichever controller runs (device, host,
+            # sharded): tuning launches use the general kernels, which carry that stream only, and a warmup must not
+            # depend on where its controller lives.  `rng_rounds=7` applies to the sampling launches (documented on sample())
+            run.rounds = 10
         if (self.params.tuning and pot is not None and isinstance(self, MetropolisSampler)
                 and (run.shard is None or run.shard.world == 1) and os.environ.get('NFMC_TUNE_DEVICE', '1') != '0'):
             tune = DeviceTuning(self, run)
-            run.rounds = 10   # warmup launches run on the general kernels, which carry the default stream only
             # one ABI call enqueues every (kernel, controller) pair of up to 512 transitions: no host work per update
             tune.every = max(1, int(getattr(self.params, 'tune_every', 1)))
             limit = hip.MAX_STEPS_PER_CALL if time_limit_seconds is None and not show_progress else max(32, tune.every)

@@ -39,6 +39,150 @@ def _agreeing(got, want, tol):
     return err < tol
 
 
+# ================================================================================================ C1
+def test_C1_readme_call_shape_moments_and_oracle(dev):
+    """configs[0] (README.md:33-58, test/test_samplers.py:139-144): `sample(lambda x: sum x^2, event_shape=(25,),
+    strategy='jump_mala', flow='realnvp', n_chains=100, n_iterations=200)` -- a plain Python lambda as the target,
+    the default inner K = 100 (sampling/base.py:31), step 25^(-1/3): samples of shape (200 * 101, 100, 25), finite,
+    moments of N(0, I/2); and T = 2 of the same call (same x0, same default flow weights) transition by transition
+    against `oracle.samplers.jump_sample` on the Philox stream (jump.py:156-246 over langevin.py:61-122)."""
+    from nfmc_amd import sample
+    from oracle import flow as oflow, potentials as opot, samplers as osamp
+    d, n, T, K = 25, 100, 200, 100
+
+    def target(x):
+        return torch.sum(x ** 2, dim=1)
+
+    torch.manual_seed(0)
+    out = sample(target, event_shape=(d,), strategy='jump_mala', flow='realnvp', n_chains=n, n_iterations=T,
+                 show_progress=False, seed=0)
+    assert out.samples.shape == (T * (K + 1), n, d)
+    assert torch.isfinite(out.samples).all()
+    st = out.statistics
+    assert st.n_attempted_trajectories == n * T * K and st.n_attempted_jumps == n * T
+    assert st.n_target_calls == 2 * n * T * K + 2 * n * T and st.n_target_gradient_calls == 2 * n * T * K
+    # 2.02e6 correlated draws per coordinate (MALA at h = 0.342 in d = 25 accepts ~0.5): the sample variance of the mean
+    # is ~1e-3 .. 2e-3 per coordinate
+    assert float(out.mean.abs().max()) < 2e-2
+    np.testing.assert_allclose(out.variance.numpy(), 0.5, rtol=4e-2)
+    np.testing.assert_allclose(out.second_moment.numpy(), 0.5, rtol=4e-2)
+    assert 0.2 < st.acceptance_rate < 0.9
+    # the stored states themselves carry the same moments as the device sums
+    np.testing.assert_allclose(out.samples.mean(dim=(0, 1)).numpy(), out.mean.numpy(), atol=2e-4)
+    # T = 2 of the same call against the oracle, default-initialised flow (weights of torch.manual_seed(1) on both sides)
+    T2, seed = 2, 31
+    torch.manual_seed(1)
+    of = oflow.Flow(oflow.RealNVP((d,)))
+    x0 = torch.randn(n, d, generator=torch.Generator().manual_seed(2))
+    torch.manual_seed(1)
+    got = sample(target, event_shape=(d,), strategy='jump_mala', flow='realnvp', x0=x0, n_iterations=T2,
+                 show_progress=False, seed=seed)
+    tr = osamp.jump_sample(x0, opot.sum_squares, of, 'langevin', T2, K, d ** (-1 / 3), noise=osamp.PhiloxNoise(seed))
+    a, b = got.samples.reshape(T2 * (K + 1), n, d), tr.stacked()
+    same = _agreeing(a, b, 3e-4)
+    assert same.float().mean() > 0.9, float(same.float().mean())
+    np.testing.assert_allclose(a[:, same].numpy(), b[:, same].numpy(), atol=3e-4, rtol=0)
+    assert abs(got.statistics.n_accepted_trajectories - tr.n_accepted) <= 0.01 * n * T2 * K
+    assert abs(got.statistics.n_accepted_jumps - tr.n_accepted_jumps) <= 3
+
+
+# ================================================================================================ C2
+def _c2_flows(d=64):
+    """configs[1]'s flow: the DEFAULT RealNVP (conditioner width max(4, int(3 log10 32)) = 4, two couplings) with the
+    bench's proposal-scale match (bench.py: _match_scale_), so that the independence sampler accepts (~0.6)."""
+    import bench
+    from nfmc_amd.flows import Flow, RealNVP
+    from oracle import flow as oflow
+    torch.manual_seed(1)
+    of = bench._match_scale_(oflow.Flow(oflow.RealNVP((d,))))
+    f = Flow(RealNVP((d,)))
+    f.load_state_dict(of.state_dict())
+    return of, f
+
+
+def test_C2_imh_d64_default_flow_matches_oracle(dev, monkeypatch):
+    """configs[1] at n = 256, T = 50: strategy 'imh' (FixedIMH, imh.py:200-255), U = sum x^2, d = 64, default RealNVP
+    through `nfmc_imh_parallel_f32` (the test fails if another route is taken) against `oracle.samplers.imh_sample` on
+    the same Philox streams: every stored state of every chain that made the oracle's accept decisions."""
+    from nfmc_amd.potentials import SumOfSquares
+    from nfmc_amd.samplers import imh, jump
+    from oracle import potentials as opot, samplers as osamp
+    d, n, T, seed = 64, 256, 50, 909
+    of, f = _c2_flows(d)
+    assert f.bijection.n_hidden == 4 and f.bijection.n_coupling == 2   # the default architecture at d = 64
+    x0 = torch.randn(n, d, generator=torch.Generator().manual_seed(0))
+    calls = []
+    orig = jump.launch_imh_parallel
+    monkeypatch.setattr(imh, 'launch_imh_parallel', lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+    monkeypatch.setattr(imh, 'launch_flow_mh', lambda *a, **k: (_ for _ in ()).throw(AssertionError('sequential kernel')))
+    s = imh.FixedIMH((d,), SumOfSquares((d,)), imh.IMHKernel((d,), flow=f), imh.IMHParameters(n_iterations=T))
+    s.seed = seed
+    out = s.sample(x0, show_progress=False)
+    assert calls, 'nfmc_imh_parallel_f32 did not run'
+    tr = osamp.imh_sample(x0, opot.sum_squares, of, T, noise=osamp.PhiloxNoise(seed))
+    got, want = out.samples.reshape(T, n, d), tr.stacked()
+    same = _agreeing(got, want, 2e-4)
+    assert same.float().mean() > 0.93, float(same.float().mean())
+    np.testing.assert_allclose(got[:, same].numpy(), want[:, same].numpy(), atol=2e-4, rtol=0)
+    st = out.statistics
+    assert st.n_attempted_trajectories == n * T and st.n_target_calls == 2 * n * T   # imh.py:236-240
+    assert abs(st.n_accepted_trajectories - tr.n_accepted) <= 0.01 * n * T
+    assert 0.05 < st.acceptance_rate < 0.9 and tr.n_accepted > 0.05 * n * T       # the proposal is alive (~0.11-0.15)
+    np.testing.assert_allclose(out.mean.numpy(), tr.moments.first.numpy(), atol=3e-3)
+    np.testing.assert_allclose(out.second_moment.numpy(), tr.moments.second.numpy(), rtol=2e-2, atol=2e-3)
+
+
+def test_C2_imh_8192x64_T1000_full_size_properties(dev, monkeypatch):
+    """configs[1] at its full size (8192 chains, d = 64, T = 1000): counters (n_target_calls = 2nT), run-twice bitwise
+    identity, shard invariance, data-parallel == sequential kernel bit for bit (states, acceptances), and moments of
+    N(0, I/2).  An independence sampler whose proposal is not the target mixes slowly (acceptance ~0.15 with the bench's
+    scale-matched default flow: chains dwell on states of high pi / q), so the moment check uses the one property that
+    does not depend on the mixing time: started from EXACT draws of the target, every later state is an exact draw too
+    (the transition leaves N(0, I/2) invariant) -- a wrong accept rule or a wrong log q would drift to the proposal's
+    moments.  Tolerance: what 8192 independent chains guarantee even if they never moved (sigma of the variance
+    estimate sqrt(2 / 8192) = 1.6 %, of the mean 0.78 %; max over 64 coordinates)."""
+    from nfmc_amd.dist import Shard
+    from nfmc_amd.potentials import SumOfSquares
+    from nfmc_amd.samplers import imh
+    d, n, T = 64, 8192, 1000
+    _of, f = _c2_flows(d)
+    xs = 0.7071067811865476 * torch.randn(n, d, generator=torch.Generator().manual_seed(0))   # exact draws of N(0, I/2)
+
+    def run(x, shard=None, T=T, seed=0):
+        s = imh.FixedIMH((d,), SumOfSquares((d,)), imh.IMHKernel((d,), flow=f),
+                         imh.IMHParameters(n_iterations=T, store_samples=False))
+        s.seed = seed
+        s.shard = shard
+        return s.sample(x, show_progress=False)
+
+    a, b = run(xs), run(xs)
+    st = a.statistics
+    assert a.samples is None
+    assert st.n_attempted_trajectories == n * T and st.n_target_calls == 2 * n * T and st.n_target_gradient_calls == 0
+    assert 0.05 < st.acceptance_rate < 0.9
+    assert float(a.mean.abs().max()) < 2.5e-2
+    np.testing.assert_allclose(a.variance.numpy(), 0.5, rtol=5e-2)
+    np.testing.assert_allclose(a.second_moment.numpy(), 0.5, rtol=5e-2)
+    # the chains do move: the last states are exact draws again, and mostly not the first ones
+    la = a.running_samples.last_sample.cpu()
+    assert float((la == xs).all(dim=1).float().mean()) < 0.2
+    np.testing.assert_allclose(la.var(dim=0).numpy(), 0.5, rtol=8e-2)
+    assert torch.equal(a.running_samples.last_sample, b.running_samples.last_sample)
+    assert torch.equal(a.statistics.expectations['second_moment'].total, b.statistics.expectations['second_moment'].total)
+    assert st.n_accepted_trajectories == b.statistics.n_accepted_trajectories
+    sh = Shard(rank=2, world=4)
+    sh.merge_statistics = lambda s_: s_
+    lo, hi = sh.bounds(n)
+    part = run(xs, shard=sh)
+    assert torch.equal(part.running_samples.last_sample, a.running_samples.last_sample[lo:hi])
+    # parallel == sequential: same Philox counters per (chain, step)
+    monkeypatch.setenv('NFMC_IMH_PARALLEL', '0')
+    c = run(xs)
+    assert torch.equal(c.running_samples.last_sample, a.running_samples.last_sample)
+    assert c.statistics.n_accepted_trajectories == st.n_accepted_trajectories
+    np.testing.assert_allclose(c.second_moment.numpy(), a.second_moment.numpy(), rtol=1e-5)
+
+
 # ================================================================================================ C3
 def test_C3_jump_mala_d64_k100_matches_oracle(dev):
     """configs[2] at n = 256: jump_mala, U = sum x^2, d = 64, K = 100 inner MALA transitions (h = 64^(-1/3)) per

@@ -56,6 +56,20 @@ def test_struct_sizes_match_the_header():
         assert ctypes.sizeof(getattr(hip, n)) == sz, n
 
 
+def test_a_library_of_another_abi_version_is_refused(tmp_path):
+    """`hip.lib()` compares nfmc_limits().abi_version with the version its ctypes structs mirror BEFORE binding any other
+    symbol: a stale or side-built library selected through NFMC_LIB would read pointers at the wrong offsets."""
+    src = tmp_path / 'fake.c'
+    src.write_text('typedef struct {int abi_version, a, b, c, d, e;} L;\n'
+                   'int nfmc_limits(L* o) { o->abi_version = 1; o->a = o->b = o->c = o->d = o->e = 0; return 0; }\n')
+    so = tmp_path / 'libnfmc_hip.old.so'
+    subprocess.check_call(['gcc', '-shared', '-fPIC', str(src), '-o', str(so)])
+    code = ('import sys; sys.path.insert(0, %r)\nfrom nfmc_amd import hip\n'
+            'try:\n    hip.lib()\nexcept RuntimeError as e:\n    assert "ABI version 1" in str(e), e; print("refused")\n' % ROOT)
+    out = subprocess.check_output([sys.executable, '-c', code], env=dict(os.environ, NFMC_LIB=str(so)))
+    assert out.decode().strip().endswith('refused')
+
+
 def test_samplers_fail_loudly_without_gpu():
     if torch.cuda.is_available():
         pytest.skip('GPU present')

@@ -27,6 +27,12 @@ def main(root):
                                     'sgpr': row.get('SGPR_Count'), 'lds': row.get('LDS_Block_Size'),
                                     'grid': row.get('Grid_Size'), 'wg': row.get('Workgroup_Size')})
     out = {}
+    try:   # the digest of the library that was profiled (the tree's in-tree build): bench.py flags a summary of other code
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from nfmc_amd import hip
+        out['_meta'] = {'library_digest': hip.build_digest(), 'source': root}
+    except Exception as e:   # noqa
+        out['_meta'] = {'library_digest': None, 'error': repr(e)}
     for k, counters in acc.items():
         out[k] = dict(meta[k])
         for c, vals in sorted(counters.items()):

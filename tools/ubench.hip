@@ -54,6 +54,9 @@ BENCH_KERNEL(k_pk_mul, asm volatile("v_pk_mul_f32 %0, %0, %0\n v_pk_mul_f32 %1, 
 BENCH_KERNEL(k_pk_add, asm volatile("v_pk_add_f32 %0, %0, %0\n v_pk_add_f32 %1, %1, %1\n v_pk_add_f32 %2, %2, %2\n v_pk_add_f32 %3, %3, %3" : "+v"(pa), "+v"(pb), "+v"(pc), "+v"(pd));)
 BENCH_KERNEL(k_and_or, asm volatile("v_and_or_b32 %0, %0, %1, %2\n v_and_or_b32 %1, %1, %2, %3\n v_and_or_b32 %2, %2, %3, %0\n v_and_or_b32 %3, %3, %0, %1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));)
 BENCH_KERNEL(k_mul_f32, asm volatile("v_mul_f32 %0, %0, %0\n v_mul_f32 %1, %1, %1\n v_mul_f32 %2, %2, %2\n v_mul_f32 %3, %3, %3" : "+v"(fa), "+v"(fb), "+v"(fc), "+v"(fd));)
+BENCH_KERNEL(k_add_f32, asm volatile("v_add_f32 %0, %0, %1\n v_add_f32 %1, %1, %2\n v_add_f32 %2, %2, %3\n v_add_f32 %3, %3, %0" : "+v"(fa), "+v"(fb), "+v"(fc), "+v"(fd));)
+BENCH_KERNEL(k_mov, asm volatile("v_mov_b32 %0, %1\n v_mov_b32 %1, %2\n v_mov_b32 %2, %3\n v_mov_b32 %3, %0" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));)
+BENCH_KERNEL(k_fma4, asm volatile("v_fma_f32 %0, %1, %2, %0\n v_fma_f32 %1, %2, %3, %1\n v_fma_f32 %2, %3, %0, %2\n v_fma_f32 %3, %0, %1, %3" : "+v"(fa), "+v"(fb), "+v"(fc), "+v"(fd));)
 BENCH_KERNEL(k_cos, asm volatile("v_cos_f32 %0, %0\n v_cos_f32 %1, %1\n v_cos_f32 %2, %2\n v_cos_f32 %3, %3" : "+v"(fa), "+v"(fb), "+v"(fc), "+v"(fd));)
 BENCH_KERNEL(k_fmac_e32, asm volatile("v_fmac_f32 %0, %1, %2\n v_fmac_f32 %1, %2, %3\n v_fmac_f32 %2, %3, %0\n v_fmac_f32 %3, %0, %1" : "+v"(fa), "+v"(fb), "+v"(fc), "+v"(fd));)
 
@@ -81,7 +84,8 @@ int main() {
                   {"v_cndmask(sgpr)", k_cndmask_s}, {"v_bfi_b32", k_bfi}, {"v_pk_fma_f32", k_pk_fma}, {"v_pk_mul_f32", k_pk_mul},
                   {"v_pk_add_f32", k_pk_add}, {"v_and_or_b32", k_and_or}, {"v_mul_f32", k_mul_f32}, {"v_cos_f32", k_cos},
                   {"v_fmac_f32(e32)", k_fmac_e32}, {"cndmask e64 vcc", k_cndmask_e64vcc}, {"cndmask e32 indep", k_cndmask_ind}, {"cndmask e32 vcc set", k_cndmask_setvcc},
-                  {"v_bitop3_b32", k_bitop3}, {"v_bitop3_b32(sgpr)", k_bitop3_s}, {"v_xor x2 (dependent pair, sgpr)", k_xor_pair}};
+                  {"v_bitop3_b32", k_bitop3}, {"v_bitop3_b32(sgpr)", k_bitop3_s}, {"v_xor x2 (dependent pair, sgpr)", k_xor_pair},
+                  {"v_add_f32", k_add_f32}, {"v_mov_b32", k_mov}, {"v_fma_f32 (4 distinct regs)", k_fma4}};
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
