@@ -25,41 +25,27 @@ namespace nfmc {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-// Workgroup shape (compile-time knobs, A/B'd on the GPU: tools/ab_c4.sh):
-//   NFMC_MFMA_WAVES   waves per workgroup, 16 chains each (8 -> 128 chains, 4 -> 64 chains)
-//   NFMC_MFMA_IMAGES  LDS weight images per workgroup: 2 = double-buffered pipeline, ONE barrier per GEMM and one
-//                     workgroup per CU; 1 = a single image, two barriers per GEMM, but TWO workgroups fit a CU (2 x ~77 KB
-//                     of LDS): their barriers are independent, so while one stages / waits the other's waves own the
-//                     matrix pipe -- the two waves of a SIMD are no longer in lock-step.
-#ifndef NFMC_MFMA_WAVES
-#define NFMC_MFMA_WAVES 8
-#endif
-#ifndef NFMC_MFMA_IMAGES
-#define NFMC_MFMA_IMAGES 2
-#endif
+// Workgroup shape: 8 waves of 16 chains (128 chains per workgroup), two LDS weight images used alternately (ONE barrier per
+// GEMM), one workgroup per CU.  Measured alternatives, not kept: two 4-wave workgroups per CU with one image each (round 2:
+// 3.72 vs 3.50 ms, every workgroup re-stages every operand for half as many chains); 4 waves with TWO 16-chain tiles each,
+// one wave per SIMD with the whole 512-entry register file, the next image copied by LDS-DMA woven into the MFMA stream
+// (round 3: 3.0-3.4 vs 2.28 ms -- tools/experiments/r03_c4_two_tiles_per_wave.patch).
 #ifndef NFMC_STAGE_BATCH
 #define NFMC_STAGE_BATCH 4
 #endif
 #ifndef NFMC_FRAG_CHUNK
 #define NFMC_FRAG_CHUNK 4
 #endif
-#ifndef NFMC_EPI_VALU
-#define NFMC_EPI_VALU 4
-#endif
-constexpr int kMfmaWaves = NFMC_MFMA_WAVES;
-constexpr int kMfmaImages = NFMC_MFMA_IMAGES;
+constexpr int kMfmaWaves = 8;
+constexpr int kMfmaImages = 2;
 constexpr int kMfmaBlock = 64 * kMfmaWaves;
 constexpr int kMfmaChains = 16 * kMfmaWaves;     // chains per workgroup
 // Threads that stage weight images.  Of the two waves of a SIMD the OLDER (waves 0..3 of an 8-wave workgroup) wins the
 // issue arbitration, finishes every GEMM phase first and then waits for its partner (timeline: tools/trace_c4.py: at the
 // C4 shape the old wave needs ~14.5k cycles for a 256-MFMA phase, the young one ~21.7k, the last third of it alone on
 // the SIMD).  So the whole copy belongs to the old waves -- it runs under the partner's MFMAs -- and the young waves
-// go from their last MFMA straight to the barrier: C4 2.66 -> 2.47 ms per trajectory.  -DNFMC_STAGE_ALL: every wave copies.
-#if defined(NFMC_STAGE_ALL) || NFMC_MFMA_WAVES != 8
-constexpr int kStageThreads = kMfmaBlock;
-#else
+// go from their last MFMA straight to the barrier: C4 2.66 -> 2.47 ms per trajectory.
 constexpr int kStageThreads = kMfmaBlock / 2;
-#endif
 #ifndef NFMC_CK_MAX_GRID
 #define NFMC_CK_MAX_GRID 256
 #endif
@@ -115,9 +101,6 @@ __device__ __forceinline__ void stage_matrix(float* __restrict__ img, const floa
     if constexpr (kStagers < kMfmaBlock) {
         if (__builtin_amdgcn_readfirstlane(tid) >= kStagers) return;
     }
-#ifdef NFMC_X_NO_STAGE
-    if (tid >= 0) return;   // ablation: no global -> LDS copy (barriers stay)
-#endif
     // The weights sit in L2, so a staging is latency, not bandwidth: as a plain loop every piece was load -> wait ->
     // store (8 dependent L2 round trips per 128 x 128 operand, ~10k cycles in which both waves of every SIMD sat idle:
     // the largest single loss of the first version, MFMA pipe busy 59 %).  Loads are issued BATCH at a time before
@@ -174,30 +157,6 @@ __device__ __forceinline__ void stage_vector(float* __restrict__ dst, const floa
     for (int i = tid; i < len; i += kMfmaBlock) dst[rev ? (i / BLK) * BLK + (BLK - 1 - (i % BLK)) : i] = b[i];
 }
 
-// ---- one 16-row output tile: acc += A[16*mo .. +15][0 .. 16*TK) x act ; arow = img + (16*mo + col)*ld + 4*q
-template <int TK>
-__device__ __forceinline__ void gemm_tile(f32x4& acc, const float* __restrict__ arow, const f32x4 (&act)[TK]) {
-    // All A fragments of the tile are read first; the fence between the reads and the MFMAs lets the scheduler
-    // move the NEXT tile's reads above this tile's MFMAs (one tile of look-ahead, TK*4 extra registers) but no
-    // further: without any fence it hoists the reads of every tile of the unrolled GEMM and spills.
-    f32x4 a[TK];
-#pragma unroll
-    for (int mk = 0; mk < TK; ++mk) a[mk] = *reinterpret_cast<const f32x4*>(arow + 16 * mk);
-#ifndef NFMC_MFMA_FENCE_END
-    __builtin_amdgcn_sched_barrier(0);
-#endif
-#pragma unroll
-    for (int mk = 0; mk < TK; ++mk) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mk][0], act[mk][0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mk][1], act[mk][1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mk][2], act[mk][2], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mk][3], act[mk][3], acc, 0, 0, 0);
-    }
-#ifdef NFMC_MFMA_FENCE_END
-    __builtin_amdgcn_sched_barrier(0);
-#endif
-}
-
 #ifdef NFMC_TRACE_STEPS
 // Diagnostic build (tools/trace_c4.py, with NFMC_TRACE): per-step marks of workgroup 0 of the trajectory kernel, one
 // stream per wave behind the phase marks (30 = a step's reads begin, 31 = its MFMAs are issued, the epilogue follows).
@@ -224,63 +183,28 @@ __device__ __forceinline__ void step_mark(int id) {
 //   row(i)   LDS address of the A fragments of step i (this lane's row / column group)
 //   init(i)  set up the accumulator of step i        acc(i)  the accumulator (f32x4&)
 //   act(i)   the B operand tiles (f32x4[TK])          fin(i)  the elementwise epilogue of step i
-// Four orderings of the same work exist as compile-time variants; measured on one box at the C4 shape (d = 128,
-// H = 128 x 2, 65536 chains, L = 10; tools/ab_c4.sh; all bitwise equal in their results):
-//   default                  reads(i), MFMAs(i), epilogue(i)                                    3.53 ms per trajectory
-//   NFMC_MFMA_EPI            epilogue(i - 1) woven between the MFMAs of step i (sched_group_barrier)           3.54
-//   NFMC_MFMA_PREFETCH       reads(i + 1) issued before MFMAs(i) (two fragment sets, exact lgkmcnt waits)      3.60
-//   NFMC_MFMA_PAIRS          steps in pairs, MFMAs of two accumulators interleaved                             3.66
-// None beats the plain order: the ablations (tools/ab_c4_time.sh: -DNFMC_X_NO_MFMA / NO_LDS / NO_STAGE) show why --
-// without the fragment reads the kernel still takes 3.43 ms, without MFMAs and reads 0.87 ms, and a register-only MFMA
-// loop reaches 153-156 TFLOP/s with one dependent accumulator per wave (tools/ubench_mfma.hip): neither LDS latency
-// nor the accumulation chain is what idles the matrix pipe.  The 0.87 ms of weight staging, elementwise epilogues,
-// barriers and the leapfrog's global round trips (with ~300 scratch reloads per gradient around the GEMMs) run while
-// BOTH waves of every SIMD are outside their GEMMs, because the barriers keep the eight waves in lock-step.
+// Order: reads(i), MFMAs(i), epilogue(i), one step at a time.  Round 2 measured three other orders of the same work at the
+// C4 shape (tools/ab_c4.sh, all bitwise equal in their results; 3.53 ms per trajectory for this one at the time):
+// epilogue(i - 1) woven between the MFMAs of step i (sched_group_barrier) 3.54; reads(i + 1) issued before MFMAs(i) with two
+// fragment sets 3.60; steps in pairs with two interleaved accumulators 3.66.  None beat the plain order and they were
+// removed: ablations of the same build (no fragment reads: 3.43 ms; no MFMAs and no reads: 0.87 ms) and a register-only
+// MFMA loop (153-156 TFLOP/s on one dependent accumulator per wave, tools/ubench_mfma.hip) showed that neither LDS latency
+// nor the accumulation chain idles the matrix pipe.  What does (timeline of tools/trace_c4.py): of the two
+// waves of a SIMD the older wins the issue arbitration, finishes a phase early, stages the next image and waits at the
+// barrier; the younger runs the last third of the phase alone at ~75-80 % MFMA density.  (Round 1 had read this as "the
+// barriers keep the eight waves in lock-step"; the timeline showed they are a third of a phase apart.)
 template <int TK>
 __device__ __forceinline__ void frag_load(f32x4 (&a)[TK], const float* __restrict__ arow) {
-#ifdef NFMC_X_NO_LDS
-#pragma unroll
-    for (int mk = 0; mk < TK; ++mk) asm volatile("" : "=v"(a[mk]));   // ablation: no LDS reads, operands are whatever is there
-    return;
-#endif
 #pragma unroll
     for (int mk = 0; mk < TK; ++mk) a[mk] = *reinterpret_cast<const f32x4*>(arow + 16 * mk);
 }
 template <int TK, int NSTEP, class Row, class Init, class Acc, class Act, class Fin>
 __device__ __forceinline__ void gemm_phase(Row row, Init init, Acc acc, Act act, Fin fin) {
-    static_assert(NSTEP % 2 == 0, "steps come in pairs");
-#ifdef NFMC_MFMA_EPI
-    // One step at a time; the elementwise epilogue of step i - 1 (tanh, exp, rcp, ... of a finished tile) is woven
-    // between the MFMAs of step i: the accumulation chain of a tile is dependent (a new MFMA every 40 cycles at best,
-    // 8 of them occupying the issue port), so up to ~4 ordinary VALU instructions fit behind every MFMA for free.
-    // In plain order both waves of a SIMD run their epilogues at the same time (the barriers keep them in lock-step)
-    // with the matrix pipe idle: measured, all non-MFMA work of the kernel (0.87 ms of 3.5) was serialised with the MFMAs.
-#pragma unroll
-    for (int i = 0; i < NSTEP; ++i) {
-        f32x4 a[TK];
-        frag_load<TK>(a, row(i));
-        init(i);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int mk = 0; mk < TK; ++mk)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc(i) = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mk][r], act(i)[mk][r], acc(i), 0, 0, 0);
-        if (i > 0) fin(i - 1);
-#pragma unroll
-        for (int k = 0; k < 4 * TK; ++k) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
-            __builtin_amdgcn_sched_group_barrier(0x002, NFMC_EPI_VALU, 0);   // then a few VALU of the previous epilogue
-        }
-    }
-    fin(NSTEP - 1);
-    return;
-#endif
-#if !defined(NFMC_MFMA_PAIRS) && !defined(NFMC_MFMA_PREFETCH) && !defined(NFMC_MFMA_EPI)
-    // DEFAULT (fastest measured, see the table above).  A step's A fragments are read in chunks of at most kFragChunk
-    // k-tiles (4 registers each): the scheduler may move the NEXT chunk's reads above this chunk's MFMAs (the fence
-    // stops anything further), so the fragments cost 2 x 4 x kFragChunk registers at the peak -- 32 instead of 64 for
-    // an 8-tile step: the kernel lives at the 256-register limit of two waves per SIMD and spills cost more than the
-    // shorter look-ahead (16 MFMAs = 512 cycles still cover an LDS read).
+    // A step's A fragments are read in chunks of at most kFragChunk k-tiles (4 registers each): the scheduler may move the
+    // NEXT chunk's reads above this chunk's MFMAs (the fence stops anything further), so the fragments cost
+    // 2 x 4 x kFragChunk registers at the peak -- 32 instead of 64 for an 8-tile step: the kernel lives at the 256-register
+    // limit of two waves per SIMD and spills cost more than the shorter look-ahead (16 MFMAs = 512 cycles still cover an
+    // LDS read).
     constexpr int CH = TK < NFMC_FRAG_CHUNK ? TK : NFMC_FRAG_CHUNK;
     static_assert(TK % CH == 0, "whole chunks");
 #pragma unroll
@@ -294,84 +218,16 @@ __device__ __forceinline__ void gemm_phase(Row row, Init init, Acc acc, Act act,
             f32x4 a[CH];
             frag_load<CH>(a, row(i) + 16 * c0);
             __builtin_amdgcn_sched_barrier(0);
-#ifdef NFMC_X_NO_MFMA
-#pragma unroll
-            for (int mk = 0; mk < CH; ++mk) asm volatile("" ::"v"(a[mk]));   // ablation: reads kept, no MFMAs
-#else
 #pragma unroll
             for (int mk = 0; mk < CH; ++mk)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     acc(i) = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mk][r], act(i)[c0 + mk][r], acc(i), 0, 0, 0);
-#endif
         }
 #ifdef NFMC_TRACE_STEPS
         step_mark(31);
 #endif
         fin(i);
-    }
-    return;
-#endif
-#ifdef NFMC_MFMA_PREFETCH
-    // One step at a time; the NEXT step's LDS reads (A fragments and, in init(), its bias tile) are issued before this
-    // step's MFMAs, so that they travel under them.  init(i + 1) therefore runs before fin(i): callers double-buffer
-    // whatever both touch.  (The reads of a step must all be issued before the next step's, else the in-order LDS
-    // counter makes the MFMAs wait for the newest read: the first attempt read the bias after the prefetch and got
-    // s_waitcnt lgkmcnt(0) in front of every tile.)
-    f32x4 a0[TK], a1[TK];
-    frag_load<TK>(a0, row(0));
-    init(0);
-#pragma unroll
-    for (int i = 0; i < NSTEP; i += 2) {
-        frag_load<TK>(a1, row(i + 1));
-        init(i + 1);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int mk = 0; mk < TK; ++mk)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc(i) = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[mk][r], act(i)[mk][r], acc(i), 0, 0, 0);
-        fin(i);
-        if (i + 2 < NSTEP) {
-            frag_load<TK>(a0, row(i + 2));
-            init(i + 2);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int mk = 0; mk < TK; ++mk)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc(i + 1) = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[mk][r], act(i + 1)[mk][r], acc(i + 1), 0, 0, 0);
-        fin(i + 1);
-    }
-    return;
-#endif
-#pragma unroll
-    for (int i = 0; i < NSTEP; i += 2) {
-        f32x4 a0[TK], a1[TK];
-        frag_load<TK>(a0, row(i));
-        frag_load<TK>(a1, row(i + 1));
-        init(i);
-        init(i + 1);
-        __builtin_amdgcn_sched_barrier(0);   // reads of this pair before its MFMAs, nothing of the next pair hoisted
-#ifdef NFMC_MFMA_NO_INTERLEAVE
-#pragma unroll
-        for (int mk = 0; mk < TK; ++mk)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc(i) = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[mk][r], act(i)[mk][r], acc(i), 0, 0, 0);
-#pragma unroll
-        for (int mk = 0; mk < TK; ++mk)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc(i + 1) = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[mk][r], act(i + 1)[mk][r], acc(i + 1), 0, 0, 0);
-#else
-#pragma unroll
-        for (int mk = 0; mk < TK; ++mk)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                acc(i) = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[mk][r], act(i)[mk][r], acc(i), 0, 0, 0);
-                acc(i + 1) = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[mk][r], act(i + 1)[mk][r], acc(i + 1), 0, 0, 0);
-            }
-#endif
-        fin(i);
-        fin(i + 1);
     }
 }
 
@@ -481,8 +337,7 @@ struct WeightPipe {
     __device__ __forceinline__ void stage(const float* W, bool rev_rows, bool rev_cols, const float* v, int vlen,
                                           bool vrev) {
         mark(1);
-        if constexpr (kMfmaImages == 2) buf ^= 1;
-        else __syncthreads();   // single image: every wave must be done reading the previous GEMM's operand
+        buf ^= 1;
         stage_matrix<K, RBLK, CBLK, ROWS>(img(), W, rev_rows, rev_cols);
         if (v) stage_vector<VBLK>(vec(), v, vlen, vrev);
         mark(2);
