@@ -30,7 +30,7 @@ extern "C" {
 
 typedef void* nfmc_stream_t; /* hipStream_t */
 
-#define NFMC_ABI_VERSION 2
+#define NFMC_ABI_VERSION 3
 
 enum {
     NFMC_OK = 0,
@@ -374,6 +374,38 @@ int nfmc_philox_uniforms_f32(const NfmcRng* rng, int32_t tag, int64_t n, float* 
 
 /* ---- introspection */
 #define NFMC_MAX_STEPS_PER_CALL 512
+/* ---- f1: maximum-likelihood (re)fit of the RealNVP proposal on the device.
+ * Replaces the torchflows `Flow.fit` epochs of jump.py:139-151 (warmup), jump.py:193-201 (refit when fit_nf) and
+ * imh.py:166-170 (AdaptiveIMH).  One call = one optimiser step on one batch: the mean negative log-likelihood of the rows
+ * x (n, d), its gradient with respect to every parameter (hand-written reverse sweep, csrc/fit_kernels.hip) and the AdamW
+ * update (torch.optim.AdamW semantics).  The trainable vector `params` has the layout of the flow's weight blob -- coupling
+ * layers (n_coupling * layer_stride floats, VALU layout above), then at `ea_off` the four ElementwiseAffine vectors
+ * (ea0 log-scale, ea0 shift, ea1 log-scale, ea1 shift; d4 = d rounded up to 4 floats each) -- and `flow`'s pointers must be
+ * views of it (weights = params, ea0_log_scale = params + ea_off, ...), so the sampling kernels see every step at once.
+ * Shapes: affine / additive couplings (n_bins = 0), n_hidden <= 32, one or two hidden layers, d <= 256
+ * (nfmc_flow_fit_supported_f32); other flows are trained by the host package's torch path. */
+typedef struct {
+    float lr, beta1, beta2, eps, weight_decay;
+    int32_t step;             /* 1-based count of applied steps, for the bias corrections */
+} NfmcAdamW;
+
+typedef struct {
+    NfmcRealNVP flow;         /* views of `params` (see above) */
+    float* params;            /* (n_params) trainable vector, updated in place */
+    float* adam_m;            /* (n_params) first moments, zero before the first step */
+    float* adam_v;            /* (n_params) second moments */
+    int64_t n_params;         /* >= ea_off + 4 * d4 */
+    int64_t ea_off;           /* offset of the ElementwiseAffine vectors inside params (multiple of 4) */
+    float* partial;           /* scratch, >= nfmc_flow_fit_partial_floats(n, n_params) floats, ZEROED once by the caller */
+    int64_t partial_floats;
+    float* status;            /* device (2): [0] mean NLL of the batch at the parameters BEFORE the step;
+                                 [1] 1 if the step was applied, 0 if the loss was not finite (parameters untouched) */
+} NfmcFlowFit;
+
+int nfmc_flow_fit_supported_f32(const NfmcRealNVP* flow);
+int64_t nfmc_flow_fit_partial_floats(int64_t n, int64_t n_params);
+int nfmc_flow_fit_step_f32(const NfmcFlowFit* fit, const float* x, int64_t n, const NfmcAdamW* opt, nfmc_stream_t stream);
+
 typedef struct {
     int32_t abi_version;
     int32_t max_d_sampler;   /* largest d for nfmc_mala/hmc_steps */

@@ -1,0 +1,408 @@
+// f1: maximum-likelihood (re)fit of the RealNVP proposal on the device -- one optimiser step per call:
+//   nll_grad_kernel   mean negative log-likelihood of the batch and its gradient with respect to EVERY parameter
+//   adamw_fold_kernel fixed-order fold of the per-workgroup partial gradients + the AdamW update, in one launch
+// Replaces the torchflows `Flow.fit` epochs the reference runs at jump.py:139-151 (warmup), jump.py:193-201 (refit every
+// outer iteration when fit_nf) and imh.py:166-170 (AdaptiveIMH's one-epoch refits), which the round-2 build evaluated with
+// eager torch autograd + torch.optim.AdamW (2.75 ms per epoch at the C5 shape: ~50 small launches forward and backward).
+//
+// Layout: one wave per workgroup, one batch row per lane, the wave's (64, d) tile of rows in LDS twice (state and its
+// gradient) -- the one-chain-per-lane scheme of flow_device.hpp, weights wave-uniform through the scalar cache.
+// No activation is stored: going backward, a coupling layer's input is rebuilt from its output (x_b = (z_b - beta) / alpha)
+// and its conditioner re-evaluated from the unchanged source half, as in NeuTra's reverse sweep.
+// Weight gradients are sums over rows of outer products (delta x activation).  With rows on lanes that would be one
+// cross-lane reduction per weight; instead each layer has a ROW phase (lanes = rows: conditioner, affine map, input
+// gradients; the per-row hidden activations and deltas go to a small LDS tile) and TRANSPOSED phases (lanes = output
+// coordinates: every lane walks the 64 rows of the tile, reads the per-row values column-wise / by broadcast, re-derives the
+// row's scale from the stored activations, and accumulates its own weights' gradients in registers): no reductions, no
+// atomics, every partial sum in a fixed order.
+// The trainable vector has the layout of the flow's weight blob (flows.py: packed): coupling layers, then the four
+// ElementwiseAffine vectors; gradients and AdamW moments use the same indices.
+#include "flow_device.hpp"
+
+namespace nfmc {
+
+constexpr int kFitBlock = 64;
+constexpr int kFitTail = 4;   // per-workgroup partial: [n_params] gradient sums, then sum of losses, number of rows
+
+__host__ __device__ inline int fit_hb_stride(int hp) { return 4 * hp + 1; }   // odd: lanes = rows write conflict-free
+__host__ __device__ inline size_t fit_lds_bytes(int d, int hp) {
+    return ((size_t)2 * 64 * tile_stride(d) + (size_t)64 * fit_hb_stride(hp)) * sizeof(float);
+}
+
+// offsets of a coupling layer's pieces inside its blob (VALU layout, flow_device.hpp)
+struct FitOff {
+    int w1t, b1, wht, bh, w3, b3;
+};
+__device__ __forceinline__ FitOff fit_offsets(const FlowGeom& g, int HP) {
+    FitOff o;
+    o.w1t = 0;
+    o.b1 = g.d_a * HP;
+    o.wht = o.b1 + HP;
+    o.bh = o.wht + HP * HP;
+    o.w3 = o.b1 + HP + (g.n_hl - 1) * (HP * HP + HP);
+    o.b3 = o.w3 + 2 * g.d_b * HP;
+    return o;
+}
+
+template <int HP>
+__global__ void __launch_bounds__(kFitBlock) nll_grad_kernel(NfmcRealNVP f, const float* __restrict__ x, int64_t n,
+                                                             float* __restrict__ partial, int64_t pstride, int64_t ea_off,
+                                                             int d4, int64_t n_params, int64_t tiles) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const FlowGeom g = make_geom(f);
+    const int d = g.d, stride = tile_stride(d), hs = fit_hb_stride(HP);
+    const int lane = threadIdx.x;
+    float* const xt = lds;                       // state tile: row r at xt + r * stride
+    float* const gt = lds + 64 * stride;         // gradient of the loss with respect to the state
+    float* const hb = lds + 2 * 64 * stride;     // per row: h_last | delta_last | h_first | delta_first (HP each)
+    float* const xrow = xt + lane * stride;
+    float* const grow = gt + lane * stride;
+    float* const P = partial + (int64_t)blockIdx.x * pstride;
+    const FitOff o = fit_offsets(g, HP);
+    const bool rev_last = (g.n_coupling & 1) != 0;
+    bool first = true;
+    float loss_acc = 0.f, rows_acc = 0.f;
+    auto emit = [&](int64_t idx, float v) { P[idx] = first ? v : P[idx] + v; };
+    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int64_t r0 = tile * 64;
+        const int nvalid = (int)(n - r0 < 64 ? n - r0 : 64);
+        const bool valid = lane < nvalid;
+        __syncthreads();
+        tile_load(xt, stride, x, r0, n, d);
+        __syncthreads();
+        // ---- forward: z = f(x) in place, loss_i = -log N(z) - logdet
+        const float ld = flow_forward_row<HP>(xrow, f, g);
+        float ss = 0.f;
+        for (int c = 0; c < d; ++c) {
+            const float z = xrow[c];
+            ss = fmaf(z, z, ss);
+            grow[c] = valid ? z : 0.f;           // dL/dz of 0.5 |z|^2; rows beyond the batch carry no gradient
+        }
+        if (valid) {
+            loss_acc += 0.5f * ss + 0.5f * (float)d * kLog2Pi - ld;
+            rows_acc += 1.f;
+        }
+        __syncthreads();
+        // ---- last ElementwiseAffine (logical coordinates), transposed: z_p = e^s y_p + t
+        for (int c = lane; c < d; c += kFitBlock) {
+            const int p = phys(c, d, rev_last);
+            const float s = f.ea1_log_scale[c], t = f.ea1_shift[c];
+            const float es = fast_exp(s), eis = fast_exp(-s);
+            float as = 0.f, at = 0.f;
+            for (int r = 0; r < 64; ++r) {
+                const float gz = gt[r * stride + p], zc = xt[r * stride + p] - t;
+                as = fmaf(gz, zc, as);
+                at += gz;
+                gt[r * stride + p] = gz * es;
+                xt[r * stride + p] = zc * eis;
+            }
+            emit(ea_off + 2 * d4 + c, as - (float)nvalid);   // d(-logdet)/ds = -1 per row
+            emit(ea_off + 3 * d4 + c, at);
+        }
+        __syncthreads();
+        for (int l = g.n_coupling - 1; l >= 0; --l) {
+            const bool rev = (l & 1) == 0;
+            const float* __restrict__ W = f.weights + l * g.layer_stride;
+            const int64_t L0 = (int64_t)l * g.layer_stride;
+            // ---- ROW phase (lane = row)
+            {
+                float h1[HP], hl[HP];
+                const float* b1 = W + o.b1;
+#pragma unroll
+                for (int k = 0; k < HP; ++k) h1[k] = b1[k];
+                for (int j = 0; j < g.d_a; ++j) {
+                    const float xj = xrow[phys(j, d, rev)];
+                    const float* w = W + (int64_t)j * HP;
+#pragma unroll
+                    for (int k = 0; k < HP; ++k) h1[k] = fmaf(w[k], xj, h1[k]);
+                }
+#pragma unroll
+                for (int k = 0; k < HP; ++k) h1[k] = fast_tanh(h1[k]);
+                if (g.n_hl > 1) {
+                    const float* Wh = W + o.wht;
+                    const float* bh = W + o.bh;
+#pragma unroll
+                    for (int k = 0; k < HP; ++k) hl[k] = bh[k];
+#pragma unroll
+                    for (int i = 0; i < HP; ++i)
+#pragma unroll
+                        for (int k = 0; k < HP; ++k) hl[k] = fmaf(Wh[i * HP + k], h1[i], hl[k]);
+#pragma unroll
+                    for (int k = 0; k < HP; ++k) hl[k] = fast_tanh(hl[k]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < HP; ++k) hl[k] = h1[k];
+                }
+                float gh[HP];
+#pragma unroll
+                for (int k = 0; k < HP; ++k) gh[k] = 0.f;
+                const float* W3 = W + o.w3;
+                const float* b3 = W + o.b3;
+                for (int t = 0; t < g.d_b; ++t) {
+                    float ua = b3[t], ub = b3[g.d_b + t];
+                    const float* wa = W3 + (int64_t)t * HP;
+                    const float* wb = W3 + (int64_t)(g.d_b + t) * HP;
+#pragma unroll
+                    for (int k = 0; k < HP; ++k) {
+                        ua = fmaf(wa[k], hl[k], ua);
+                        ub = fmaf(wb[k], hl[k], ub);
+                    }
+                    const float alpha = fast_exp(fmaf(0.5f, ua, g.log1m)) + g.m;
+                    const float ra = __builtin_amdgcn_rcpf(alpha);
+                    const int p = phys(g.d_a + t, d, rev);
+                    const float xb = (xrow[p] - 0.5f * ub) * ra;
+                    const float gz = grow[p];
+                    xrow[p] = xb;                                    // the layer's input
+                    grow[p] = gz * alpha;                            // dL/dx_b
+                    const float ga = fmaf(gz, xb, valid ? -ra : 0.f);   // dL/dalpha: z_b = alpha x_b + beta, -log alpha
+                    const float da = 0.5f * ga * (alpha - g.m), db = 0.5f * gz;
+#pragma unroll
+                    for (int k = 0; k < HP; ++k) gh[k] = fmaf(wa[k], da, fmaf(wb[k], db, gh[k]));
+                }
+                float dl[HP], df[HP];   // deltas (gradients of the pre-activations) of the last / first hidden layer
+#pragma unroll
+                for (int k = 0; k < HP; ++k) dl[k] = gh[k] * (1.f - hl[k] * hl[k]);
+                if (g.n_hl > 1) {
+                    const float* Wh = W + o.wht;
+#pragma unroll
+                    for (int i = 0; i < HP; ++i) {
+                        float a = 0.f;
+#pragma unroll
+                        for (int k = 0; k < HP; ++k) a = fmaf(Wh[i * HP + k], dl[k], a);
+                        df[i] = a * (1.f - h1[i] * h1[i]);
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < HP; ++k) df[k] = dl[k];
+                }
+                for (int j = 0; j < g.d_a; ++j) {
+                    const float* w = W + (int64_t)j * HP;
+                    float a = 0.f;
+#pragma unroll
+                    for (int k = 0; k < HP; ++k) a = fmaf(w[k], df[k], a);
+                    grow[phys(j, d, rev)] += a;
+                }
+                float* hrow = hb + lane * hs;
+#pragma unroll
+                for (int k = 0; k < HP; ++k) {
+                    hrow[k] = hl[k];
+                    hrow[HP + k] = dl[k];
+                    hrow[2 * HP + k] = h1[k];
+                    hrow[3 * HP + k] = df[k];
+                }
+            }
+            __syncthreads();
+            // ---- TRANSPOSED phases (lane = output coordinate; rows walked in order)
+            // W3 (2 d_b, HP) and b3: the lane re-derives alpha of (row, t) from the row's stored activations
+            for (int t = lane; t < g.d_b; t += kFitBlock) {
+                float wa[HP], aa[HP], ab[HP];
+                const float* war = W + o.w3 + (int64_t)t * HP;
+#pragma unroll
+                for (int k = 0; k < HP; ++k) {
+                    wa[k] = war[k];
+                    aa[k] = 0.f;
+                    ab[k] = 0.f;
+                }
+                const float ba = W[o.b3 + t];
+                float sa = 0.f, sb = 0.f;
+                const int p = phys(g.d_a + t, d, rev);
+                for (int r = 0; r < 64; ++r) {
+                    const float* hrow = hb + r * hs;
+                    float h[HP];
+                    float ua = ba;
+#pragma unroll
+                    for (int k = 0; k < HP; ++k) {
+                        h[k] = hrow[k];
+                        ua = fmaf(wa[k], h[k], ua);
+                    }
+                    const float alpha = fast_exp(fmaf(0.5f, ua, g.log1m)) + g.m;
+                    const float ra = __builtin_amdgcn_rcpf(alpha);
+                    const float gz = gt[r * stride + p] * ra, xb = xt[r * stride + p];
+                    const float ga = fmaf(gz, xb, r < nvalid ? -ra : 0.f);
+                    const float da = 0.5f * ga * (alpha - g.m), db = 0.5f * gz;
+                    sa += da;
+                    sb += db;
+#pragma unroll
+                    for (int k = 0; k < HP; ++k) {
+                        aa[k] = fmaf(da, h[k], aa[k]);
+                        ab[k] = fmaf(db, h[k], ab[k]);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < HP; ++k) {
+                    emit(L0 + o.w3 + (int64_t)t * HP + k, aa[k]);
+                    emit(L0 + o.w3 + (int64_t)(g.d_b + t) * HP + k, ab[k]);
+                }
+                emit(L0 + o.b3 + t, sa);
+                emit(L0 + o.b3 + g.d_b + t, sb);
+            }
+            // Wh^T (HP_in, HP_out), bh, b1
+            if (g.n_hl > 1) {
+                for (int e = lane; e < HP * HP; e += kFitBlock) {
+                    const int i = e / HP, k = e - i * HP;
+                    float a = 0.f;
+                    for (int r = 0; r < 64; ++r) a = fmaf(hb[r * hs + 2 * HP + i], hb[r * hs + HP + k], a);
+                    emit(L0 + o.wht + e, a);
+                }
+            }
+            if (lane < HP) {
+                float a1 = 0.f, a2 = 0.f;
+                for (int r = 0; r < 64; ++r) {
+                    a1 += hb[r * hs + 3 * HP + lane];
+                    a2 += hb[r * hs + HP + lane];
+                }
+                emit(L0 + o.b1 + lane, a1);
+                if (g.n_hl > 1) emit(L0 + o.bh + lane, a2);
+            }
+            // W1^T (d_a, HP)
+            for (int j = lane; j < g.d_a; j += kFitBlock) {
+                float a[HP];
+#pragma unroll
+                for (int k = 0; k < HP; ++k) a[k] = 0.f;
+                const int p = phys(j, d, rev);
+                for (int r = 0; r < 64; ++r) {
+                    const float xj = xt[r * stride + p];
+#pragma unroll
+                    for (int k = 0; k < HP; ++k) a[k] = fmaf(xj, hb[r * hs + 3 * HP + k], a[k]);
+                }
+#pragma unroll
+                for (int k = 0; k < HP; ++k) emit(L0 + (int64_t)j * HP + k, a[k]);
+            }
+            __syncthreads();
+        }
+        // ---- first ElementwiseAffine, transposed: the tile holds its OUTPUT y = e^s x + t and dL/dy
+        for (int c = lane; c < d; c += kFitBlock) {
+            const float t = f.ea0_shift[c];
+            float as = 0.f, at = 0.f;
+            for (int r = 0; r < 64; ++r) {
+                const float gy = gt[r * stride + c];
+                as = fmaf(gy, xt[r * stride + c] - t, as);
+                at += gy;
+            }
+            emit(ea_off + c, as - (float)nvalid);
+            emit(ea_off + d4 + c, at);
+        }
+        first = false;
+    }
+    // loss and row count of this workgroup's rows: fixed-order sum over the lanes
+    __syncthreads();
+    lds[lane] = loss_acc;
+    lds[64 + lane] = rows_acc;
+    __syncthreads();
+    if (lane == 0) {
+        float a = 0.f, b = 0.f;
+        for (int r = 0; r < 64; ++r) {
+            a += lds[r];
+            b += lds[64 + r];
+        }
+        P[n_params] = a;
+        P[n_params + 1] = b;
+    }
+}
+
+// Fold of the partial gradients (fixed order: workgroup 0, 1, ...) + AdamW, one thread per parameter.
+// torch.optim.AdamW semantics: p <- p (1 - lr wd);  m <- b1 m + (1 - b1) g;  v <- b2 v + (1 - b2) g^2;
+// p <- p - lr (m / bc1) / (sqrt(v / bc2) + eps),  bc = 1 - beta^step.  A non-finite batch loss applies NO step
+// (flow_training._loop: `continue` before backward) and reports it: status[1] = 0.
+__global__ void __launch_bounds__(256) adamw_fold_kernel(float* __restrict__ params, float* __restrict__ am,
+                                                         float* __restrict__ av, const float* __restrict__ partial,
+                                                         int64_t pstride, int nparts, int64_t n_params, NfmcAdamW opt,
+                                                         float* __restrict__ status) {
+    __shared__ float sh[2];
+    if (threadIdx.x == 0) {
+        float ls = 0.f, rows = 0.f;
+        for (int w = 0; w < nparts; ++w) {
+            ls += partial[w * pstride + n_params];
+            rows += partial[w * pstride + n_params + 1];
+        }
+        sh[0] = ls / rows;
+        sh[1] = rows;
+    }
+    __syncthreads();
+    const float loss = sh[0], rows = sh[1];
+    const bool ok = fabsf(loss) <= 3.0e38f;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        status[0] = loss;
+        status[1] = ok ? 1.f : 0.f;
+    }
+    if (!ok) return;
+    const float bc1 = 1.f - powf(opt.beta1, (float)opt.step), bc2 = 1.f - powf(opt.beta2, (float)opt.step);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_params; i += (int64_t)gridDim.x * blockDim.x) {
+        float gsum = 0.f;
+        for (int w = 0; w < nparts; ++w) gsum += partial[w * pstride + i];
+        const float gr = gsum / rows;
+        float p = params[i];
+        p *= 1.f - opt.lr * opt.weight_decay;
+        const float m = opt.beta1 * am[i] + (1.f - opt.beta1) * gr;
+        const float v = opt.beta2 * av[i] + (1.f - opt.beta2) * gr * gr;
+        am[i] = m;
+        av[i] = v;
+        params[i] = p - opt.lr * (m / bc1) / (sqrtf(v / bc2) + opt.eps);
+    }
+}
+
+static int fit_grid(int64_t n) {
+    const int64_t tiles = (n + 63) / 64;
+    return (int)(tiles < 256 ? tiles : 256);
+}
+
+static bool fit_supported(const NfmcRealNVP* f) {
+    if (!f || f->n_bins != 0 || f->d <= 0 || f->d > 256 || f->n_coupling < 0) return false;
+    if (f->n_hidden <= 0 || f->n_hidden > 32 || f->n_hidden_layers < 1 || f->n_hidden_layers > 2) return false;
+    const int hp = nfmc_realnvp_padded_hidden(f->n_hidden);
+    return hp > 0 && fit_lds_bytes(f->d, hp) <= 160 * 1024;
+}
+
+}  // namespace nfmc
+
+using namespace nfmc;
+
+extern "C" int nfmc_flow_fit_supported_f32(const NfmcRealNVP* flow) { return fit_supported(flow) ? 1 : 0; }
+
+extern "C" int64_t nfmc_flow_fit_partial_floats(int64_t n, int64_t n_params) {
+    if (n <= 0 || n_params <= 0) return 0;
+    return (int64_t)fit_grid(n) * (n_params + kFitTail);
+}
+
+extern "C" int nfmc_flow_fit_step_f32(const NfmcFlowFit* fit, const float* x, int64_t n, const NfmcAdamW* opt,
+                                      nfmc_stream_t stream) {
+    if (!fit || !x || !opt || n <= 0) return NFMC_EINVAL;
+    const NfmcRealNVP& f = fit->flow;
+    if (!fit->params || !fit->adam_m || !fit->adam_v || !fit->partial || !fit->status) return NFMC_EINVAL;
+    if (!fit_supported(&f)) return NFMC_EUNSUPPORTED;
+    const int d4 = (f.d + 3) / 4 * 4;
+    if (fit->ea_off < (int64_t)f.n_coupling * f.layer_stride || fit->n_params < fit->ea_off + 4 * d4) return NFMC_EINVAL;
+    // the flow's pointers must be views of the trainable vector in the gradient's layout
+    if (f.weights != fit->params || f.ea0_log_scale != fit->params + fit->ea_off || f.ea0_shift != fit->params + fit->ea_off + d4 ||
+        f.ea1_log_scale != fit->params + fit->ea_off + 2 * d4 || f.ea1_shift != fit->params + fit->ea_off + 3 * d4)
+        return NFMC_EINVAL;
+    const int grid = fit_grid(n);
+    const int64_t pstride = fit->n_params + kFitTail;
+    if (fit->partial_floats < (int64_t)grid * pstride) return NFMC_ESCRATCH;
+    if (opt->step < 1) return NFMC_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int hp = nfmc_realnvp_padded_hidden(f.n_hidden);
+    const size_t lds = fit_lds_bytes(f.d, hp);
+    const int64_t tiles = (n + 63) / 64;
+#define NFMC_FIT_LAUNCH(HPV)                                                                                              \
+    {                                                                                                                     \
+        auto kern = nll_grad_kernel<HPV>;                                                                                 \
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
+        if (e != hipSuccess) return (int)e;                                                                               \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kFitBlock), lds, st, f, x, n, fit->partial, pstride, fit->ea_off, d4,   \
+                           fit->n_params, tiles);                                                                         \
+    }
+    switch (hp) {
+        case 4: NFMC_FIT_LAUNCH(4) break;
+        case 8: NFMC_FIT_LAUNCH(8) break;
+        case 16: NFMC_FIT_LAUNCH(16) break;
+        case 32: NFMC_FIT_LAUNCH(32) break;
+        default: return NFMC_EUNSUPPORTED;
+    }
+#undef NFMC_FIT_LAUNCH
+    const int ablocks = (int)((fit->n_params + 255) / 256);
+    hipLaunchKernelGGL(adamw_fold_kernel, dim3(ablocks < 1024 ? ablocks : 1024), dim3(256), 0, st, fit->params, fit->adam_m,
+                       fit->adam_v, fit->partial, pstride, grid, fit->n_params, *opt, fit->status);
+    NFMC_HIP_CHECK_LAUNCH();
+    return NFMC_OK;
+}

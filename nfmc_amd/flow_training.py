@@ -5,9 +5,11 @@ surface nfmc passes (`early_stopping`, `early_stopping_threshold`, `keep_best_we
 `n_epochs`, `lr`, `n_samples`, `check_for_divergences`, `show_progress`, `time_limit_seconds`) and the
 `ValueError`-on-divergence contract the callers catch (jump.py:150, imh.py:174).
 
-Training needs gradients with respect to the WEIGHTS, which the sampling kernels never compute, so this
-module evaluates the same RealNVP spec with differentiable torch ops (on the GPU when there is one).
-It is not on the sampling path: `sample()` never calls into it unless `warmup=True` / `fit_nf=True`.
+`fit` of a RealNVP / NICE flow with a narrow conditioner (n_hidden <= 32, d <= 256: every default flow) runs on the device:
+`DeviceFit` drives `nfmc_flow_fit_step_f32` (csrc/fit_kernels.hip: hand-written reverse sweep with weight gradients +
+fused AdamW), two launches per epoch.  Everything else -- `variational_fit`, spline couplings, wide conditioners,
+mini-batches -- evaluates the same spec with differentiable torch ops (on the GPU when there is one).
+None of it is on the sampling path: `sample()` never calls into it unless `warmup=True` / `fit_nf=True`.
 """
 import math
 import time
@@ -156,6 +158,129 @@ def _loop(flow, loss_fn, val_fn, n_epochs, lr, early_stopping, early_stopping_th
     return best_loss
 
 
+class DeviceFit:
+    """State of a maximum-likelihood fit on the device (include/nfmc_hip.h: NfmcFlowFit, csrc/fit_kernels.hip): the flow's
+    parameters as ONE trainable vector in the layout of its weight blob, AdamW moments, per-workgroup partial gradients.
+    `step(x)` enqueues one optimiser step (gradient kernel + fold / AdamW kernel) and returns nothing; `status` holds the
+    batch loss before the step and whether it was applied.  `write_back()` copies the vector into the nn.Parameters."""
+
+    def __init__(self, bijection, device, n_rows, lr):
+        import ctypes as C
+        from . import hip
+        self.C, self.hip, self.bij, self.dev = C, hip, bijection, device
+        st, keep = bijection.packed(device, min_hidden=0)
+        blob = keep[0]
+        self.d = d = bijection.d
+        self.d4 = (d + 3) // 4 * 4
+        self.ea_off = int(keep[1].storage_offset() - blob.storage_offset())
+        self.params = blob.clone()
+        self.n_params = int(self.params.numel())
+        self.m = torch.zeros_like(self.params)
+        self.v = torch.zeros_like(self.params)
+        nfl = int(hip.lib().nfmc_flow_fit_partial_floats(int(n_rows), self.n_params))
+        self.partial = torch.zeros(nfl, dtype=torch.float32, device=device)
+        self.status = torch.zeros(2, dtype=torch.float32, device=device)
+        self.layer_stride = int(st.layer_stride)
+        self.flow_struct = self._struct(st, self.params)
+        self.fit = hip.NfmcFlowFit(self.flow_struct, hip.ptr(self.params), hip.ptr(self.m), hip.ptr(self.v), self.n_params,
+                                   self.ea_off, hip.ptr(self.partial), nfl, hip.ptr(self.status))
+        self.opt = hip.NfmcAdamW(float(lr), 0.9, 0.999, 1e-8, 0.01, 0)   # torch.optim.AdamW defaults
+        self.n_rows = int(n_rows)
+
+    def _struct(self, st, vec):
+        hip, o, d4 = self.hip, self.ea_off, self.d4
+        view = lambda k: hip.ptr(vec[o + k * d4:o + k * d4 + self.d])
+        return hip.NfmcRealNVP(st.d, st.n_coupling, st.n_hidden, st.n_hidden_layers, st.min_scale, st.n_bins, view(0), view(1),
+                               view(2), view(3), hip.ptr(vec), st.layer_stride, st.spline_bound, 0)
+
+    @staticmethod
+    def supported(bijection, device) -> bool:
+        from . import hip
+        from .flows import RealNVP
+        if not isinstance(bijection, RealNVP) or bijection.n_bins != 0 or device.type != 'cuda':
+            return False
+        if bijection.n_hidden > 32 or bijection.n_hidden_layers > 2 or bijection.d > 256 or bijection.n_coupling < 1:
+            return False
+        st, _keep = bijection.packed(device, min_hidden=0)
+        import ctypes as C
+        return bool(hip.lib().nfmc_flow_fit_supported_f32(C.byref(st)))
+
+    def step(self, x, applied_steps):
+        """One AdamW step on the mean NLL of the rows x (n_rows, d) float32 on the device."""
+        self.opt.step = int(applied_steps) + 1
+        self.hip.check(self.hip.lib().nfmc_flow_fit_step_f32(self.C.byref(self.fit), self.hip.ptr(x), int(x.shape[0]),
+                                                             self.C.byref(self.opt), self.hip.stream()), 'nfmc_flow_fit_step_f32')
+
+    def nll(self, x):
+        """Mean NLL of rows x under the CURRENT trainable vector (forward kernel), as a device scalar."""
+        n = int(x.shape[0])
+        lp = torch.empty(n, dtype=torch.float32, device=self.dev)
+        self.hip.check(self.hip.lib().nfmc_realnvp_forward_f32(self.C.byref(self.flow_struct), self.hip.ptr(x), n, None, None,
+                                                               self.hip.ptr(lp), self.hip.stream()), 'nfmc_realnvp_forward_f32')
+        return -lp.mean()
+
+    def write_back(self, vec=None):
+        """The trainable vector (or a saved copy of it) into the flow's nn.Parameters (inverse of RealNVP.packed)."""
+        vec = self.params if vec is None else vec
+        bij = self.bij
+        H, nhl, d = bij.n_hidden, bij.n_hidden_layers, bij.d
+        hp = int(self.hip.lib().nfmc_realnvp_padded_hidden(H))
+        d_a, d_b = d // 2, d - d // 2
+        with torch.no_grad():
+            for li, cpl in enumerate(bij.couplings):
+                lin = list(cpl.conditioner)
+                cur = li * self.layer_stride
+                lin[0].weight.copy_(vec[cur:cur + d_a * hp].reshape(d_a, hp)[:, :H].t())
+                cur += d_a * hp
+                lin[0].bias.copy_(vec[cur:cur + H])
+                cur += hp
+                for l in lin[1:-1]:
+                    l.weight.copy_(vec[cur:cur + hp * hp].reshape(hp, hp)[:H, :H].t())
+                    cur += hp * hp
+                    l.bias.copy_(vec[cur:cur + H])
+                    cur += hp
+                lin[-1].weight.copy_(vec[cur:cur + 2 * d_b * hp].reshape(2 * d_b, hp)[:, :H])
+                cur += 2 * d_b * hp
+                lin[-1].bias.copy_(vec[cur:cur + 2 * d_b])
+            ea0, ea1 = bij.layers[0], bij.layers[-1]
+            for k, t in enumerate((ea0.log_scale, ea0.shift, ea1.log_scale, ea1.shift)):
+                t.copy_(vec[self.ea_off + k * self.d4:self.ea_off + k * self.d4 + d])
+
+
+def _fit_device(flow, xt, xv, n_epochs, lr, early_stopping, early_stopping_threshold, keep_best_weights, time_limit_seconds):
+    """`_loop` for the full-batch maximum-likelihood fit with the step on the device (same order of events: loss at the
+    current weights, step unless it is not finite, validation at the new weights, best-so-far bookkeeping).  The host reads
+    ONE 12-byte tensor per epoch (batch loss, step applied, validation loss)."""
+    fitter = DeviceFit(flow.bijection, xt.device, xt.shape[0], lr)
+    best_loss, best_vec, since_best, applied = math.inf, (fitter.params.clone() if keep_best_weights else None), 0, 0
+    t0 = time.time()
+    try:
+        for _epoch in range(int(n_epochs)):
+            if time_limit_seconds is not None and time.time() - t0 >= time_limit_seconds:
+                break
+            fitter.step(xt, applied)
+            val = fitter.nll(xv).reshape(1) if xv is not None else fitter.status[:1]
+            loss, ok, v = (float(t) for t in torch.cat([fitter.status, val]).cpu())
+            if not math.isfinite(loss) or ok == 0.0:
+                raise ValueError('flow training diverged (non-finite loss)')
+            applied += 1
+            if not math.isfinite(v):
+                raise ValueError('flow training diverged (non-finite validation loss)')
+            if v < best_loss:
+                best_loss, since_best = v, 0
+                if keep_best_weights:
+                    best_vec.copy_(fitter.params)
+            else:
+                since_best += 1
+                if early_stopping and since_best > early_stopping_threshold:
+                    break
+    finally:
+        # whatever happened, the nn.Parameters end up as the best weights seen (or the last ones): callers that catch the
+        # ValueError restore their own saved state_dict on top (jump.py:150-151)
+        fitter.write_back(best_vec if keep_best_weights else None)
+    return best_loss
+
+
 def fit(flow, x_train, x_val=None, n_epochs: int = 500, lr: float = 0.05, batch_size='adaptive',
         shuffle: bool = True, show_progress: bool = False, keep_best_weights: bool = True,
         early_stopping: bool = False, early_stopping_threshold: int = 50, time_limit_seconds=None, **_ignored):
@@ -168,6 +293,12 @@ def fit(flow, x_train, x_val=None, n_epochs: int = 500, lr: float = 0.05, batch_
     if n == 0:
         return
     bs = n if batch_size == 'adaptive' or batch_size is None else max(1, min(int(batch_size), n))
+    import os
+    if (bs >= n and os.environ.get('NFMC_FIT_TORCH') != '1' and DeviceFit.supported(flow.bijection, dev)):
+        # full-batch fit of a RealNVP the fit kernels cover: every epoch is two launches of libnfmc_hip (fit_kernels.hip)
+        _fit_device(flow, xt.contiguous(), xv.contiguous() if xv is not None else None, n_epochs, lr, early_stopping,
+                    early_stopping_threshold, keep_best_weights, time_limit_seconds)
+        return
     gen = torch.Generator(device='cpu').manual_seed(int(torch.randint(0, 2 ** 31, ()).item()))
 
     def nll(x):

@@ -21,7 +21,7 @@ MAX_STEPS_PER_CALL = 512
 IMH_PARALLEL_MAX_STEPS = 65536
 
 c_fp = C.c_void_p  # all device pointers travel as void*
-NFMC_ABI_VERSION = 2   # include/nfmc_hip.h
+NFMC_ABI_VERSION = 3   # include/nfmc_hip.h
 
 
 class NfmcPotential(C.Structure):
@@ -102,6 +102,16 @@ class NfmcSelectArgs(C.Structure):
                 ('mask_out', c_fp)]
 
 
+class NfmcAdamW(C.Structure):
+    _fields_ = [('lr', C.c_float), ('beta1', C.c_float), ('beta2', C.c_float), ('eps', C.c_float),
+                ('weight_decay', C.c_float), ('step', C.c_int32)]
+
+
+class NfmcFlowFit(C.Structure):
+    _fields_ = [('flow', NfmcRealNVP), ('params', c_fp), ('adam_m', c_fp), ('adam_v', c_fp), ('n_params', C.c_int64),
+                ('ea_off', C.c_int64), ('partial', c_fp), ('partial_floats', C.c_int64), ('status', c_fp)]
+
+
 class NfmcLimits(C.Structure):
     _fields_ = [('abi_version', C.c_int32), ('max_d_sampler', C.c_int32), ('max_d_flow', C.c_int32),
                 ('max_hidden_valu', C.c_int32), ('max_hidden', C.c_int32), ('max_steps_per_call', C.c_int32)]
@@ -137,6 +147,9 @@ SYMBOLS = [
     ('nfmc_stats_fold_f32', C.c_int, [C.POINTER(NfmcStats), C.c_int32, C.c_uint64, c_fp, C.c_uint64, c_fp]),
     ('nfmc_philox_normals_f32', C.c_int, [C.POINTER(NfmcRng), C.c_int32, C.c_int64, C.c_int32, c_fp, c_fp]),
     ('nfmc_philox_uniforms_f32', C.c_int, [C.POINTER(NfmcRng), C.c_int32, C.c_int64, c_fp, c_fp]),
+    ('nfmc_flow_fit_supported_f32', C.c_int, [C.POINTER(NfmcRealNVP)]),
+    ('nfmc_flow_fit_partial_floats', C.c_int64, [C.c_int64, C.c_int64]),
+    ('nfmc_flow_fit_step_f32', C.c_int, [C.POINTER(NfmcFlowFit), c_fp, C.c_int64, C.POINTER(NfmcAdamW), c_fp]),
     ('nfmc_limits', C.c_int, [C.POINTER(NfmcLimits)]),
     ('nfmc_error_string', C.c_char_p, [C.c_int]),
     ('nfmc_build_digest', C.c_char_p, []),

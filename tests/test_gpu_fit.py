@@ -1,0 +1,194 @@
+"""f1 on the device: the maximum-likelihood (re)fit of the RealNVP proposal (jump.py:139-151,193-201; imh.py:166-170) through
+`nfmc_flow_fit_step_f32` (csrc/fit_kernels.hip: hand-written reverse sweep with weight gradients + fused AdamW) against
+autograd of the flow restatement and against the eager torch loop it replaces.
+
+Tolerances: gradients of the mean NLL agree with autograd to 2e-4 relative to the largest entry of each parameter tensor
+(fp32 sums over up to 700 rows in a different order; hardware exp / rcp / tanh); the first AdamW step to 2e-6 in the
+parameters wherever the gradient is not negligible; the loss of each of 25 epochs to 1e-3 (first 8) / 2e-2 relative."""
+import copy
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'GPU tests need a ROCm device'
+    return torch.device('cuda', 0)
+
+
+def _flow(d, n_hidden, n_hl, n_layers, seed, nice=False):
+    from nfmc_amd.flows import Flow, NICE, RealNVP
+    from oracle import flow as oflow
+    ck = {'n_hidden': n_hidden, 'n_layers': n_hl}
+    of = oflow.perturb_(oflow.Flow((oflow.NICE if nice else oflow.RealNVP)((d,), n_layers=n_layers, conditioner_kwargs=ck)),
+                        seed, 0.3, 0.8)
+    f = Flow((NICE if nice else RealNVP)((d,), n_layers=n_layers, conditioner_kwargs=ck))
+    f.load_state_dict(of.state_dict())
+    return of, f
+
+
+SHAPES = [  # d, n_hidden, hidden layers, coupling layers, rows, NICE
+    (6, 4, 2, 2, 50, False), (7, 3, 1, 3, 64, False), (25, 4, 2, 2, 200, False), (64, 4, 2, 2, 333, False),
+    (64, 8, 2, 2, 128, False), (64, 16, 1, 2, 70, False), (100, 7, 2, 3, 129, False), (128, 32, 2, 2, 65, False),
+    (256, 7, 2, 2, 700, False), (16, 5, 2, 2, 90, True),
+]
+
+
+@pytest.mark.parametrize('d,H,nhl,nl,n,nice', SHAPES)
+def test_nll_gradient_matches_autograd(dev, d, H, nhl, nl, n, nice):
+    """One step with lr = 0, weight decay 0 and beta1 = 0 leaves the parameters alone and the first moment equal to the
+    gradient: every entry against autograd of the CPU restatement (oracle/flow.py), the batch loss against its value."""
+    from nfmc_amd.flow_training import DeviceFit
+    of, f = _flow(d, H, nhl, nl, 3 + d, nice)
+    x = (torch.randn(n, d, generator=torch.Generator().manual_seed(d)) * 0.8)
+    f.to(dev)
+    assert DeviceFit.supported(f.bijection, dev)
+    fit = DeviceFit(f.bijection, dev, n, lr=0.0)
+    fit.opt.beta1, fit.opt.weight_decay = 0.0, 0.0
+    before = fit.params.clone()
+    fit.step(x.to(dev), 0)
+    torch.cuda.synchronize()
+    loss_gpu, applied = (float(v) for v in fit.status.cpu())
+    assert applied == 1.0 and torch.equal(fit.params, before)          # lr = 0: nothing moved
+    loss = -of.log_prob(x).mean()
+    loss.backward()
+    np.testing.assert_allclose(loss_gpu, float(loss.detach()), rtol=2e-5, atol=2e-5)
+    g = copy.deepcopy(f)
+    fit.bij = g.bijection
+    fit.write_back(fit.m)                                               # the gradient, laid out as parameters
+    want = dict(of.named_parameters())
+    for name, p in g.named_parameters():
+        w = want[name].grad
+        scale = max(float(w.abs().max()), 1e-3)
+        np.testing.assert_allclose(p.detach().cpu().numpy(), w.numpy(), atol=2e-4 * scale, rtol=0, err_msg=name)
+    # the padded entries of the blob (hidden units beyond n_hidden, alignment gaps) carry no gradient
+    used = torch.zeros_like(fit.m, dtype=torch.bool)
+    probe = copy.deepcopy(f)
+    fit.bij = probe.bijection
+    marker = torch.arange(1, fit.n_params + 1, dtype=torch.float32, device=dev)
+    fit.write_back(marker)
+    for p in probe.parameters():
+        used[(p.detach().reshape(-1).long() - 1)] = True
+    assert float(fit.m[~used].abs().max() if (~used).any() else 0.0) == 0.0
+
+
+def test_device_steps_follow_torch_adamw(dev):
+    """The fused AdamW step against torch.optim.AdamW on autograd gradients of the same restatement (flow_training.py:
+    forward_torch), same data, same start.  AdamW divides by sqrt(v): a parameter whose gradient is ~0 moves by +-lr in a
+    direction that rounding decides, and such differences feed back, so the two runs are compared where that cannot
+    matter: the first step entry by entry wherever the gradient is not negligible, and the LOSS of every one of 25 epochs
+    (flat directions do not move it), not the parameters after 25 epochs."""
+    from nfmc_amd.flow_training import DeviceFit, _base_log_prob, forward_torch
+    d, n, lr = 64, 1500, 0.02
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(n, d, generator=g) * torch.linspace(0.4, 1.6, d) + 0.3).to(dev)
+    _of, fa = _flow(d, 4, 2, 2, 11)
+    fa.to(dev)
+    fb = copy.deepcopy(fa)
+    fit = DeviceFit(fa.bijection, dev, n, lr=lr)
+    opt = torch.optim.AdamW(fb.parameters(), lr=lr)
+    la, lb = [], []
+    for epoch in range(25):
+        fit.step(x, epoch)
+        la.append(float(fit.status[0]))
+        opt.zero_grad()
+        z, ld = forward_torch(fb.bijection, x)
+        loss = -(_base_log_prob(z) + ld).mean()
+        loss.backward()
+        if epoch == 0:
+            grads = {k: p.grad.detach().clone() for k, p in fb.named_parameters()}
+        opt.step()
+        lb.append(float(loss))
+        if epoch == 0:
+            fit.write_back()
+            for (name, pa), (_n, pb) in zip(fa.named_parameters(), fb.named_parameters()):
+                gr = grads[name]
+                big = gr.abs() > 1e-4 * gr.abs().max()
+                assert big.float().mean() > 0.5, name
+                np.testing.assert_allclose(pa.detach()[big].cpu().numpy(), pb.detach()[big].cpu().numpy(), atol=2e-6, rtol=0,
+                                           err_msg=name)
+    la, lb = np.array(la), np.array(lb)
+    assert lb[-1] < lb[0] - 1.0                                           # it learns: nats over 64 dimensions
+    np.testing.assert_allclose(la[:8], lb[:8], rtol=1e-3)
+    np.testing.assert_allclose(la, lb, rtol=2e-2, atol=5e-2)
+
+
+def test_flow_fit_api_goes_through_the_device_path(dev, monkeypatch):
+    """`Flow.fit(x, x_val=..., keep_best_weights=True)` (the call of jump.py:139-149) with the step on the device against
+    the eager torch loop (NFMC_FIT_TORCH=1): both end at the same validation NLL."""
+    from nfmc_amd import flow_training as ft
+    d, n = 64, 1500
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n, d, generator=g) * torch.linspace(0.4, 1.6, d) + 0.3
+    xv = torch.randn(400, d, generator=g) * torch.linspace(0.4, 1.6, d) + 0.3
+    res = []
+    for torch_path in ('0', '1'):
+        monkeypatch.setenv('NFMC_FIT_TORCH', torch_path)
+        calls = []
+        orig = ft.DeviceFit.step
+        monkeypatch.setattr(ft.DeviceFit, 'step', lambda self, xx, k, _o=orig: (calls.append(k), _o(self, xx, k))[1])
+        _of, f = _flow(d, 4, 2, 2, 11)
+        n0 = float(-f.log_prob(xv.to(dev)).mean())
+        f.fit(x, x_val=xv, n_epochs=25, lr=0.02, early_stopping=False, keep_best_weights=True, show_progress=False)
+        res.append((n0, float(-f.log_prob(xv.to(dev)).mean()), len(calls)))
+        monkeypatch.setattr(ft.DeviceFit, 'step', orig)
+    (n0, na, ca), (_n0, nb, cb) = res
+    assert ca == 25 and cb == 0                                           # the device path ran / was switched off
+    assert na < n0 - 1.0 and nb < n0 - 1.0
+    assert abs(na - nb) < 2e-2 * abs(n0 - nb)
+
+
+def test_device_fit_early_stopping_best_weights_and_divergence(dev):
+    """The loop semantics of flow_training._loop on the device path: early stopping counts epochs without improvement of the
+    validation loss, the best weights come back, a non-finite loss raises ValueError (jump.py:150) and leaves the weights
+    the flow came in with."""
+    from nfmc_amd import flow_training as ft
+    d = 16
+    _of, f = _flow(d, 4, 2, 2, 2)
+    f.to(dev)
+    g = torch.Generator().manual_seed(1)
+    x = (torch.randn(256, d, generator=g) * 0.5).to(dev)
+    xv = (torch.randn(64, d, generator=g) * 3.0 + 2.0).to(dev)          # a validation set the training set says nothing about
+    steps = []
+    orig = ft.DeviceFit.step
+    ft.DeviceFit.step = lambda self, xx, k: (steps.append(k), orig(self, xx, k))[1]
+    try:
+        f.fit(x, x_val=xv, n_epochs=400, lr=0.05, early_stopping=True, early_stopping_threshold=5, keep_best_weights=True,
+              show_progress=False)
+    finally:
+        ft.DeviceFit.step = orig
+    assert 6 <= len(steps) < 400 and steps == list(range(len(steps)))   # stopped early; one applied step per epoch
+    before = copy.deepcopy(f.state_dict())
+    bad = x.clone()
+    bad[3, 2] = float('nan')
+    with pytest.raises(ValueError):
+        f.fit(bad, n_epochs=5, show_progress=False)
+    for k, v in f.state_dict().items():
+        assert torch.equal(v, before[k]), k
+
+
+def test_refit_inside_a_jump_run_uses_the_device_path(dev, monkeypatch):
+    """jump.py:193-201 with fit_nf: the refits of a sampling run go through nfmc_flow_fit_step_f32 (spied), the proposal
+    improves (jump acceptance rises from ~0 for the unfitted flow) and the statistics stay those of the target."""
+    from nfmc_amd import flow_training as ft, sample
+    from nfmc_amd.potentials import SumOfSquares
+    d, n = 32, 2048
+    calls = []
+    orig = ft.DeviceFit.step
+    monkeypatch.setattr(ft.DeviceFit, 'step', lambda self, xx, k: (calls.append(int(xx.shape[0])), orig(self, xx, k))[1])
+    x0 = torch.randn(n, d, generator=torch.Generator().manual_seed(0)) * 0.7071
+    torch.manual_seed(1)
+    out = sample(SumOfSquares((d,)), strategy='jump_mala', flow='realnvp', x0=x0, n_iterations=8, show_progress=False, seed=0,
+                 inner_param_kwargs={'n_iterations': 10},
+                 param_kwargs={'store_samples': False, 'fit_nf': True, 'n_jumps_before_training': 2,
+                               'flow_fit_kwargs': {'n_epochs': 60, 'lr': 0.02}})
+    assert len(calls) >= 60 and max(calls) <= 4096                      # train_val_split caps (sampling/base.py:46-61)
+    st = out.statistics
+    assert st.jump_acceptance_rate > 0.05, st.jump_acceptance_rate
+    np.testing.assert_allclose(out.variance.numpy(), 0.5, rtol=5e-2)
+    assert math.isfinite(float(out.mean.abs().max()))

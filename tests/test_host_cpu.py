@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(handle, name), f'{name} declared in include/nfmc_hip.h but not exported'
     assert declared == {s[0] for s in hip.SYMBOLS}, 'hip.SYMBOLS and the header disagree'
     lim = hip.limits()
-    assert lim.abi_version == 2 and lim.max_d_sampler >= 256 and lim.max_steps_per_call == hip.MAX_STEPS_PER_CALL
+    assert lim.abi_version == hip.NFMC_ABI_VERSION == 3 and lim.max_d_sampler >= 256 and lim.max_steps_per_call == hip.MAX_STEPS_PER_CALL
     assert hip.lib().nfmc_error_string(-5).decode().startswith('statistics scratch')
     assert hip.lib().nfmc_stats_scratch_bytes(64) > 0 and hip.lib().nfmc_stats_scratch_bytes(5000) == 0
     assert hip.lib().nfmc_realnvp_padded_hidden(5) == 8 and hip.lib().nfmc_realnvp_padded_hidden(100) == 128
@@ -42,7 +42,7 @@ def test_struct_sizes_match_the_header():
     """Compile a tiny C program against include/nfmc_hip.h and compare sizeof() with the ctypes mirrors."""
     from nfmc_amd import hip
     names = ['NfmcPotential', 'NfmcRng', 'NfmcStats', 'NfmcSampleStore', 'NfmcTune', 'NfmcJumpTail', 'NfmcMalaArgs', 'NfmcHmcArgs', 'NfmcRealNVP', 'NfmcFlowMhArgs',
-             'NfmcNeutraHmcArgs', 'NfmcSelectArgs', 'NfmcLimits']
+             'NfmcNeutraHmcArgs', 'NfmcSelectArgs', 'NfmcLimits', 'NfmcAdamW', 'NfmcFlowFit']
     src = '#include <stdio.h>\n#include "nfmc_hip.h"\nint main(){' + ''.join(
         f'printf("%zu\\n", sizeof({n}));' for n in names) + 'return 0;}'
     import tempfile
