@@ -405,6 +405,11 @@ typedef struct {
 int nfmc_flow_fit_supported_f32(const NfmcRealNVP* flow);
 int64_t nfmc_flow_fit_partial_floats(int64_t n, int64_t n_params);
 int nfmc_flow_fit_step_f32(const NfmcFlowFit* fit, const float* x, int64_t n, const NfmcAdamW* opt, nfmc_stream_t stream);
+/* The same step for the variational fit of imh.py:67-72 / neutra.py:84-91 (`Flow.variational_fit`): rows z (n, d) are
+ * latents drawn from N(0, I) by the caller, the loss is the reverse KL estimate mean[log q(x) - log p(x)], x = f^-1(z),
+ * with -log p = the closed-form potential `pot` (its gradient is evaluated in the kernel). */
+int nfmc_flow_variational_fit_step_f32(const NfmcFlowFit* fit, const NfmcPotential* pot, const float* z, int64_t n,
+                                       const NfmcAdamW* opt, nfmc_stream_t stream);
 
 typedef struct {
     int32_t abi_version;

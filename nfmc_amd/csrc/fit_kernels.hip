@@ -1,8 +1,10 @@
-// f1: maximum-likelihood (re)fit of the RealNVP proposal on the device -- one optimiser step per call:
-//   nll_grad_kernel   mean negative log-likelihood of the batch and its gradient with respect to EVERY parameter
+// f1: maximum-likelihood (re)fit and variational (reverse-KL) fit of the RealNVP proposal on the device -- one optimiser
+// step per call:
+//   fit_grad_kernel   mean loss of the batch and its gradient with respect to EVERY parameter
 //   adamw_fold_kernel fixed-order fold of the per-workgroup partial gradients + the AdamW update, in one launch
 // Replaces the torchflows `Flow.fit` epochs the reference runs at jump.py:139-151 (warmup), jump.py:193-201 (refit every
-// outer iteration when fit_nf) and imh.py:166-170 (AdaptiveIMH's one-epoch refits), which the round-2 build evaluated with
+// outer iteration when fit_nf), imh.py:166-170 (AdaptiveIMH's one-epoch refits) and the `Flow.variational_fit` epochs of
+// imh.py:67-72 / neutra.py:84-91 (warmup of the independence and NeuTra samplers), which the round-2 build evaluated with
 // eager torch autograd + torch.optim.AdamW (2.75 ms per epoch at the C5 shape: ~50 small launches forward and backward).
 //
 // Layout: one wave per workgroup, one batch row per lane, the wave's (64, d) tile of rows in LDS twice (state and its
@@ -44,10 +46,16 @@ __device__ __forceinline__ FitOff fit_offsets(const FlowGeom& g, int HP) {
     return o;
 }
 
-template <int HP>
-__global__ void __launch_bounds__(kFitBlock) nll_grad_kernel(NfmcRealNVP f, const float* __restrict__ x, int64_t n,
-                                                             float* __restrict__ partial, int64_t pstride, int64_t ea_off,
-                                                             int d4, int64_t n_params, int64_t tiles) {
+// RKL = false: maximum likelihood.  Rows are data x; forward sweep x -> z, loss_i = -log N(z_i) - logdet_forward; the
+//   backward sweep walks the layers last to first, rebuilding each layer's INPUT from its output.
+// RKL = true: reverse KL (variational fit, imh.py:67-72 / neutra.py:84-91).  Rows are latents z ~ N(0, I); inverse sweep
+//   z -> x = f^-1(z), loss_i = log q(x_i) - log p(x_i) = log N(z_i) - logdet_inverse + U(x_i) with the closed-form potential
+//   U = -log p and its gradient; the backward sweep walks the layers first to last, rebuilding each inverse layer's INPUT
+//   (the forward map's output) from its output.  Same phases, different elementwise formulas.
+template <int HP, bool RKL>
+__global__ void __launch_bounds__(kFitBlock) fit_grad_kernel(NfmcRealNVP f, NfmcPotential pot, const float* __restrict__ x,
+                                                             int64_t n, float* __restrict__ partial, int64_t pstride,
+                                                             int64_t ea_off, int d4, int64_t n_params, int64_t tiles) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const FlowGeom g = make_geom(f);
     const int d = g.d, stride = tile_stride(d), hs = fit_hb_stride(HP);
@@ -68,39 +76,73 @@ __global__ void __launch_bounds__(kFitBlock) nll_grad_kernel(NfmcRealNVP f, cons
         const int nvalid = (int)(n - r0 < 64 ? n - r0 : 64);
         const bool valid = lane < nvalid;
         __syncthreads();
-        tile_load(xt, stride, x, r0, n, d);
+        tile_load(xt, stride, x, r0, n, d, RKL && rev_last);
         __syncthreads();
-        // ---- forward: z = f(x) in place, loss_i = -log N(z) - logdet
-        const float ld = flow_forward_row<HP>(xrow, f, g);
-        float ss = 0.f;
-        for (int c = 0; c < d; ++c) {
-            const float z = xrow[c];
-            ss = fmaf(z, z, ss);
-            grow[c] = valid ? z : 0.f;           // dL/dz of 0.5 |z|^2; rows beyond the batch carry no gradient
-        }
-        if (valid) {
-            loss_acc += 0.5f * ss + 0.5f * (float)d * kLog2Pi - ld;
-            rows_acc += 1.f;
-        }
-        __syncthreads();
-        // ---- last ElementwiseAffine (logical coordinates), transposed: z_p = e^s y_p + t
-        for (int c = lane; c < d; c += kFitBlock) {
-            const int p = phys(c, d, rev_last);
-            const float s = f.ea1_log_scale[c], t = f.ea1_shift[c];
-            const float es = fast_exp(s), eis = fast_exp(-s);
-            float as = 0.f, at = 0.f;
-            for (int r = 0; r < 64; ++r) {
-                const float gz = gt[r * stride + p], zc = xt[r * stride + p] - t;
-                as = fmaf(gz, zc, as);
-                at += gz;
-                gt[r * stride + p] = gz * es;
-                xt[r * stride + p] = zc * eis;
+        if constexpr (!RKL) {
+            // ---- forward: z = f(x) in place, loss_i = -log N(z) - logdet
+            const float ld = flow_forward_row<HP>(xrow, f, g);
+            float ss = 0.f;
+            for (int c = 0; c < d; ++c) {
+                const float z = xrow[c];
+                ss = fmaf(z, z, ss);
+                grow[c] = valid ? z : 0.f;           // dL/dz of 0.5 |z|^2; rows beyond the batch carry no gradient
             }
-            emit(ea_off + 2 * d4 + c, as - (float)nvalid);   // d(-logdet)/ds = -1 per row
-            emit(ea_off + 3 * d4 + c, at);
+            if (valid) {
+                loss_acc += 0.5f * ss + 0.5f * (float)d * kLog2Pi - ld;
+                rows_acc += 1.f;
+            }
+        } else {
+            // ---- x = f^-1(z) in place, loss_i = log N(z) - logdet_inverse + U(x); dL/dx = grad U
+            float ss = 0.f;
+            for (int c = 0; c < d; ++c) ss = fmaf(xrow[c], xrow[c], ss);
+            const float ld = flow_inverse_row<HP>(xrow, f, g);
+            const float u = potential_value_grad_row(xrow, grow, pot, d);
+            if (!valid)
+                for (int c = 0; c < d; ++c) grow[c] = 0.f;
+            if (valid) {
+                loss_acc += -0.5f * ss - 0.5f * (float)d * kLog2Pi - ld + u;
+                rows_acc += 1.f;
+            }
         }
         __syncthreads();
-        for (int l = g.n_coupling - 1; l >= 0; --l) {
+        if constexpr (!RKL) {
+            // ---- last ElementwiseAffine (logical coordinates), transposed: z_p = e^s y_p + t
+            for (int c = lane; c < d; c += kFitBlock) {
+                const int p = phys(c, d, rev_last);
+                const float s = f.ea1_log_scale[c], t = f.ea1_shift[c];
+                const float es = fast_exp(s), eis = fast_exp(-s);
+                float as = 0.f, at = 0.f;
+                for (int r = 0; r < 64; ++r) {
+                    const float gz = gt[r * stride + p], zc = xt[r * stride + p] - t;
+                    as = fmaf(gz, zc, as);
+                    at += gz;
+                    gt[r * stride + p] = gz * es;
+                    xt[r * stride + p] = zc * eis;
+                }
+                emit(ea_off + 2 * d4 + c, as - (float)nvalid);   // d(-logdet)/ds = -1 per row
+                emit(ea_off + 3 * d4 + c, at);
+            }
+        } else {
+            // ---- first ElementwiseAffine inverted, transposed: x = (y - t) e^-s, -logdet_inverse contains +s
+            for (int c = lane; c < d; c += kFitBlock) {
+                const float s = f.ea0_log_scale[c], t = f.ea0_shift[c];
+                const float es = fast_exp(s), eis = fast_exp(-s);
+                float as = 0.f, at = 0.f;
+                for (int r = 0; r < 64; ++r) {
+                    const float gx = gt[r * stride + c], xv = xt[r * stride + c];
+                    const float gy = gx * eis;
+                    as = fmaf(-gx, xv, as);
+                    at -= gy;
+                    gt[r * stride + c] = gy;
+                    xt[r * stride + c] = fmaf(es, xv, t);
+                }
+                emit(ea_off + c, as + (float)nvalid);
+                emit(ea_off + d4 + c, at);
+            }
+        }
+        __syncthreads();
+        for (int li = 0; li < g.n_coupling; ++li) {
+            const int l = RKL ? li : g.n_coupling - 1 - li;
             const bool rev = (l & 1) == 0;
             const float* __restrict__ W = f.weights + l * g.layer_stride;
             const int64_t L0 = (int64_t)l * g.layer_stride;
@@ -150,12 +192,25 @@ __global__ void __launch_bounds__(kFitBlock) nll_grad_kernel(NfmcRealNVP f, cons
                     const float alpha = fast_exp(fmaf(0.5f, ua, g.log1m)) + g.m;
                     const float ra = __builtin_amdgcn_rcpf(alpha);
                     const int p = phys(g.d_a + t, d, rev);
-                    const float xb = (xrow[p] - 0.5f * ub) * ra;
-                    const float gz = grow[p];
-                    xrow[p] = xb;                                    // the layer's input
-                    grow[p] = gz * alpha;                            // dL/dx_b
-                    const float ga = fmaf(gz, xb, valid ? -ra : 0.f);   // dL/dalpha: z_b = alpha x_b + beta, -log alpha
-                    const float da = 0.5f * ga * (alpha - g.m), db = 0.5f * gz;
+                    float da, db;
+                    if constexpr (!RKL) {
+                        const float xb = (xrow[p] - 0.5f * ub) * ra;
+                        const float gz = grow[p];
+                        xrow[p] = xb;                                    // the layer's input
+                        grow[p] = gz * alpha;                            // dL/dx_b
+                        const float ga = fmaf(gz, xb, valid ? -ra : 0.f);   // dL/dalpha: z_b = alpha x_b + beta, -log alpha
+                        da = 0.5f * ga * (alpha - g.m);
+                        db = 0.5f * gz;
+                    } else {
+                        // inverse layer v_b = (y_b - beta) / alpha with +log alpha in the loss; the tile holds v, dL/dv
+                        const float vb = xrow[p], gv = grow[p];
+                        xrow[p] = fmaf(alpha, vb, 0.5f * ub);            // the inverse layer's input y_b
+                        const float gy = gv * ra;
+                        grow[p] = gy;                                    // dL/dy_b
+                        const float ga = ((valid ? 1.f : 0.f) - gv * vb) * ra;
+                        da = 0.5f * ga * (alpha - g.m);
+                        db = -0.5f * gy;
+                    }
 #pragma unroll
                     for (int k = 0; k < HP; ++k) gh[k] = fmaf(wa[k], da, fmaf(wb[k], db, gh[k]));
                 }
@@ -195,31 +250,44 @@ __global__ void __launch_bounds__(kFitBlock) nll_grad_kernel(NfmcRealNVP f, cons
             // ---- TRANSPOSED phases (lane = output coordinate; rows walked in order)
             // W3 (2 d_b, HP) and b3: the lane re-derives alpha of (row, t) from the row's stored activations
             for (int t = lane; t < g.d_b; t += kFitBlock) {
-                float wa[HP], aa[HP], ab[HP];
+                float wa[HP], wb[RKL ? HP : 1], aa[HP], ab[HP];
                 const float* war = W + o.w3 + (int64_t)t * HP;
+                const float* wbr = W + o.w3 + (int64_t)(g.d_b + t) * HP;
 #pragma unroll
                 for (int k = 0; k < HP; ++k) {
                     wa[k] = war[k];
+                    if constexpr (RKL) wb[k] = wbr[k];
                     aa[k] = 0.f;
                     ab[k] = 0.f;
                 }
-                const float ba = W[o.b3 + t];
+                const float ba = W[o.b3 + t], bb = W[o.b3 + g.d_b + t];
                 float sa = 0.f, sb = 0.f;
                 const int p = phys(g.d_a + t, d, rev);
                 for (int r = 0; r < 64; ++r) {
                     const float* hrow = hb + r * hs;
                     float h[HP];
-                    float ua = ba;
+                    float ua = ba, ub = bb;
 #pragma unroll
                     for (int k = 0; k < HP; ++k) {
                         h[k] = hrow[k];
                         ua = fmaf(wa[k], h[k], ua);
+                        if constexpr (RKL) ub = fmaf(wb[k], h[k], ub);
                     }
                     const float alpha = fast_exp(fmaf(0.5f, ua, g.log1m)) + g.m;
                     const float ra = __builtin_amdgcn_rcpf(alpha);
-                    const float gz = gt[r * stride + p] * ra, xb = xt[r * stride + p];
-                    const float ga = fmaf(gz, xb, r < nvalid ? -ra : 0.f);
-                    const float da = 0.5f * ga * (alpha - g.m), db = 0.5f * gz;
+                    float da, db;
+                    if constexpr (!RKL) {
+                        const float gz = gt[r * stride + p] * ra, xb = xt[r * stride + p];
+                        const float ga = fmaf(gz, xb, r < nvalid ? -ra : 0.f);
+                        da = 0.5f * ga * (alpha - g.m);
+                        db = 0.5f * gz;
+                    } else {
+                        const float gy = gt[r * stride + p];                         // = dL/dv / alpha
+                        const float vb = (xt[r * stride + p] - 0.5f * ub) * ra;
+                        const float ga = ((r < nvalid ? 1.f : 0.f) - gy * alpha * vb) * ra;
+                        da = 0.5f * ga * (alpha - g.m);
+                        db = -0.5f * gy;
+                    }
                     sa += da;
                     sb += db;
 #pragma unroll
@@ -270,17 +338,33 @@ __global__ void __launch_bounds__(kFitBlock) nll_grad_kernel(NfmcRealNVP f, cons
             }
             __syncthreads();
         }
-        // ---- first ElementwiseAffine, transposed: the tile holds its OUTPUT y = e^s x + t and dL/dy
-        for (int c = lane; c < d; c += kFitBlock) {
-            const float t = f.ea0_shift[c];
-            float as = 0.f, at = 0.f;
-            for (int r = 0; r < 64; ++r) {
-                const float gy = gt[r * stride + c];
-                as = fmaf(gy, xt[r * stride + c] - t, as);
-                at += gy;
+        if constexpr (!RKL) {
+            // ---- first ElementwiseAffine, transposed: the tile holds its OUTPUT y = e^s x + t and dL/dy
+            for (int c = lane; c < d; c += kFitBlock) {
+                const float t = f.ea0_shift[c];
+                float as = 0.f, at = 0.f;
+                for (int r = 0; r < 64; ++r) {
+                    const float gy = gt[r * stride + c];
+                    as = fmaf(gy, xt[r * stride + c] - t, as);
+                    at += gy;
+                }
+                emit(ea_off + c, as - (float)nvalid);
+                emit(ea_off + d4 + c, at);
             }
-            emit(ea_off + c, as - (float)nvalid);
-            emit(ea_off + d4 + c, at);
+        } else {
+            // ---- last ElementwiseAffine inverted (logical coordinates), transposed: the tile holds v = (z - t) e^-s and dL/dv
+            for (int c = lane; c < d; c += kFitBlock) {
+                const int p = phys(c, d, rev_last);
+                const float eis = fast_exp(-f.ea1_log_scale[c]);
+                float as = 0.f, at = 0.f;
+                for (int r = 0; r < 64; ++r) {
+                    const float gv = gt[r * stride + p];
+                    as = fmaf(-gv, xt[r * stride + p], as);
+                    at = fmaf(-gv, eis, at);
+                }
+                emit(ea_off + 2 * d4 + c, as + (float)nvalid);
+                emit(ea_off + 3 * d4 + c, at);
+            }
         }
         first = false;
     }
@@ -364,12 +448,13 @@ extern "C" int64_t nfmc_flow_fit_partial_floats(int64_t n, int64_t n_params) {
     return (int64_t)fit_grid(n) * (n_params + kFitTail);
 }
 
-extern "C" int nfmc_flow_fit_step_f32(const NfmcFlowFit* fit, const float* x, int64_t n, const NfmcAdamW* opt,
-                                      nfmc_stream_t stream) {
+static int fit_step(const NfmcFlowFit* fit, const NfmcPotential* pot, const float* x, int64_t n, const NfmcAdamW* opt,
+                    nfmc_stream_t stream) {
     if (!fit || !x || !opt || n <= 0) return NFMC_EINVAL;
     const NfmcRealNVP& f = fit->flow;
     if (!fit->params || !fit->adam_m || !fit->adam_v || !fit->partial || !fit->status) return NFMC_EINVAL;
     if (!fit_supported(&f)) return NFMC_EUNSUPPORTED;
+    if (pot && pot->kind != NFMC_POT_QUADRATIC && pot->kind != NFMC_POT_FUNNEL) return NFMC_EUNSUPPORTED;
     const int d4 = (f.d + 3) / 4 * 4;
     if (fit->ea_off < (int64_t)f.n_coupling * f.layer_stride || fit->n_params < fit->ea_off + 4 * d4) return NFMC_EINVAL;
     // the flow's pointers must be views of the trainable vector in the gradient's layout
@@ -384,14 +469,19 @@ extern "C" int nfmc_flow_fit_step_f32(const NfmcFlowFit* fit, const float* x, in
     const int hp = nfmc_realnvp_padded_hidden(f.n_hidden);
     const size_t lds = fit_lds_bytes(f.d, hp);
     const int64_t tiles = (n + 63) / 64;
-#define NFMC_FIT_LAUNCH(HPV)                                                                                              \
+    NfmcPotential p0 = {};
+    if (pot) p0 = *pot;
+#define NFMC_FIT_LAUNCH2(HPV, RKLV)                                                                                       \
     {                                                                                                                     \
-        auto kern = nll_grad_kernel<HPV>;                                                                                 \
+        auto kern = fit_grad_kernel<HPV, RKLV>;                                                                           \
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
         if (e != hipSuccess) return (int)e;                                                                               \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kFitBlock), lds, st, f, x, n, fit->partial, pstride, fit->ea_off, d4,   \
-                           fit->n_params, tiles);                                                                         \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kFitBlock), lds, st, f, p0, x, n, fit->partial, pstride, fit->ea_off,   \
+                           d4, fit->n_params, tiles);                                                                     \
     }
+#define NFMC_FIT_LAUNCH(HPV)            \
+    if (pot) NFMC_FIT_LAUNCH2(HPV, true) \
+    else NFMC_FIT_LAUNCH2(HPV, false)
     switch (hp) {
         case 4: NFMC_FIT_LAUNCH(4) break;
         case 8: NFMC_FIT_LAUNCH(8) break;
@@ -400,9 +490,21 @@ extern "C" int nfmc_flow_fit_step_f32(const NfmcFlowFit* fit, const float* x, in
         default: return NFMC_EUNSUPPORTED;
     }
 #undef NFMC_FIT_LAUNCH
+#undef NFMC_FIT_LAUNCH2
     const int ablocks = (int)((fit->n_params + 255) / 256);
     hipLaunchKernelGGL(adamw_fold_kernel, dim3(ablocks < 1024 ? ablocks : 1024), dim3(256), 0, st, fit->params, fit->adam_m,
                        fit->adam_v, fit->partial, pstride, grid, fit->n_params, *opt, fit->status);
     NFMC_HIP_CHECK_LAUNCH();
     return NFMC_OK;
+}
+
+extern "C" int nfmc_flow_fit_step_f32(const NfmcFlowFit* fit, const float* x, int64_t n, const NfmcAdamW* opt,
+                                      nfmc_stream_t stream) {
+    return fit_step(fit, nullptr, x, n, opt, stream);
+}
+
+extern "C" int nfmc_flow_variational_fit_step_f32(const NfmcFlowFit* fit, const NfmcPotential* pot, const float* z, int64_t n,
+                                                  const NfmcAdamW* opt, nfmc_stream_t stream) {
+    if (!pot) return NFMC_EINVAL;
+    return fit_step(fit, pot, z, n, opt, stream);
 }

@@ -488,6 +488,30 @@ __device__ __forceinline__ float potential_row(const float* __restrict__ row, co
     return u;
 }
 
+// grad of the closed-form potential for a whole row, written to grow (physical order == x order)
+__device__ __forceinline__ float potential_value_grad_row(const float* __restrict__ row, float* __restrict__ grow,
+                                                          const NfmcPotential& p, int d) {
+    if (p.kind == NFMC_POT_FUNNEL) {
+        const float x0 = row[0];
+        float s = 0.f;
+        for (int c = 1; c < d; ++c) s = fmaf(row[c], row[c], s);
+        const float inv_s2 = 1.f / (p.a_scalar * p.a_scalar);
+        const float e = fast_exp(-x0);
+        const float hd = 0.5f * (float)(d - 1);
+        grow[0] = x0 * inv_s2 - 0.5f * e * s + hd;
+        for (int c = 1; c < d; ++c) grow[c] = row[c] * e;
+        return 0.5f * x0 * x0 * inv_s2 + 0.5f * e * s + hd * x0;
+    }
+    float u = 0.f;
+    for (int c = 0; c < d; ++c) {
+        const float a = p.a ? p.a[c] : p.a_scalar;
+        const float t = row[c] - (p.b ? p.b[c] : p.b_scalar);
+        u = fmaf(a * t, t, u);
+        grow[c] = 2.f * a * t;
+    }
+    return u;
+}
+
 // Coalesced wave-tile IO: rows r0 .. r0+63 of a row-major (n, d) array <-> tile[64][stride].
 // `rev` stores column c of the array at tile column d-1-c (latent side of a flow with an odd number of
 // reversals, see latent_col).

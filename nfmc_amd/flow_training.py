@@ -7,8 +7,9 @@ surface nfmc passes (`early_stopping`, `early_stopping_threshold`, `keep_best_we
 
 `fit` of a RealNVP / NICE flow with a narrow conditioner (n_hidden <= 32, d <= 256: every default flow) runs on the device:
 `DeviceFit` drives `nfmc_flow_fit_step_f32` (csrc/fit_kernels.hip: hand-written reverse sweep with weight gradients +
-fused AdamW), two launches per epoch.  Everything else -- `variational_fit`, spline couplings, wide conditioners,
-mini-batches -- evaluates the same spec with differentiable torch ops (on the GPU when there is one).
+fused AdamW), two launches per epoch; so does `variational_fit` when the caller knows the target as a closed-form potential
+(`potential=`, which the samplers pass).  Everything else -- spline couplings, wide conditioners, mini-batches, arbitrary
+Python targets -- evaluates the same spec with differentiable torch ops (on the GPU when there is one).
 None of it is on the sampling path: `sample()` never calls into it unless `warmup=True` / `fit_nf=True`.
 """
 import math
@@ -211,6 +212,14 @@ class DeviceFit:
         self.hip.check(self.hip.lib().nfmc_flow_fit_step_f32(self.C.byref(self.fit), self.hip.ptr(x), int(x.shape[0]),
                                                              self.C.byref(self.opt), self.hip.stream()), 'nfmc_flow_fit_step_f32')
 
+    def step_variational(self, z, pot_struct, applied_steps):
+        """One AdamW step on the reverse-KL estimate mean[log q(x) - log p(x)], x = f^-1(z), for latents z (n, d) on the
+        device and a closed-form potential descriptor (hip.NfmcPotential) as -log p."""
+        self.opt.step = int(applied_steps) + 1
+        self.hip.check(self.hip.lib().nfmc_flow_variational_fit_step_f32(
+            self.C.byref(self.fit), self.C.byref(pot_struct), self.hip.ptr(z), int(z.shape[0]), self.C.byref(self.opt),
+            self.hip.stream()), 'nfmc_flow_variational_fit_step_f32')
+
     def nll(self, x):
         """Mean NLL of rows x under the CURRENT trainable vector (forward kernel), as a device scalar."""
         n = int(x.shape[0])
@@ -316,16 +325,60 @@ def fit(flow, x_train, x_val=None, n_epochs: int = 500, lr: float = 0.05, batch_
           show_progress, time_limit_seconds)
 
 
+def _variational_fit_device(flow, potential, dev, n_epochs, lr, n_samples, early_stopping, early_stopping_threshold,
+                            keep_best_weights, check_for_divergences, time_limit_seconds):
+    """`_loop` for the reverse-KL fit with the step on the device: each epoch draws its latents with torch.randn on the
+    device (the global CUDA generator, as the torch path does), then ONE ABI call; the host reads the 8-byte status.
+    A non-finite epoch is skipped (the kernel applies no step) or raises, as `check_for_divergences` says."""
+    d = flow.bijection.d
+    fitter = DeviceFit(flow.bijection, dev, n_samples, lr)
+    pot = potential.descriptor(dev)
+    best_loss, best_vec, since_best, applied = math.inf, (fitter.params.clone() if keep_best_weights else None), 0, 0
+    t0 = time.time()
+    try:
+        for _epoch in range(int(n_epochs)):
+            if time_limit_seconds is not None and time.time() - t0 >= time_limit_seconds:
+                break
+            z = torch.randn(n_samples, d, device=dev)
+            fitter.step_variational(z, pot, applied)
+            loss, ok = (float(t) for t in fitter.status.cpu())
+            if not math.isfinite(loss) or ok == 0.0:
+                if check_for_divergences:
+                    raise ValueError('flow training diverged (non-finite loss)')
+                continue
+            applied += 1
+            if loss < best_loss:
+                best_loss, since_best = loss, 0
+                if keep_best_weights:
+                    best_vec.copy_(fitter.params)
+            else:
+                since_best += 1
+                if early_stopping and since_best > early_stopping_threshold:
+                    break
+    finally:
+        fitter.write_back(best_vec if keep_best_weights else None)
+    return best_loss
+
+
 def variational_fit(flow, log_prob_fn, n_epochs: int = 500, lr: float = 0.05, n_samples: int = 1000,
                     early_stopping: bool = False, early_stopping_threshold: int = 50, keep_best_weights: bool = True,
                     check_for_divergences: bool = False, show_progress: bool = False, time_limit_seconds=None,
-                    **_ignored):
-    """Reverse-KL fit: minimise E_{z~N(0,I)} [ log q(x) - log p(x) ], x = f^-1(z)."""
+                    potential=None, **_ignored):
+    """Reverse-KL fit: minimise E_{z~N(0,I)} [ log q(x) - log p(x) ], x = f^-1(z).
+    `potential` (beyond the reference's keywords): the closed-form descriptor of -log p (nfmc_amd.potentials) when the
+    caller has one -- the samplers pass what `resolve_target` found; the step then runs on the device
+    (nfmc_flow_variational_fit_step_f32) for flows the fit kernels cover."""
     dev = _train_device(flow)
     flow.to(dev)
     d = flow.bijection.d
     event_shape = flow.event_shape
     n_samples = max(int(n_samples), 1)
+    import os
+    if (potential is not None and os.environ.get('NFMC_FIT_TORCH') != '1' and hasattr(potential, 'descriptor')
+            and int(getattr(potential, 'event_size', -1)) == d and DeviceFit.supported(flow.bijection, dev)):
+        _variational_fit_device(flow, potential, dev, n_epochs, lr, n_samples, early_stopping, early_stopping_threshold,
+                                keep_best_weights, check_for_divergences, time_limit_seconds)
+        return
 
     def loss_fn():
         z = torch.randn(n_samples, d, device=dev)

@@ -150,6 +150,8 @@ SYMBOLS = [
     ('nfmc_flow_fit_supported_f32', C.c_int, [C.POINTER(NfmcRealNVP)]),
     ('nfmc_flow_fit_partial_floats', C.c_int64, [C.c_int64, C.c_int64]),
     ('nfmc_flow_fit_step_f32', C.c_int, [C.POINTER(NfmcFlowFit), c_fp, C.c_int64, C.POINTER(NfmcAdamW), c_fp]),
+    ('nfmc_flow_variational_fit_step_f32', C.c_int, [C.POINTER(NfmcFlowFit), C.POINTER(NfmcPotential), c_fp, C.c_int64,
+                                                    C.POINTER(NfmcAdamW), c_fp]),
     ('nfmc_limits', C.c_int, [C.POINTER(NfmcLimits)]),
     ('nfmc_error_string', C.c_char_p, [C.c_int]),
     ('nfmc_build_digest', C.c_char_p, []),

@@ -44,6 +44,12 @@ class IMHParameters(NFMCParameters):
             }
 
 
+def _accepts_potential(flow) -> bool:
+    """Only the package's own Flow takes the extra keyword; foreign flow objects get the reference's call."""
+    from ..flows import Flow
+    return isinstance(flow, Flow)
+
+
 class AbstractIMH(Sampler):
     def __init__(self, event_shape, target, kernel: Optional[IMHKernel] = None,
                  params: Optional[IMHParameters] = None):
@@ -55,8 +61,11 @@ class AbstractIMH(Sampler):
 
     def warmup(self, x0, show_progress: bool = True, time_limit_seconds=None) -> MCMCOutput:
         """imh.py:60-75: variational fit of the flow to the target, then one flow sample as state."""
+        # the closed-form descriptor of the target, when there is one, lets the fit step run on the device (flow_training.py)
+        pot = resolve_target(self.target, tuple(x0.shape[1:]), getattr(self, 'fuse', 'auto'), x0)
+        extra = {'potential': pot} if pot is not None and _accepts_potential(self.kernel.flow) else {}
         self.kernel.flow.variational_fit(lambda v: -self.target(v), **self.params.warmup_fit_kwargs,
-                                         show_progress=show_progress, time_limit_seconds=time_limit_seconds)
+                                         show_progress=show_progress, time_limit_seconds=time_limit_seconds, **extra)
         out = MCMCOutput(event_shape=tuple(x0.shape[1:]), store_samples=self.params.store_samples)
         out.running_samples.add(self.kernel.flow.sample(x0.shape[0]).detach())
         return out

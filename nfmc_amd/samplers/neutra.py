@@ -122,9 +122,12 @@ class NeuTra(Sampler):
         """neutra.py:70-107: variational fit, then tune the inner sampler."""
         fit_limit = 0.3 * time_limit_seconds if time_limit_seconds is not None else None
         t0 = time.time()
+        from .imh import _accepts_potential
+        pot = resolve_target(self.target, tuple(x0.shape[1:]), getattr(self, 'fuse', 'auto'), x0)
+        extra = {'potential': pot} if pot is not None and _accepts_potential(self.kernel.flow) else {}
         self.kernel.flow.variational_fit(lambda v: -self.target(v),
                                          **{**dict(time_limit_seconds=fit_limit), **self.params.warmup_fit_kwargs},
-                                         show_progress=show_progress)
+                                         show_progress=show_progress, **extra)
         inner_limit = time_limit_seconds - (time.time() - t0) if time_limit_seconds is not None else None
         self.inner_sampler.params.tuning_mode()
         self.inner_sampler.params.store_samples = self.params.store_samples

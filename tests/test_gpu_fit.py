@@ -103,7 +103,7 @@ def test_device_steps_follow_torch_adamw(dev):
         if epoch == 0:
             grads = {k: p.grad.detach().clone() for k, p in fb.named_parameters()}
         opt.step()
-        lb.append(float(loss))
+        lb.append(float(loss.detach()))
         if epoch == 0:
             fit.write_back()
             for (name, pa), (_n, pb) in zip(fa.named_parameters(), fb.named_parameters()):
@@ -141,6 +141,83 @@ def test_flow_fit_api_goes_through_the_device_path(dev, monkeypatch):
     assert ca == 25 and cb == 0                                           # the device path ran / was switched off
     assert na < n0 - 1.0 and nb < n0 - 1.0
     assert abs(na - nb) < 2e-2 * abs(n0 - nb)
+
+
+RKL_CASES = [  # d, n_hidden, hidden layers, coupling layers, rows, potential
+    (6, 4, 2, 2, 40, 'sum'), (7, 3, 1, 3, 64, 'diag'), (25, 4, 2, 2, 130, 'sum'), (64, 8, 2, 2, 100, 'diag'),
+    (16, 5, 2, 3, 70, 'funnel'), (128, 4, 2, 2, 65, 'funnel'), (256, 7, 2, 2, 200, 'sum'), (1, 4, 2, 2, 10, 'sum'),
+]
+
+
+@pytest.mark.parametrize('d,H,nhl,nl,n,kind', RKL_CASES)
+def test_reverse_kl_gradient_matches_autograd(dev, d, H, nhl, nl, n, kind):
+    """The variational-fit step (imh.py:67-72, neutra.py:84-91): loss mean[log q(x) - log p(x)], x = f^-1(z), and its
+    gradient with respect to every parameter from nfmc_flow_variational_fit_step_f32 (lr = 0, beta1 = 0: first moment =
+    gradient) against autograd through the CPU restatement's inverse pass and the potential's torch form."""
+    from nfmc_amd.flow_training import DeviceFit
+    from nfmc_amd.potentials import DiagonalGaussian, Funnel, SumOfSquares
+    from oracle import flow as oflow
+    of, f = _flow(d, H, nhl, nl, 5 + d)
+    f.to(dev)
+    g0 = torch.Generator().manual_seed(100 + d)
+    if kind == 'sum':
+        pot = SumOfSquares((d,))
+    elif kind == 'diag':
+        pot = DiagonalGaussian((d,), torch.linspace(-0.5, 0.5, d), torch.linspace(0.6, 1.7, d))
+    else:
+        pot = Funnel((d,), 3.0)
+    z = torch.randn(n, d, generator=g0)
+    fit = DeviceFit(f.bijection, dev, n, lr=0.0)
+    fit.opt.beta1, fit.opt.weight_decay = 0.0, 0.0
+    fit.step_variational(z.to(dev), pot.descriptor(dev), 0)
+    torch.cuda.synchronize()
+    loss_gpu, applied = (float(v) for v in fit.status.cpu())
+    x, ld = of.bijection.inverse(z)
+    loss = (of.base_log_prob(z) - ld + pot(x)).mean()
+    loss.backward()
+    assert applied == 1.0
+    np.testing.assert_allclose(loss_gpu, float(loss.detach()), rtol=3e-5, atol=3e-5)
+    gflow = copy.deepcopy(f)
+    fit.bij = gflow.bijection
+    fit.write_back(fit.m)
+    want = dict(of.named_parameters())
+    for name, p in gflow.named_parameters():
+        w = want[name].grad
+        if w is None or w.numel() == 0:      # d = 1: the source half is empty, W1 has no entries
+            continue
+        scale = max(float(w.abs().max()), 1e-3)
+        np.testing.assert_allclose(p.detach().cpu().numpy(), w.numpy(), atol=3e-4 * scale, rtol=0, err_msg=name)
+
+
+def test_variational_fit_through_the_sampler_warmup(dev, monkeypatch):
+    """FixedIMH.warmup (imh.py:60-75) on a target that `resolve_target` recognises: the variational fit runs on the device
+    (spied), the proposal improves (IMH acceptance after the warmup far above the unfitted flow's), and with the device
+    path switched off (NFMC_FIT_TORCH=1) the eager loop reaches a comparable proposal."""
+    from nfmc_amd import flow_training as ft
+    from nfmc_amd.sample import create_sampler
+    d, n = 16, 512
+    acc = {}
+    for torch_path in ('0', '1'):
+        monkeypatch.setenv('NFMC_FIT_TORCH', torch_path)
+        calls = []
+        orig = ft.DeviceFit.step_variational
+        monkeypatch.setattr(ft.DeviceFit, 'step_variational',
+                            lambda self, z, pot, k, _o=orig: (calls.append(int(z.shape[0])), _o(self, z, pot, k))[1])
+        torch.manual_seed(3)
+        s = create_sampler(target=lambda x: torch.sum(x ** 2, dim=-1), event_shape=(d,), strategy='imh',
+                           param_kwargs={'n_iterations': 200, 'store_samples': False})
+        s.seed = 1
+        x0 = torch.randn(n, d, generator=torch.Generator().manual_seed(2))
+        cold = s.sample(x0, show_progress=False).statistics.acceptance_rate
+        s.params.warmup_fit_kwargs.update(n_epochs=150, n_samples=256, lr=0.02)
+        w = s.warmup(x0, show_progress=False)
+        out = s.sample(w.running_samples.last_sample, show_progress=False)
+        acc[torch_path] = (cold, out.statistics.acceptance_rate, len(calls))
+        monkeypatch.setattr(ft.DeviceFit, 'step_variational', orig)
+    (cold, warm, n_dev), (_c, warm_t, n_t) = acc['0'], acc['1']
+    assert 50 <= n_dev <= 150 and n_t == 0      # early stopping (imh.py:27-36 defaults) may end the fit before 150 epochs
+    assert warm > max(0.3, 3 * cold) and warm_t > max(0.3, 3 * cold), acc
+    assert abs(warm - warm_t) < 0.15, acc
 
 
 def test_device_fit_early_stopping_best_weights_and_divergence(dev):
