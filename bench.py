@@ -14,7 +14,9 @@ work (what the CPU test of the launcher uses).
 
 Workload (default C3 = BASELINE.json configs[2]): strategy jump_mala, U = sum x^2, d = 64,
 65536 chains PER GPU (weak scaling: global chain ids continue across ranks), 100 inner MALA transitions per jump
-(h = 64^(-1/3) = 0.25, unit mass), adjusted jumps with the build's default RealNVP (weights seed 1),
+(h = 64^(-1/3) = 0.25, unit mass), adjusted jumps with the build's default RealNVP (weights seed 1) FITTED once before
+any timing by `Flow.fit` on draws of the target -- the state the reference's warmup=True leaves (`--unfitted-flow` keeps the
+random initialisation of rounds 1-2, which accepts ~0.2 % of the jumps; same arithmetic per transition either way),
 store_samples=False, x0 ~ N(0, I) from torch.manual_seed(0) on the CPU, uploaded before the timed region.  One bench
 "step" = one outer iteration = 101 Markov transitions of every chain.  W untimed warm-up steps carry the state from
 x0 to stationarity; then R (>= 5) timed repetitions of EXACTLY K steps each, every repetition bracketed by barrier +
@@ -116,27 +118,47 @@ PARITY_ROWS = 8192
 PMC_STEPS = 3                     # --steps of the PMC passes in tools/profile_bench.sh
 
 
-def build_sampler(cfg, n_steps, fit_nf=False, flow_seed=1):
-    """The sampler of one repetition: K bench steps.  Flow weights from torch.manual_seed(flow_seed)."""
+FLOW_STATE = {}   # config name -> state_dict of the jump configs' FITTED flow (fitted_flow_state), shared by every leg
+
+
+def fitted_flow_state(cfg_name, cfg, dev):
+    """The proposal flow of the jump configs in the state the reference's `warmup=True` leaves it in: the default RealNVP
+    (weights from torch.manual_seed(1)) fitted by maximum likelihood (`Flow.fit`, jump.py:139-149; on the device:
+    csrc/fit_kernels.hip) to 4096 + 1024 draws of the target N(0, I/2) from a fixed generator -- ONCE, outside every timed
+    region.  An unfitted flow accepts ~0.2 % of the jumps; the arithmetic per transition is the same either way."""
+    import torch
+    from nfmc_amd.flows import Flow, RealNVP
+    if cfg_name not in FLOW_STATE:
+        d = cfg['d']
+        torch.manual_seed(1)
+        f = Flow(RealNVP((d,))).to(dev)
+        gen = torch.Generator().manual_seed(7)
+        xt = (torch.randn(4096, d, generator=gen) * 0.7071067811865476).to(dev)
+        xv = (torch.randn(1024, d, generator=gen) * 0.7071067811865476).to(dev)
+        f.fit(xt, x_val=xv, n_epochs=300, lr=0.02, early_stopping=True, early_stopping_threshold=30, keep_best_weights=True,
+              show_progress=False)
+        FLOW_STATE[cfg_name] = {k: v.detach().cpu().clone() for k, v in f.state_dict().items()}
+    return FLOW_STATE[cfg_name]
+
+
+def build_sampler(cfg, n_steps, fit_nf=False, flow_seed=1, flow_state=None):
+    """The sampler of one repetition: K bench steps.  Flow weights from torch.manual_seed(flow_seed), or `flow_state`."""
     import torch
     from nfmc_amd.potentials import Funnel, SumOfSquares
     from nfmc_amd.sample import create_sampler
     d = cfg['d']
     torch.manual_seed(flow_seed)
     st = cfg['strategy']
-    if st == 'jump_mala':
+    if st in ('jump_mala', 'jump_hmc'):
         pk = {'n_iterations': n_steps, 'store_samples': False}
         if fit_nf:
             pk.update(fit_nf=True, n_jumps_before_training=0, flow_fit_kwargs={'n_epochs': 2, 'show_progress': False})
-        return create_sampler(SumOfSquares((d,)), strategy=st, flow='realnvp', param_kwargs=pk,
-                              inner_param_kwargs={'n_iterations': cfg['inner']})
-    if st == 'jump_hmc':
-        pk = {'n_iterations': n_steps, 'store_samples': False}
-        if fit_nf:
-            pk.update(fit_nf=True, n_jumps_before_training=0, flow_fit_kwargs={'n_epochs': 2, 'show_progress': False})
-        return create_sampler(SumOfSquares((d,)), strategy=st, flow='realnvp', param_kwargs=pk,
-                              inner_kernel_kwargs={'n_leapfrog_steps': 20, 'step_size': 0.05},
-                              inner_param_kwargs={'n_iterations': cfg['inner']})
+        kw = {'inner_kernel_kwargs': {'n_leapfrog_steps': 20, 'step_size': 0.05}} if st == 'jump_hmc' else {}
+        s = create_sampler(SumOfSquares((d,)), strategy=st, flow='realnvp', param_kwargs=pk,
+                           inner_param_kwargs={'n_iterations': cfg['inner']}, **kw)
+        if flow_state is not None:
+            s.kernel.flow.load_state_dict(flow_state)
+        return s
     if st == 'imh':
         s = create_sampler(SumOfSquares((d,)), strategy=st, flow='realnvp',
                            param_kwargs={'n_iterations': n_steps * cfg['inner'], 'store_samples': False})
@@ -185,6 +207,8 @@ def _oracle_flow(cfg):
     if cfg['strategy'] == 'neutra_hmc':
         return oflow.Flow(oflow.RealNVP((cfg['d'],), conditioner_kwargs={'n_hidden': 128, 'n_layers': 2}))
     f = oflow.Flow(oflow.RealNVP((cfg['d'],)))
+    if cfg.get('_flow_state') is not None:
+        f.load_state_dict(cfg['_flow_state'])
     return _match_scale_(f) if cfg['strategy'] == 'imh' else f
 
 
@@ -245,7 +269,7 @@ def parity_vs_oracle(cfg, dev):
     from oracle import samplers as osamp
     n, seed = PARITY_ROWS, 123
     x0 = initial_state(cfg, n)
-    s = build_sampler(cfg, 1)
+    s = build_sampler(cfg, 1, flow_state=cfg.get('_flow_state'))
     s.seed = seed
     out = s.sample(x0.to(dev), show_progress=False)
     tr, transitions = _oracle_run(cfg, x0, _oracle_flow(cfg), 1, noise=osamp.PhiloxNoise(seed))
@@ -476,6 +500,9 @@ def main():
     ap.add_argument('--rng-rounds', type=int, choices=[10, 7], default=10,
                     help='Philox4x32 rounds of the noise stream: 10 = the library default (what `value` is quoted on); 7 = the '
                          'opt-in stream.  With the default, C3 / C5 also time the 7-round stream and report it as `philox7`')
+    ap.add_argument('--unfitted-flow', action='store_true',
+                    help='jump configs: keep the randomly initialised proposal flow (round 1-2 behaviour: ~0.2 %% of the jumps '
+                         'accepted) instead of fitting it once, before any timing, as `warmup=True` would')
     ap.add_argument('--backend', choices=['nccl', 'gloo'], default='nccl')
     ap.add_argument('--rehearse', action='store_true', help='launcher / rendezvous / reduction only, no GPU work')
     ap.add_argument('--share-device', action='store_true',
@@ -512,9 +539,13 @@ def main():
     n_local = cfg['n_per_gpu']
     n_total = n_local * world
     x_start = initial_state(cfg, n_total).to(dev)   # resident in HBM before any timed region
+    cfg = dict(cfg)
+    cfg['_flow_state'] = None
+    if cfg['strategy'] in ('jump_mala', 'jump_hmc') and not args.unfitted_flow:
+        cfg['_flow_state'] = fitted_flow_state(args.config, cfg, dev)   # deterministic: every rank fits the same flow
 
     def run(n_steps, x, time_kernels=False, rounds=None):
-        s = build_sampler(cfg, n_steps, fit_nf=args.fit_nf)
+        s = build_sampler(cfg, n_steps, fit_nf=args.fit_nf, flow_state=cfg['_flow_state'])
         s.seed = 0
         s.rng_rounds = args.rng_rounds if rounds is None else rounds
         s.shard = shard
@@ -542,7 +573,7 @@ def main():
     # one-time initialisation outside the timed region whatever W is: library / code-object load, allocator warm-up,
     # weight packing -- ONE step of the same path at the same per-GPU size (every launch a profiler sees has the same
     # shape, so per-kernel averages agree with the HIP-event mean below)
-    prime = build_sampler(cfg, 1)
+    prime = build_sampler(cfg, 1, flow_state=cfg['_flow_state'])
     prime.seed = 0
     prime.sample(x_start[:n_local], show_progress=False)
     torch.cuda.synchronize(dev)
@@ -619,6 +650,10 @@ def main():
                        'x0': 'N(0, I), torch.manual_seed(0) on the CPU, uploaded before timing; W warm-up steps carry it '
                              'to stationarity' + (' (x 0.5 for the funnel)' if cfg['strategy'] == 'neutra_hmc' else ''),
                        'fit_nf': bool(args.fit_nf),
+                       'proposal_flow': ('default RealNVP, weights seed 1' + (
+                           ', fitted ONCE before timing by Flow.fit (maximum likelihood, device path) to 4096 draws of the '
+                           'target: the state warmup=True leaves' if cfg['_flow_state'] is not None else
+                           ' (unfitted)' if cfg['strategy'].startswith('jump') else '')),
                        'sharding': f'chains x{world}, no data-path collective; one statistics all-reduce per sample()'
                                    + ('; refit-buffer all-gather every outer iteration' if args.fit_nf else '')},
             'repetitions': len(reps), 'rep_ms': rep_ms, 'rep_ms_median': statistics.median(rep_ms),

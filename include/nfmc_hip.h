@@ -398,8 +398,13 @@ typedef struct {
     int64_t ea_off;           /* offset of the ElementwiseAffine vectors inside params (multiple of 4) */
     float* partial;           /* scratch, >= nfmc_flow_fit_partial_floats(n, n_params) floats, ZEROED once by the caller */
     int64_t partial_floats;
-    float* status;            /* device (2): [0] mean NLL of the batch at the parameters BEFORE the step;
-                                 [1] 1 if the step was applied, 0 if the loss was not finite (parameters untouched) */
+    float* status;            /* device (3): [0] mean loss of the batch at the parameters BEFORE the step;
+                                 [1] 1 if the step was applied, 0 if the loss was not finite (parameters untouched);
+                                 [2] mean NLL of the validation rows at the parameters BEFORE the step ([0] if none) */
+    const float* x_val;       /* optional (maximum likelihood only): validation rows (n_val, d), evaluated in the same launch */
+    int64_t n_val;
+    float* params_prev;       /* optional (n_params): receives the parameters as they were BEFORE the step -- what the
+                                 validation loss of this call belongs to (best-weights bookkeeping without a second launch) */
 } NfmcFlowFit;
 
 int nfmc_flow_fit_supported_f32(const NfmcRealNVP* flow);

@@ -24,12 +24,18 @@
 namespace nfmc {
 
 constexpr int kFitBlock = 64;
-constexpr int kFitTail = 4;   // per-workgroup partial: [n_params] gradient sums, then sum of losses, number of rows
+constexpr int kFitTail = 4;   // per-workgroup partial: [n_params] gradient sums, then loss sum, rows, validation loss sum, validation rows
 
 __host__ __device__ inline int fit_hb_stride(int hp) { return 4 * hp + 1; }   // odd: lanes = rows write conflict-free
-__host__ __device__ inline size_t fit_lds_bytes(int d, int hp) {
-    return ((size_t)2 * 64 * tile_stride(d) + (size_t)64 * fit_hb_stride(hp)) * sizeof(float);
+__host__ __device__ inline size_t fit_lds_bytes(int d, int hp, int rpw = 64) {
+    return ((size_t)2 * rpw * tile_stride(d) + (size_t)rpw * fit_hb_stride(hp)) * sizeof(float);
 }
+// Rows per wave: 64 (every lane owns a row in the row phases).  Measured alternative at the C5 refit shape (4096 rows,
+// d = 256, conditioner 6 -> 8): 16 rows per wave = 256 waves instead of 64, transposed phases four times shorter -- 325 us per
+// launch against 266 us, and a fold over 256 slabs instead of 64 (72 against 31 us): the row phases, whose length does not
+// depend on the number of rows, dominate (dependent chains behind scalar weight loads, one wave per CU), so fewer, fuller
+// waves win.  The 16-row instantiation stays for batches of at most 16 rows (variational fits draw 1 .. 16 latents).
+__host__ __device__ inline int fit_rows_per_wave(int64_t n) { return n <= 16 ? 16 : 64; }
 
 // offsets of a coupling layer's pieces inside its blob (VALU layout, flow_device.hpp)
 struct FitOff {
@@ -52,32 +58,65 @@ __device__ __forceinline__ FitOff fit_offsets(const FlowGeom& g, int HP) {
 //   z -> x = f^-1(z), loss_i = log q(x_i) - log p(x_i) = log N(z_i) - logdet_inverse + U(x_i) with the closed-form potential
 //   U = -log p and its gradient; the backward sweep walks the layers first to last, rebuilding each inverse layer's INPUT
 //   (the forward map's output) from its output.  Same phases, different elementwise formulas.
-template <int HP, bool RKL>
+// Tiles [0, tiles) are batch rows; tiles [tiles, tiles + vtiles) are VALIDATION rows (maximum likelihood only): forward
+// sweep and loss, no gradient -- they ride in the same launch, on otherwise idle CUs, instead of a second kernel.
+template <int RPW>
+__device__ __forceinline__ void fit_tile_load(float* __restrict__ tile, int stride, const float* __restrict__ src, int64_t r0,
+                                              int64_t n, int d, bool rev) {
+    const int lane = threadIdx.x & 63;
+    const int64_t rows = n - r0 < RPW ? n - r0 : RPW;
+    const int total = (int)rows * d;
+    const float* s = src + r0 * d;
+    for (int i = lane; i < RPW * d; i += kWave) {
+        const int r = i / d, c = i - r * d;
+        tile[r * stride + (rev ? d - 1 - c : c)] = i < total ? s[i] : 0.f;  // rows beyond n: zeros
+    }
+}
+
+template <int HP, bool RKL, int RPW>
 __global__ void __launch_bounds__(kFitBlock) fit_grad_kernel(NfmcRealNVP f, NfmcPotential pot, const float* __restrict__ x,
-                                                             int64_t n, float* __restrict__ partial, int64_t pstride,
-                                                             int64_t ea_off, int d4, int64_t n_params, int64_t tiles) {
+                                                             int64_t n, const float* __restrict__ xv, int64_t nv,
+                                                             float* __restrict__ partial, int64_t pstride,
+                                                             int64_t ea_off, int d4, int64_t n_params, int64_t tiles,
+                                                             int64_t vtiles) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const FlowGeom g = make_geom(f);
     const int d = g.d, stride = tile_stride(d), hs = fit_hb_stride(HP);
     const int lane = threadIdx.x;
     float* const xt = lds;                       // state tile: row r at xt + r * stride
-    float* const gt = lds + 64 * stride;         // gradient of the loss with respect to the state
-    float* const hb = lds + 2 * 64 * stride;     // per row: h_last | delta_last | h_first | delta_first (HP each)
+    float* const gt = lds + RPW * stride;        // gradient of the loss with respect to the state
+    float* const hb = lds + 2 * RPW * stride;    // per row: h_last | delta_last | h_first | delta_first (HP each)
+    const bool rowlane = lane < RPW;             // lanes that own a row in the ROW phases
     float* const xrow = xt + lane * stride;
     float* const grow = gt + lane * stride;
     float* const P = partial + (int64_t)blockIdx.x * pstride;
     const FitOff o = fit_offsets(g, HP);
     const bool rev_last = (g.n_coupling & 1) != 0;
     bool first = true;
-    float loss_acc = 0.f, rows_acc = 0.f;
+    float loss_acc = 0.f, rows_acc = 0.f, vloss_acc = 0.f, vrows_acc = 0.f;
     auto emit = [&](int64_t idx, float v) { P[idx] = first ? v : P[idx] + v; };
-    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        const int64_t r0 = tile * 64;
-        const int nvalid = (int)(n - r0 < 64 ? n - r0 : 64);
+    for (int64_t tile = blockIdx.x; tile < tiles + vtiles; tile += gridDim.x) {
+        if (tile >= tiles) {   // a validation tile (wave-uniform): loss only
+            const int64_t r0 = (tile - tiles) * RPW;
+            __syncthreads();
+            fit_tile_load<RPW>(xt, stride, xv, r0, nv, d, false);
+            __syncthreads();
+            if (rowlane && r0 + lane < nv) {
+                const float ld = flow_forward_row<HP>(xrow, f, g);
+                float ss = 0.f;
+                for (int c = 0; c < d; ++c) ss = fmaf(xrow[c], xrow[c], ss);
+                vloss_acc += 0.5f * ss + 0.5f * (float)d * kLog2Pi - ld;
+                vrows_acc += 1.f;
+            }
+            continue;
+        }
+        const int64_t r0 = tile * RPW;
+        const int nvalid = (int)(n - r0 < RPW ? n - r0 : RPW);
         const bool valid = lane < nvalid;
         __syncthreads();
-        tile_load(xt, stride, x, r0, n, d, RKL && rev_last);
+        fit_tile_load<RPW>(xt, stride, x, r0, n, d, RKL && rev_last);
         __syncthreads();
+        if (rowlane) {
         if constexpr (!RKL) {
             // ---- forward: z = f(x) in place, loss_i = -log N(z) - logdet
             const float ld = flow_forward_row<HP>(xrow, f, g);
@@ -104,6 +143,7 @@ __global__ void __launch_bounds__(kFitBlock) fit_grad_kernel(NfmcRealNVP f, Nfmc
                 rows_acc += 1.f;
             }
         }
+        }
         __syncthreads();
         if constexpr (!RKL) {
             // ---- last ElementwiseAffine (logical coordinates), transposed: z_p = e^s y_p + t
@@ -112,7 +152,7 @@ __global__ void __launch_bounds__(kFitBlock) fit_grad_kernel(NfmcRealNVP f, Nfmc
                 const float s = f.ea1_log_scale[c], t = f.ea1_shift[c];
                 const float es = fast_exp(s), eis = fast_exp(-s);
                 float as = 0.f, at = 0.f;
-                for (int r = 0; r < 64; ++r) {
+                for (int r = 0; r < RPW; ++r) {
                     const float gz = gt[r * stride + p], zc = xt[r * stride + p] - t;
                     as = fmaf(gz, zc, as);
                     at += gz;
@@ -128,7 +168,7 @@ __global__ void __launch_bounds__(kFitBlock) fit_grad_kernel(NfmcRealNVP f, Nfmc
                 const float s = f.ea0_log_scale[c], t = f.ea0_shift[c];
                 const float es = fast_exp(s), eis = fast_exp(-s);
                 float as = 0.f, at = 0.f;
-                for (int r = 0; r < 64; ++r) {
+                for (int r = 0; r < RPW; ++r) {
                     const float gx = gt[r * stride + c], xv = xt[r * stride + c];
                     const float gy = gx * eis;
                     as = fmaf(-gx, xv, as);
@@ -147,7 +187,7 @@ __global__ void __launch_bounds__(kFitBlock) fit_grad_kernel(NfmcRealNVP f, Nfmc
             const float* __restrict__ W = f.weights + l * g.layer_stride;
             const int64_t L0 = (int64_t)l * g.layer_stride;
             // ---- ROW phase (lane = row)
-            {
+            if (rowlane) {
                 float h1[HP], hl[HP];
                 const float* b1 = W + o.b1;
 #pragma unroll
@@ -263,7 +303,7 @@ __global__ void __launch_bounds__(kFitBlock) fit_grad_kernel(NfmcRealNVP f, Nfmc
                 const float ba = W[o.b3 + t], bb = W[o.b3 + g.d_b + t];
                 float sa = 0.f, sb = 0.f;
                 const int p = phys(g.d_a + t, d, rev);
-                for (int r = 0; r < 64; ++r) {
+                for (int r = 0; r < RPW; ++r) {
                     const float* hrow = hb + r * hs;
                     float h[HP];
                     float ua = ba, ub = bb;
@@ -309,13 +349,13 @@ __global__ void __launch_bounds__(kFitBlock) fit_grad_kernel(NfmcRealNVP f, Nfmc
                 for (int e = lane; e < HP * HP; e += kFitBlock) {
                     const int i = e / HP, k = e - i * HP;
                     float a = 0.f;
-                    for (int r = 0; r < 64; ++r) a = fmaf(hb[r * hs + 2 * HP + i], hb[r * hs + HP + k], a);
+                    for (int r = 0; r < RPW; ++r) a = fmaf(hb[r * hs + 2 * HP + i], hb[r * hs + HP + k], a);
                     emit(L0 + o.wht + e, a);
                 }
             }
             if (lane < HP) {
                 float a1 = 0.f, a2 = 0.f;
-                for (int r = 0; r < 64; ++r) {
+                for (int r = 0; r < RPW; ++r) {
                     a1 += hb[r * hs + 3 * HP + lane];
                     a2 += hb[r * hs + HP + lane];
                 }
@@ -328,7 +368,7 @@ __global__ void __launch_bounds__(kFitBlock) fit_grad_kernel(NfmcRealNVP f, Nfmc
 #pragma unroll
                 for (int k = 0; k < HP; ++k) a[k] = 0.f;
                 const int p = phys(j, d, rev);
-                for (int r = 0; r < 64; ++r) {
+                for (int r = 0; r < RPW; ++r) {
                     const float xj = xt[r * stride + p];
 #pragma unroll
                     for (int k = 0; k < HP; ++k) a[k] = fmaf(xj, hb[r * hs + 3 * HP + k], a[k]);
@@ -343,7 +383,7 @@ __global__ void __launch_bounds__(kFitBlock) fit_grad_kernel(NfmcRealNVP f, Nfmc
             for (int c = lane; c < d; c += kFitBlock) {
                 const float t = f.ea0_shift[c];
                 float as = 0.f, at = 0.f;
-                for (int r = 0; r < 64; ++r) {
+                for (int r = 0; r < RPW; ++r) {
                     const float gy = gt[r * stride + c];
                     as = fmaf(gy, xt[r * stride + c] - t, as);
                     at += gy;
@@ -357,7 +397,7 @@ __global__ void __launch_bounds__(kFitBlock) fit_grad_kernel(NfmcRealNVP f, Nfmc
                 const int p = phys(c, d, rev_last);
                 const float eis = fast_exp(-f.ea1_log_scale[c]);
                 float as = 0.f, at = 0.f;
-                for (int r = 0; r < 64; ++r) {
+                for (int r = 0; r < RPW; ++r) {
                     const float gv = gt[r * stride + p];
                     as = fmaf(-gv, xt[r * stride + p], as);
                     at = fmaf(-gv, eis, at);
@@ -368,19 +408,17 @@ __global__ void __launch_bounds__(kFitBlock) fit_grad_kernel(NfmcRealNVP f, Nfmc
         }
         first = false;
     }
-    // loss and row count of this workgroup's rows: fixed-order sum over the lanes
+    // losses and row counts of this workgroup's rows: fixed-order sums over the lanes
     __syncthreads();
     lds[lane] = loss_acc;
     lds[64 + lane] = rows_acc;
+    lds[128 + lane] = vloss_acc;
+    lds[192 + lane] = vrows_acc;
     __syncthreads();
-    if (lane == 0) {
-        float a = 0.f, b = 0.f;
-        for (int r = 0; r < 64; ++r) {
-            a += lds[r];
-            b += lds[64 + r];
-        }
-        P[n_params] = a;
-        P[n_params + 1] = b;
+    if (lane < 4) {
+        float a = 0.f;
+        for (int r = 0; r < 64; ++r) a += lds[64 * lane + r];
+        P[n_params + lane] = a;
     }
 }
 
@@ -389,33 +427,39 @@ __global__ void __launch_bounds__(kFitBlock) fit_grad_kernel(NfmcRealNVP f, Nfmc
 // p <- p - lr (m / bc1) / (sqrt(v / bc2) + eps),  bc = 1 - beta^step.  A non-finite batch loss applies NO step
 // (flow_training._loop: `continue` before backward) and reports it: status[1] = 0.
 __global__ void __launch_bounds__(256) adamw_fold_kernel(float* __restrict__ params, float* __restrict__ am,
-                                                         float* __restrict__ av, const float* __restrict__ partial,
-                                                         int64_t pstride, int nparts, int64_t n_params, NfmcAdamW opt,
-                                                         float* __restrict__ status) {
-    __shared__ float sh[2];
-    if (threadIdx.x == 0) {
-        float ls = 0.f, rows = 0.f;
-        for (int w = 0; w < nparts; ++w) {
-            ls += partial[w * pstride + n_params];
-            rows += partial[w * pstride + n_params + 1];
-        }
-        sh[0] = ls / rows;
-        sh[1] = rows;
+                                                         float* __restrict__ av, float* __restrict__ prev,
+                                                         const float* __restrict__ partial, int64_t pstride, int nparts,
+                                                         int64_t n_params, NfmcAdamW opt, float* __restrict__ status) {
+    __shared__ float sh[4];
+    if (threadIdx.x < 4) {
+        float a = 0.f;
+        for (int w = 0; w < nparts; ++w) a += partial[w * pstride + n_params + threadIdx.x];
+        sh[threadIdx.x] = a;
     }
     __syncthreads();
-    const float loss = sh[0], rows = sh[1];
+    const float rows = sh[1], loss = sh[0] / rows;
     const bool ok = fabsf(loss) <= 3.0e38f;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         status[0] = loss;
         status[1] = ok ? 1.f : 0.f;
+        status[2] = sh[3] > 0.f ? sh[2] / sh[3] : loss;   // validation loss at the parameters BEFORE the step
     }
-    if (!ok) return;
     const float bc1 = 1.f - powf(opt.beta1, (float)opt.step), bc2 = 1.f - powf(opt.beta2, (float)opt.step);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_params; i += (int64_t)gridDim.x * blockDim.x) {
-        float gsum = 0.f;
-        for (int w = 0; w < nparts; ++w) gsum += partial[w * pstride + i];
-        const float gr = gsum / rows;
         float p = params[i];
+        if (prev) prev[i] = p;
+        if (!ok) continue;
+        float gsum = 0.f;
+        int w = 0;
+        for (; w + 8 <= nparts; w += 8) {   // eight loads in flight; the sum keeps the workgroup order
+            float t[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[k] = partial[(w + k) * pstride + i];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) gsum += t[k];
+        }
+        for (; w < nparts; ++w) gsum += partial[w * pstride + i];
+        const float gr = gsum / rows;
         p *= 1.f - opt.lr * opt.weight_decay;
         const float m = opt.beta1 * am[i] + (1.f - opt.beta1) * gr;
         const float v = opt.beta2 * av[i] + (1.f - opt.beta2) * gr * gr;
@@ -425,8 +469,9 @@ __global__ void __launch_bounds__(256) adamw_fold_kernel(float* __restrict__ par
     }
 }
 
-static int fit_grid(int64_t n) {
-    const int64_t tiles = (n + 63) / 64;
+static int fit_grid(int64_t n, int64_t nv) {
+    const int rpw = fit_rows_per_wave(n);
+    const int64_t tiles = (n + rpw - 1) / rpw + (nv > 0 ? (nv + rpw - 1) / rpw : 0);
     return (int)(tiles < 256 ? tiles : 256);
 }
 
@@ -445,7 +490,7 @@ extern "C" int nfmc_flow_fit_supported_f32(const NfmcRealNVP* flow) { return fit
 
 extern "C" int64_t nfmc_flow_fit_partial_floats(int64_t n, int64_t n_params) {
     if (n <= 0 || n_params <= 0) return 0;
-    return (int64_t)fit_grid(n) * (n_params + kFitTail);
+    return (int64_t)256 * (n_params + kFitTail);   // one slab per workgroup; never more than 256 workgroups
 }
 
 static int fit_step(const NfmcFlowFit* fit, const NfmcPotential* pot, const float* x, int64_t n, const NfmcAdamW* opt,
@@ -461,24 +506,30 @@ static int fit_step(const NfmcFlowFit* fit, const NfmcPotential* pot, const floa
     if (f.weights != fit->params || f.ea0_log_scale != fit->params + fit->ea_off || f.ea0_shift != fit->params + fit->ea_off + d4 ||
         f.ea1_log_scale != fit->params + fit->ea_off + 2 * d4 || f.ea1_shift != fit->params + fit->ea_off + 3 * d4)
         return NFMC_EINVAL;
-    const int grid = fit_grid(n);
+    const bool has_val = !pot && fit->x_val && fit->n_val > 0;
+    const int64_t nv = has_val ? fit->n_val : 0;
+    const int grid = fit_grid(n, nv);
     const int64_t pstride = fit->n_params + kFitTail;
     if (fit->partial_floats < (int64_t)grid * pstride) return NFMC_ESCRATCH;
     if (opt->step < 1) return NFMC_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const int hp = nfmc_realnvp_padded_hidden(f.n_hidden);
-    const size_t lds = fit_lds_bytes(f.d, hp);
-    const int64_t tiles = (n + 63) / 64;
+    const int rpw = fit_rows_per_wave(n);
+    const size_t lds = fit_lds_bytes(f.d, hp, rpw);
+    const int64_t tiles = (n + rpw - 1) / rpw, vtiles = nv > 0 ? (nv + rpw - 1) / rpw : 0;
     NfmcPotential p0 = {};
     if (pot) p0 = *pot;
-#define NFMC_FIT_LAUNCH2(HPV, RKLV)                                                                                       \
+#define NFMC_FIT_LAUNCH3(HPV, RKLV, RPWV)                                                                                 \
     {                                                                                                                     \
-        auto kern = fit_grad_kernel<HPV, RKLV>;                                                                           \
+        auto kern = fit_grad_kernel<HPV, RKLV, RPWV>;                                                                     \
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
         if (e != hipSuccess) return (int)e;                                                                               \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kFitBlock), lds, st, f, p0, x, n, fit->partial, pstride, fit->ea_off,   \
-                           d4, fit->n_params, tiles);                                                                     \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kFitBlock), lds, st, f, p0, x, n, fit->x_val, nv, fit->partial, pstride, \
+                           fit->ea_off, d4, fit->n_params, tiles, vtiles);                                                \
     }
+#define NFMC_FIT_LAUNCH2(HPV, RKLV)              \
+    if (rpw == 16) NFMC_FIT_LAUNCH3(HPV, RKLV, 16) \
+    else NFMC_FIT_LAUNCH3(HPV, RKLV, 64)
 #define NFMC_FIT_LAUNCH(HPV)            \
     if (pot) NFMC_FIT_LAUNCH2(HPV, true) \
     else NFMC_FIT_LAUNCH2(HPV, false)
@@ -491,9 +542,10 @@ static int fit_step(const NfmcFlowFit* fit, const NfmcPotential* pot, const floa
     }
 #undef NFMC_FIT_LAUNCH
 #undef NFMC_FIT_LAUNCH2
+#undef NFMC_FIT_LAUNCH3
     const int ablocks = (int)((fit->n_params + 255) / 256);
     hipLaunchKernelGGL(adamw_fold_kernel, dim3(ablocks < 1024 ? ablocks : 1024), dim3(256), 0, st, fit->params, fit->adam_m,
-                       fit->adam_v, fit->partial, pstride, grid, fit->n_params, *opt, fit->status);
+                       fit->adam_v, fit->params_prev, fit->partial, pstride, grid, fit->n_params, *opt, fit->status);
     NFMC_HIP_CHECK_LAUNCH();
     return NFMC_OK;
 }

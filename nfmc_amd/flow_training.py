@@ -169,45 +169,95 @@ class DeviceFit:
         import ctypes as C
         from . import hip
         self.C, self.hip, self.bij, self.dev = C, hip, bijection, device
-        st, keep = bijection.packed(device, min_hidden=0)
-        blob = keep[0]
+        lib = hip.lib()
         self.d = d = bijection.d
+        self.H, self.nhl = bijection.n_hidden, bijection.n_hidden_layers
+        self.hp = int(lib.nfmc_realnvp_padded_hidden(self.H))
+        self.layer_stride = int(lib.nfmc_coupling_layer_floats(d, self.H, self.nhl, 0))
         self.d4 = (d + 3) // 4 * 4
-        self.ea_off = int(keep[1].storage_offset() - blob.storage_offset())
-        self.params = blob.clone()
-        self.n_params = int(self.params.numel())
+        self.ea_off = (max(1, bijection.n_coupling * self.layer_stride) + 3) // 4 * 4
+        self.n_params = self.ea_off + 4 * self.d4
+        # the trainable vector, gathered from the nn.Parameters ON THE DEVICE (RealNVP.packed goes through the host: a
+        # device-to-host copy per parameter tensor, ~0.6 ms of synchronisation per refit at the C5 shape)
+        self.params = torch.zeros(self.n_params, dtype=torch.float32, device=device)
+        self._scatter(self.params, to_vector=True)
         self.m = torch.zeros_like(self.params)
         self.v = torch.zeros_like(self.params)
-        nfl = int(hip.lib().nfmc_flow_fit_partial_floats(int(n_rows), self.n_params))
+        nfl = int(lib.nfmc_flow_fit_partial_floats(int(n_rows), self.n_params))
         self.partial = torch.zeros(nfl, dtype=torch.float32, device=device)
-        self.status = torch.zeros(2, dtype=torch.float32, device=device)
-        self.layer_stride = int(st.layer_stride)
-        self.flow_struct = self._struct(st, self.params)
+        self.status = torch.zeros(3, dtype=torch.float32, device=device)
+        self.prev = torch.zeros_like(self.params)     # the parameters before the latest step (what its validation loss is of)
+        self.flow_struct = self._struct(self.params)
         self.fit = hip.NfmcFlowFit(self.flow_struct, hip.ptr(self.params), hip.ptr(self.m), hip.ptr(self.v), self.n_params,
-                                   self.ea_off, hip.ptr(self.partial), nfl, hip.ptr(self.status))
+                                   self.ea_off, hip.ptr(self.partial), nfl, hip.ptr(self.status), None, 0, hip.ptr(self.prev))
         self.opt = hip.NfmcAdamW(float(lr), 0.9, 0.999, 1e-8, 0.01, 0)   # torch.optim.AdamW defaults
         self.n_rows = int(n_rows)
 
-    def _struct(self, st, vec):
-        hip, o, d4 = self.hip, self.ea_off, self.d4
+    def _struct(self, vec):
+        hip, o, d4, bij = self.hip, self.ea_off, self.d4, self.bij
         view = lambda k: hip.ptr(vec[o + k * d4:o + k * d4 + self.d])
-        return hip.NfmcRealNVP(st.d, st.n_coupling, st.n_hidden, st.n_hidden_layers, st.min_scale, st.n_bins, view(0), view(1),
-                               view(2), view(3), hip.ptr(vec), st.layer_stride, st.spline_bound, 0)
+        return hip.NfmcRealNVP(self.d, bij.n_coupling, self.H, self.nhl, float(bij.min_scale), 0, view(0), view(1), view(2),
+                               view(3), hip.ptr(vec), self.layer_stride, float(bij.spline_bound), 0)
+
+    def _scatter(self, vec, to_vector, bijection=None):
+        """nn.Parameters <-> trainable vector, by device-side slice copies in the VALU blob layout (include/nfmc_hip.h:
+        W1T (d_a, HP) | b1 | [WhT (HP, HP) | bh] | W3 (2 d_b, HP) | b3 per coupling layer, then the four ElementwiseAffine
+        vectors at ea_off)."""
+        bij = self.bij if bijection is None else bijection
+        H, hp, d = self.H, self.hp, self.d
+        d_a, d_b = d // 2, d - d // 2
+
+        def move(param, view):
+            if to_vector:
+                view.copy_(param.detach().to(view))
+            else:
+                param.copy_(view)
+
+        with torch.no_grad():
+            for li, cpl in enumerate(bij.couplings):
+                lin = list(cpl.conditioner)
+                cur = li * self.layer_stride
+                move(lin[0].weight.t(), vec[cur:cur + d_a * hp].view(d_a, hp)[:, :H])
+                cur += d_a * hp
+                move(lin[0].bias, vec[cur:cur + H])
+                cur += hp
+                for l in lin[1:-1]:
+                    move(l.weight.t(), vec[cur:cur + hp * hp].view(hp, hp)[:H, :H])
+                    cur += hp * hp
+                    move(l.bias, vec[cur:cur + H])
+                    cur += hp
+                move(lin[-1].weight, vec[cur:cur + 2 * d_b * hp].view(2 * d_b, hp)[:, :H])
+                cur += 2 * d_b * hp
+                move(lin[-1].bias, vec[cur:cur + 2 * d_b])
+            ea0, ea1 = bij.layers[0], bij.layers[-1]
+            for k, t in enumerate((ea0.log_scale, ea0.shift, ea1.log_scale, ea1.shift)):
+                move(t, vec[self.ea_off + k * self.d4:self.ea_off + k * self.d4 + d])
 
     @staticmethod
     def supported(bijection, device) -> bool:
         from . import hip
         from .flows import RealNVP
+        import ctypes as C
         if not isinstance(bijection, RealNVP) or bijection.n_bins != 0 or device.type != 'cuda':
             return False
-        if bijection.n_hidden > 32 or bijection.n_hidden_layers > 2 or bijection.d > 256 or bijection.n_coupling < 1:
+        if bijection.n_coupling < 1 or any(p.device != device for p in bijection.parameters()):
             return False
-        st, _keep = bijection.packed(device, min_hidden=0)
-        import ctypes as C
+        st = hip.NfmcRealNVP(bijection.d, bijection.n_coupling, bijection.n_hidden, bijection.n_hidden_layers,
+                             float(bijection.min_scale), 0, None, None, None, None, None, 0, 0.0, 0)   # dimensions only
         return bool(hip.lib().nfmc_flow_fit_supported_f32(C.byref(st)))
 
-    def step(self, x, applied_steps):
-        """One AdamW step on the mean NLL of the rows x (n_rows, d) float32 on the device."""
+    def set_validation(self, xv):
+        """Validation rows (n_val, d) float32 on the device: every maximum-likelihood step then also reports their mean NLL
+        at the parameters it started from (status[2]), from the same launch."""
+        self._xv = xv
+        self.fit.x_val = self.hip.ptr(xv)
+        self.fit.n_val = int(xv.shape[0])
+
+    def step(self, x, applied_steps, lr=None):
+        """One AdamW step on the mean NLL of the rows x (n_rows, d) float32 on the device (lr = 0: evaluate only)."""
+        if lr is not None:
+            self.opt.lr = float(lr)
+            self.opt.weight_decay = 0.01 if lr > 0 else 0.0
         self.opt.step = int(applied_steps) + 1
         self.hip.check(self.hip.lib().nfmc_flow_fit_step_f32(self.C.byref(self.fit), self.hip.ptr(x), int(x.shape[0]),
                                                              self.C.byref(self.opt), self.hip.stream()), 'nfmc_flow_fit_step_f32')
@@ -228,65 +278,74 @@ class DeviceFit:
                                                                self.hip.ptr(lp), self.hip.stream()), 'nfmc_realnvp_forward_f32')
         return -lp.mean()
 
-    def write_back(self, vec=None):
-        """The trainable vector (or a saved copy of it) into the flow's nn.Parameters (inverse of RealNVP.packed)."""
+    def write_back(self, vec=None, bijection=None):
+        """The trainable vector (or a saved copy of it) into the flow's nn.Parameters, and -- when it goes into the fitter's
+        own flow -- straight into that flow's pack cache: the sampling kernels' next launch takes the trained vector as its
+        weight blob without a trip through the host (RealNVP.packed would rebuild it from the parameters)."""
         vec = self.params if vec is None else vec
-        bij = self.bij
-        H, nhl, d = bij.n_hidden, bij.n_hidden_layers, bij.d
-        hp = int(self.hip.lib().nfmc_realnvp_padded_hidden(H))
-        d_a, d_b = d // 2, d - d // 2
-        with torch.no_grad():
-            for li, cpl in enumerate(bij.couplings):
-                lin = list(cpl.conditioner)
-                cur = li * self.layer_stride
-                lin[0].weight.copy_(vec[cur:cur + d_a * hp].reshape(d_a, hp)[:, :H].t())
-                cur += d_a * hp
-                lin[0].bias.copy_(vec[cur:cur + H])
-                cur += hp
-                for l in lin[1:-1]:
-                    l.weight.copy_(vec[cur:cur + hp * hp].reshape(hp, hp)[:H, :H].t())
-                    cur += hp * hp
-                    l.bias.copy_(vec[cur:cur + H])
-                    cur += hp
-                lin[-1].weight.copy_(vec[cur:cur + 2 * d_b * hp].reshape(2 * d_b, hp)[:, :H])
-                cur += 2 * d_b * hp
-                lin[-1].bias.copy_(vec[cur:cur + 2 * d_b])
-            ea0, ea1 = bij.layers[0], bij.layers[-1]
-            for k, t in enumerate((ea0.log_scale, ea0.shift, ea1.log_scale, ea1.shift)):
-                t.copy_(vec[self.ea_off + k * self.d4:self.ea_off + k * self.d4 + d])
+        self._scatter(vec, to_vector=False, bijection=bijection)
+        if bijection is None and vec.dtype == torch.float32:
+            bij, o, d4 = self.bij, self.ea_off, self.d4
+            keep = [vec] + [vec[o + k * d4:o + k * d4 + self.d] for k in range(4)]
+            cache = bij._pack_cache if isinstance(bij._pack_cache, dict) else {}
+            cache[0] = (bij._version_key(self.dev) + (0,), (self._struct(vec), keep))
+            bij._pack_cache = cache
 
 
 def _fit_device(flow, xt, xv, n_epochs, lr, early_stopping, early_stopping_threshold, keep_best_weights, time_limit_seconds):
-    """`_loop` for the full-batch maximum-likelihood fit with the step on the device (same order of events: loss at the
-    current weights, step unless it is not finite, validation at the new weights, best-so-far bookkeeping).  The host reads
-    ONE 12-byte tensor per epoch (batch loss, step applied, validation loss)."""
+    """`_loop` for the full-batch maximum-likelihood fit with the step on the device.  Same order of events per epoch e --
+    loss at the weights w_e, step unless it is not finite, validation at the new weights w_{e+1}, best-so-far bookkeeping --
+    with ONE ABI call (two launches) and ONE 12-byte read per epoch: call c reports the batch loss AND the validation loss
+    at w_c (the validation rows ride in the gradient launch), so the bookkeeping of epoch c - 1 happens at call c, on the
+    copy of w_c that the update kernel leaves in `prev`; one extra evaluate-only call closes the last epoch."""
     fitter = DeviceFit(flow.bijection, xt.device, xt.shape[0], lr)
+    if xv is not None:
+        fitter.set_validation(xv)
     best_loss, best_vec, since_best, applied = math.inf, (fitter.params.clone() if keep_best_weights else None), 0, 0
+    last_vec = None    # without best-weights bookkeeping: the weights after the last epoch that counted
     t0 = time.time()
+    n_epochs = int(n_epochs)
+
+    def book(v, vec):
+        """best-so-far bookkeeping for one finished epoch: validation value v, weights `vec` after its step"""
+        nonlocal best_loss, since_best
+        if not math.isfinite(v):
+            raise ValueError('flow training diverged (non-finite validation loss)')
+        if v < best_loss:
+            best_loss, since_best = v, 0
+            if keep_best_weights:
+                best_vec.copy_(vec)
+            return False
+        since_best += 1
+        return early_stopping and since_best > early_stopping_threshold
+
     try:
-        for _epoch in range(int(n_epochs)):
-            if time_limit_seconds is not None and time.time() - t0 >= time_limit_seconds:
+        stop = False
+        for c in range(n_epochs + (1 if xv is not None else 0)):
+            closing = c == n_epochs                      # evaluate-only call: the validation loss of the last epoch
+            if not closing and time_limit_seconds is not None and time.time() - t0 >= time_limit_seconds:
+                n_epochs = c
+                closing = xv is not None and c > 0
+                if not closing:
+                    break
+            fitter.step(xt, applied, lr=0.0 if closing else lr)
+            loss, ok, val = (float(t) for t in fitter.status.cpu())
+            if xv is not None and c > 0:                 # epoch c - 1 ended at the weights this call started from
+                last_vec = fitter.prev
+                stop = book(val, fitter.prev)
+            if closing or stop:
                 break
-            fitter.step(xt, applied)
-            val = fitter.nll(xv).reshape(1) if xv is not None else fitter.status[:1]
-            loss, ok, v = (float(t) for t in torch.cat([fitter.status, val]).cpu())
             if not math.isfinite(loss) or ok == 0.0:
                 raise ValueError('flow training diverged (non-finite loss)')
             applied += 1
-            if not math.isfinite(v):
-                raise ValueError('flow training diverged (non-finite validation loss)')
-            if v < best_loss:
-                best_loss, since_best = v, 0
-                if keep_best_weights:
-                    best_vec.copy_(fitter.params)
-            else:
-                since_best += 1
-                if early_stopping and since_best > early_stopping_threshold:
+            if xv is None:                               # no validation set: the batch loss before the step stands in
+                last_vec = fitter.params
+                if book(loss, fitter.params):
                     break
     finally:
         # whatever happened, the nn.Parameters end up as the best weights seen (or the last ones): callers that catch the
         # ValueError restore their own saved state_dict on top (jump.py:150-151)
-        fitter.write_back(best_vec if keep_best_weights else None)
+        fitter.write_back(best_vec if keep_best_weights else (last_vec.clone() if last_vec is not None else None))
     return best_loss
 
 
@@ -341,7 +400,7 @@ def _variational_fit_device(flow, potential, dev, n_epochs, lr, n_samples, early
                 break
             z = torch.randn(n_samples, d, device=dev)
             fitter.step_variational(z, pot, applied)
-            loss, ok = (float(t) for t in fitter.status.cpu())
+            loss, ok, _val = (float(t) for t in fitter.status.cpu())
             if not math.isfinite(loss) or ok == 0.0:
                 if check_for_divergences:
                     raise ValueError('flow training diverged (non-finite loss)')

@@ -109,7 +109,8 @@ class NfmcAdamW(C.Structure):
 
 class NfmcFlowFit(C.Structure):
     _fields_ = [('flow', NfmcRealNVP), ('params', c_fp), ('adam_m', c_fp), ('adam_v', c_fp), ('n_params', C.c_int64),
-                ('ea_off', C.c_int64), ('partial', c_fp), ('partial_floats', C.c_int64), ('status', c_fp)]
+                ('ea_off', C.c_int64), ('partial', c_fp), ('partial_floats', C.c_int64), ('status', c_fp),
+                ('x_val', c_fp), ('n_val', C.c_int64), ('params_prev', c_fp)]
 
 
 class NfmcLimits(C.Structure):

@@ -77,6 +77,10 @@ def train_val_split(x: torch.Tensor, train_pct: float, max_train_size: int, max_
             perm = torch.randperm(rows.shape[0], generator=torch.Generator().manual_seed(seed))
             rows = rows[perm.to(rows.device)]
     elif shuffle:
-        rows = _shuffled(rows)
+        # the rows of the shuffled buffer that survive the cut and the caps, without materialising the shuffled buffer (at
+        # the C5 shape it is 160 MiB per refit for 8192 kept rows): same permutation, same rows, same order
+        perm = torch.randperm(rows.shape[0], device=rows.device)
+        cut = int(train_pct * rows.shape[0])
+        return rows[perm[:cut][:max_train_size]], rows[perm[cut:][:max_val_size]]
     cut = int(train_pct * rows.shape[0])
     return rows[:cut][:max_train_size], rows[cut:][:max_val_size]
