@@ -403,16 +403,17 @@ def algorithmic_flops(cfg):
     """ALGORITHMIC flops per chain-transition of the dominant kernel's work ('ALGORITHMIC flops per
     chain-step'), per config.  d = event size.
       jump_mala  Gaussian MALA step: 30*d (SURVEY's figure: proposal, two potentials + gradients, two proposal densities).
-      jump_hmc   one HMC trajectory on U = sum x^2 (hmc.py:61-77,96-126): per leapfrog two gradient evaluations (d
-                 multiplies each) + three axpys (2d each) = 8d; two Hamiltonians (U: 2d, kinetic: 3d each) = 10d; the
-                 momentum draw's scaling d  ->  (8 L + 11) * d, L = 20.
+      jump_hmc   one HMC trajectory on U = sum x^2 (hmc.py:61-77,96-126) in its minimal form -- the leapfrog with ONE
+                 gradient evaluation per position (the reference evaluates the same gradient twice between two position
+                 updates): L + 1 gradients (d multiplies each), 2 L + 1 axpys (2d each) = (5 L + 3) d; two Hamiltonians
+                 (U: 2d, kinetic: 3d each) = 10d; the momentum draw's scaling d  ->  (5 L + 14) * d, L = 20.
       imh        one independence-MH transition: a RealNVP inverse pass, L_c * 2 * (d_a H + (n_hl - 1) H^2 + 2 H d_b) + 10 d
                  (SURVEY's 'RealNVP pass', default flow at d = 64: L_c = 2, H = 4, n_hl = 2), + U(x') 2d + base density 2d."""
     d, st = cfg['d'], cfg['strategy']
     if st == 'jump_mala':
         return 30.0 * d
     if st == 'jump_hmc':
-        return (8.0 * 20 + 11.0) * d
+        return (5.0 * 20 + 14.0) * d
     if st == 'imh':
         da, db, H, nhl, lc = d // 2, d - d // 2, 4, 2, 2
         return lc * 2.0 * (da * H + (nhl - 1) * H * H + 2 * H * db) + 10.0 * d + 4.0 * d
