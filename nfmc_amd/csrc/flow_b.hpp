@@ -43,9 +43,14 @@ namespace nfmc {
 // half, so W1 keeps only the source slots' rows and W3 only the target slots' rows (DP/2 each, indexed by
 // (i - first register of the half) * LPC + g): half the image -- 31 instead of 62 KB at d = 256, HP = 8, which
 // lifts the LDS limit from 2 to 5 workgroups per CU -- and half the staging work per workgroup.
-template <int CPL, int LPC, int HP, bool EXACT = false>
+// NB = 8: rational-quadratic spline couplings ('c-rqnsf', flow_device.hpp: rqs_coordinate).  A target slot's W3 row is then
+//   [(3 NB - 1) x HP weights, output-major, hidden units in the lane class's order | (3 NB - 1) biases | is_target]
+// = 116 floats at HP = 4, 208 at HP = 8 (the lane computes all 23 spline parameters of each of its target coordinates).
+template <int CPL, int LPC, int HP, bool EXACT = false, int NB = 0>
 struct FlowImage {
-    static constexpr int RS = 2 * HP + 4;
+    static constexpr int NP = 3 * NB - 1;                    // spline parameters per target coordinate
+    static constexpr int RS = NB ? NP * (HP + 1) + 1 : 2 * HP + 4;
+    static_assert(RS % 4 == 0, "whole 16-byte groups per row");
     static constexpr int DP = CPL * LPC;
     static constexpr int ROWS = EXACT ? DP / 2 : DP;         // rows of W1 / of W3 per layer
     static constexpr bool DIST = LPC >= HP;                  // one lane class per hidden unit
@@ -62,6 +67,43 @@ struct FlowImage {
         float r1[HP], r3[RS];
         bool src, tgt;
     };
+    // spline target rows are long (116 / 208 floats): copied piecewise, straight from the blob, by stage()
+    __device__ static __forceinline__ void stage_slot_rqs(float* __restrict__ img, const NfmcRealNVP& f, int l, int s, int bmid,
+                                                          int lf, int nmid) {
+        const int d = f.d, d_a = d / 2, d_b = d - d_a;
+        const bool rev = (l & 1) == 0;
+        const float* __restrict__ B = f.weights;
+        const int W = l * (int)f.layer_stride;
+        const int W3 = W + d_a * HP + bmid;
+        const int b3 = W3 + NP * d_b * HP;
+        const int c = coord_of<CPL, LPC>(s % LPC, s / LPC);
+        const int j = rev ? d - 1 - c : c;
+        const bool src = c < d && j < d_a, tgt = c < d && j >= d_a;
+        float* w = img + l * lf;
+        float* w3 = w + ROWS * HP + nmid;
+        const int sh = EXACT ? (s >= DP / 2 ? s - DP / 2 : s) : s;
+        if (!EXACT || src) {
+            const int w1 = W + (src ? j : 0) * HP;
+#pragma unroll
+            for (int k = 0; k < HP; ++k) w[sh * HP + k] = src ? B[w1 + k] : 0.f;
+        }
+        if (!EXACT || tgt) {
+            const int tt = tgt ? j - d_a : 0;
+            const int ub = (s % LPC) % HP;
+            float* row = w3 + sh * RS;
+            for (int q = 0; q < NP; ++q) {
+#pragma unroll
+                for (int k = 0; k < HP; ++k) {
+                    const int kk = DIST ? (ub ^ unit_xor<HP>(k)) : k;
+                    const float v = B[W3 + (tt * NP + q) * HP + kk];
+                    row[q * HP + k] = tgt ? v : 0.f;
+                }
+                const float bq = B[b3 + tt * NP + q];
+                row[NP * HP + q] = tgt ? bq : 0.f;
+            }
+            row[NP * HP + NP] = tgt ? 1.f : 0.f;
+        }
+    }
     __device__ static __forceinline__ SlotRows load_slot(const NfmcRealNVP& f, int l, int s, int bmid) {
         // 32-bit offsets from the (wave-uniform) blob base: scalar base + one VGPR offset per load instead of a 64-bit
         // address pair per load (the hoisted loads of a thread would otherwise cost ~2 VGPRs each)
@@ -147,6 +189,22 @@ struct FlowImage {
         const int t = threadIdx.x;
         const int nA = f.n_coupling * DP, nB = f.n_coupling * nmid;
         const bool revl = (f.n_coupling & 1) != 0;
+        if constexpr (NB > 0) {   // spline couplings: plain loops (the rows are too long to hold one per thread in registers)
+            for (int a = t; a < nA; a += nthreads) stage_slot_rqs(img, f, a / DP, a % DP, bmid, lf, nmid);
+            for (int b = t; b < nB; b += nthreads) {
+                const int q = mid_src(d_a, b % nmid);
+                img[(b / nmid) * lf + ROWS * HP + b % nmid] = q < 0 ? 0.f : f.weights[(b / nmid) * (int)f.layer_stride + q];
+            }
+            float* ea = img + f.n_coupling * lf;
+            for (int s = t; s < DP; s += nthreads) {
+                const int p = coord_of<CPL, LPC>(s % LPC, s / LPC);
+                const bool ok = p < d;
+                const int c = revl ? d - 1 - p : p;
+                store_ea(ea, s, ok ? f.ea0_log_scale[p] : 0.f, ok ? f.ea0_shift[p] : 0.f, ok ? f.ea1_log_scale[c] : 0.f,
+                         ok ? f.ea1_shift[c] : 0.f);
+            }
+            return;
+        }
         // ---- loads
         const int a0 = t < nA ? t : 0;
         const SlotRows ra = load_slot(f, a0 / DP, a0 % DP, bmid);
@@ -213,15 +271,15 @@ __device__ __forceinline__ void load_row16(float (&w)[N], const float* __restric
 typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 pk_fma(f2 a, float b, f2 c) { return __builtin_elementwise_fma(a, (f2){b, b}, c); }
 
-template <int CPL, int LPC, int HP, bool LEAN = false, bool EXACT = false>
+template <int CPL, int LPC, int HP, bool LEAN = false, bool EXACT = false, int NB = 0>
 struct FlowB {
-    using Img = FlowImage<CPL, LPC, HP, EXACT>;
+    using Img = FlowImage<CPL, LPC, HP, EXACT, NB>;
     static constexpr int DP = CPL * LPC;
     static constexpr bool kExact = EXACT;
     static_assert(!EXACT || CPL >= 8, "EXACT needs whole register quads per half");
     const float* img;  // LDS
     int n_hl, n_coupling, lf, g;
-    float m, log1m, ea_ls;
+    float m, log1m, ea_ls, bound;
 
     __device__ __forceinline__ void init(const float* lds_img, const NfmcRealNVP& f, int g_) {
         img = lds_img;
@@ -230,6 +288,7 @@ struct FlowB {
         lf = Img::layer_floats(n_hl);
         m = f.min_scale;
         log1m = __logf(1.f - f.min_scale);
+        bound = f.spline_bound;
         g = g_;
         // this lane's share of the (state-independent) log-determinant of the two ElementwiseAffine layers
         const float* ea = img + n_coupling * lf + g;
@@ -314,6 +373,36 @@ struct FlowB {
         }
         const float* W3 = img + l * lf + Img::ROWS * HP + Img::mid_floats(n_hl) + g * Img::RS;
         float ld = 0.f;
+        if constexpr (NB > 0) {
+            // spline coupling: this lane evaluates the 3 NB - 1 conditioner outputs of each of its target coordinates
+            // (weights in 16-byte LDS reads, one output at a time) and the monotone spline itself (rqs_coordinate)
+            constexpr int NP = Img::NP;
+            for (int i = T0; i < T1; ++i) {   // not unrolled: one coordinate's 23 outputs + the spline are ~350 instructions
+                const float* row = W3 + (i - T0) * LPC * Img::RS;
+                float raw[NP];
+                {
+                    float bb[NP + 1];
+                    load_row16<NP + 1>(bb, row + NP * HP);
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) raw[q] = bb[q];
+                    if (!EXACT && bb[NP] == 0.f) continue;   // not a target of this layer (generic path): bitwise unchanged
+                }
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    float w[HP];
+                    load_row16<HP>(w, row + q * HP);
+#pragma unroll
+                    for (int k = 0; k < HP; ++k) raw[q] = fmaf(w[k], h[k], raw[q]);
+                }
+                float xi = x[0];
+#pragma unroll
+                for (int r = 1; r < CPL; ++r) xi = (r == i) ? x[r] : xi;   // register i without a dynamically indexed array
+                const float yi = rqs_coordinate<INVERSE>(xi, raw, bound, ld);
+#pragma unroll
+                for (int r = 0; r < CPL; ++r) x[r] = (r == i) ? yi : x[r];
+            }
+            return INVERSE ? -ld : ld;
+        }
 #pragma unroll
         for (int i = T0; i < T1; ++i) {
             float w[Img::RS];

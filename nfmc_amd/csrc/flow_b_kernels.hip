@@ -9,7 +9,9 @@ namespace nfmc {
 // DIAG = false is the production instantiation: no replayed noise, no sample store, no mask / log-ratio outputs --
 // the branches on those pointers (and the scalar registers that carry them through the tile loop: the DIAG kernel
 // spills SGPRs into VGPR lanes there) are compiled out.  The host picks it when all of those arguments are NULL.
-template <int CPL, int LPC, int HP, template <int, int, bool> class Pot, bool FAST, bool DIAG, int RR = 10>
+// NB = 8: rational-quadratic spline couplings ('c-rqnsf') on the same skeleton (round 3; before, spline flows ran the jump on
+// the one-chain-per-lane kernel of flow_kernels.hip only).
+template <int CPL, int LPC, int HP, template <int, int, bool> class Pot, bool FAST, bool DIAG, int RR = 10, int NB = 0>
 #ifndef NFMC_FLOWB_WPE
 #define NFMC_FLOWB_WPE 1
 #endif
@@ -20,7 +22,7 @@ __global__ void __launch_bounds__(kBlock, NFMC_FLOWB_WPE) flow_mh_b_kernel(NfmcF
     const int g = lane % LPC, cw = lane / LPC;
     const int d = a.flow.d;
     const int64_t n = a.n;
-    using Flow = FlowB<CPL, LPC, HP, false, (FAST && CPL >= 8)>;
+    using Flow = FlowB<CPL, LPC, HP, false, (FAST && CPL >= 8), NB>;
     Flow::Img::stage(lds, a.flow, kBlock);
     __syncthreads();
     Flow fl;
@@ -285,6 +287,31 @@ static int launch_b2(const NfmcFlowMhArgs& a, int64_t tiles, int grid, hipStream
     }
 }
 
+// spline couplings: one instantiation per (layout, width, potential, exact-fit), diagnostics compiled in, default stream
+template <int CPL, int LPC, int HP>
+static int launch_b_rqs(const NfmcFlowMhArgs& a, bool fast, int64_t tiles, int grid, hipStream_t st, bool dry) {
+#define NFMC_LBR(POT, F)                                                                                          \
+    {                                                                                                             \
+        const size_t lds = (size_t)FlowImage<CPL, LPC, HP, (F && CPL >= 8), kRqsBins>::total_floats(a.flow.n_hidden_layers, \
+                                                                                                 a.flow.n_coupling) * sizeof(float); \
+        if (lds > 120 * 1024) return NFMC_EUNSUPPORTED;                                                           \
+        if (rng_rounds(a.rng) == 7) return NFMC_EUNSUPPORTED;                                                     \
+        if (dry) return 0;                                                                                        \
+        auto kern = flow_mh_b_kernel<CPL, LPC, HP, POT, F, true, 10, kRqsBins>;                                   \
+        if (lds > 48 * 1024) {                                                                                    \
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                                               (int)lds);                                                         \
+            if (e != hipSuccess) return (int)e;                                                                   \
+        }                                                                                                         \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, st, a, tiles);                                    \
+    }
+    if (a.pot.kind == NFMC_POT_FUNNEL) NFMC_LBR(FunnelPot, false)
+    else if (fast) NFMC_LBR(QuadraticPot, true)
+    else NFMC_LBR(QuadraticPot, false)
+#undef NFMC_LBR
+    return 0;
+}
+
 template <int CPL, int LPC, int HP>
 static int launch_b(const NfmcFlowMhArgs& a, bool fast, int64_t tiles, int grid, hipStream_t st, bool dry) {
 #define NFMC_LB(POT, F)                                                                                         \
@@ -341,9 +368,12 @@ int flow_mh_b_launch(const NfmcFlowMhArgs& a, hipStream_t st, int* grid_out, int
                       (((uintptr_t)a.x) & 15u) == 0 && (!a.samples.base || (((uintptr_t)a.samples.base) & 15u) == 0);
     // Two chains per lane group (flow_mh_b2_kernel): exact-fit quadratic targets without diagnostics, where the LDS
     // reads of the weight image bound the one-chain kernel (d >= 256; NFMC_FLOWB_DUAL=0/1 overrides for tuning).
+    const bool rqs = a.flow.n_bins != 0;
+    if (rqs && (a.flow.n_bins != kRqsBins || !(a.flow.spline_bound > 0.f))) return NFMC_EUNSUPPORTED;
     bool dual = fast && c.cpl >= 8 && c.lpc >= 8 && a.pot.kind != NFMC_POT_FUNNEL && !wants_diag(a) && dp >= 256;
     if (const char* e = getenv("NFMC_FLOWB_DUAL"))
         dual = atoi(e) != 0 && fast && c.cpl >= 8 && c.lpc >= 8 && a.pot.kind != NFMC_POT_FUNNEL && !wants_diag(a);
+    dual = dual && !rqs;
     const int cpw = (kWave / c.lpc) * (dual ? 2 : 1);
     const int64_t tiles = (a.n + (int64_t)kWavesPerBlock * cpw - 1) / ((int64_t)kWavesPerBlock * cpw);
     // Persistent workgroups: the weight image is staged once per workgroup and every wave pays a fixed prologue /
@@ -359,7 +389,8 @@ int flow_mh_b_launch(const NfmcFlowMhArgs& a, hipStream_t st, int* grid_out, int
     int rc = NFMC_EUNSUPPORTED;
 #define M(CPL, LPC)                                                                      \
     if (c.cpl == CPL && c.lpc == LPC)                                                    \
-        rc = dual ? (hp == 4 ? launch_b2<CPL, LPC, 4>(a, tiles, grid, st, dry) : launch_b2<CPL, LPC, 8>(a, tiles, grid, st, dry)) \
+        rc = rqs ? (hp == 4 ? launch_b_rqs<CPL, LPC, 4>(a, fast, tiles, grid, st, dry) : launch_b_rqs<CPL, LPC, 8>(a, fast, tiles, grid, st, dry)) \
+           : dual ? (hp == 4 ? launch_b2<CPL, LPC, 4>(a, tiles, grid, st, dry) : launch_b2<CPL, LPC, 8>(a, tiles, grid, st, dry)) \
                   : (hp == 4 ? launch_b<CPL, LPC, 4>(a, fast, tiles, grid, st, dry) : launch_b<CPL, LPC, 8>(a, fast, tiles, grid, st, dry));
     NFMC_FOR_BCFG(M)
 #undef M

@@ -376,7 +376,7 @@ extern "C" int nfmc_flow_mh_supported_f32(const NfmcFlowMhArgs* args) {
     int rc = check_flow_mh(a);
     if (rc) return rc;
     int grid = 0, dp = 0;
-    rc = (getenv("NFMC_FLOW_TILE_PATH") || a.flow.n_bins != 0) ? NFMC_EUNSUPPORTED : flow_mh_b_launch(a, nullptr, &grid, &dp, true);
+    rc = getenv("NFMC_FLOW_TILE_PATH") ? NFMC_EUNSUPPORTED : flow_mh_b_launch(a, nullptr, &grid, &dp, true);
     if (rc != NFMC_EUNSUPPORTED) return rc;
     if (rng_rounds(a.rng) != 10) return NFMC_EUNSUPPORTED;   // the opt-in stream exists in the register kernels only
     if (use_mfma_flow(&a.flow) && al16(a.x) && al16(a.samples.base)) return NFMC_OK;
@@ -392,7 +392,7 @@ extern "C" int nfmc_flow_mh_steps_f32(const NfmcFlowMhArgs* args, nfmc_stream_t 
     int dp = padded_d(d);
     hipStream_t st = (hipStream_t)stream;
     int grid = 0;
-    rc = (getenv("NFMC_FLOW_TILE_PATH") || a.flow.n_bins != 0) ? NFMC_EUNSUPPORTED : flow_mh_b_launch(a, st, &grid, &dp, false);
+    rc = getenv("NFMC_FLOW_TILE_PATH") ? NFMC_EUNSUPPORTED : flow_mh_b_launch(a, st, &grid, &dp, false);
     if (rc == NFMC_EUNSUPPORTED && rng_rounds(a.rng) != 10) return NFMC_EUNSUPPORTED;
     if (rc == NFMC_EUNSUPPORTED && use_mfma_flow(&a.flow) && al16(a.x) && al16(a.samples.base)) {
         // wide conditioners at d = 64 / 128 (16-byte aligned rows): matrix cores

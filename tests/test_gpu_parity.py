@@ -1633,6 +1633,58 @@ def test_register_flow_metropolis_matches_oracle_in_every_layout(dev, d, nh, cl,
     assert want_m.any() or d >= 100   # small flows are close enough to the target for acceptances to happen
 
 
+@pytest.mark.parametrize('d,nh,cl,nl', [(4, 3, 1, 2), (16, 4, 2, 2), (24, 3, 1, 2), (64, 4, 2, 2), (64, 8, 2, 3), (100, 8, 2, 2),
+                                        (128, 4, 2, 2)])
+def test_spline_flow_metropolis_on_the_register_layout_matches_oracle(dev, d, nh, cl, nl, monkeypatch):
+    """f4 (util.py:288-289, 'c-rqnsf'): the flow-proposal Metropolis step with rational-quadratic spline couplings on the
+    register-layout kernel (flow_mh_b_kernel<..., NB = 8>: LPC lanes per chain, each lane evaluates the 23 spline parameters
+    of its own target coordinates) against the oracle on the same Philox streams, exact-fit and ragged layouts, and against
+    the one-chain-per-lane kernel it replaces for these widths (NFMC_FLOW_TILE_PATH=1): same log-ratios to rounding."""
+    from nfmc_amd.samplers import imh, jump
+    from nfmc_amd.samplers.common import Run
+    from nfmc_amd.flows import Flow, CRQNSF
+    from nfmc_amd.potentials import SumOfSquares
+    from oracle import samplers as osamp, potentials as opot, flow as oflow
+    n, T = 70, 5
+    torch.manual_seed(d + nh)
+    ck = {'n_hidden': nh, 'n_layers': cl}
+    of = oflow.perturb_(oflow.Flow(oflow.CRQNSF((d,), n_layers=nl, conditioner_kwargs=ck)), 3, 0.3, 0.75)
+    f = Flow(CRQNSF((d,), n_layers=nl, conditioner_kwargs=ck))
+    f.load_state_dict(of.state_dict())
+    x0 = 0.7 * torch.randn(n, d)
+    pot = SumOfSquares((d,))
+    tr = osamp.imh_sample(x0, opot.sum_squares, of, T, noise=osamp.PhiloxNoise(4242))
+    want_lr = torch.stack(tr.log_ratios).numpy()
+    want_m = torch.stack(tr.masks).numpy()
+    got = {}
+    for tile_path in ('', '1'):
+        if tile_path:
+            monkeypatch.setenv('NFMC_FLOW_TILE_PATH', '1')
+        s = imh.FixedIMH((d,), pot, imh.IMHKernel((d,), flow=f), imh.IMHParameters(n_iterations=T))
+        s.seed = 4242
+        run = Run(s, x0)
+        logq = torch.empty(n, dtype=torch.float32, device=dev)
+        masks = torch.zeros(T, n, dtype=torch.uint8, device=dev)
+        lr = torch.zeros(T, n, dtype=torch.float32, device=dev)
+        samples = torch.zeros(T, n, d, dtype=torch.float32, device=dev)
+        assert jump.flow_mh_supported(run, f, pot, logq)
+        jump.launch_flow_mh(run, f, pot, logq, T, 0, False, True, run.stats.struct(), samples, masks, lr)
+        torch.cuda.synchronize()
+        got[tile_path] = (lr.cpu().numpy(), masks.cpu().numpy().astype(bool), samples.cpu().numpy())
+    got_lr, got_m, got_x = got['']
+    agree = np.logical_and.accumulate(np.vstack([np.ones((1, n), bool), (got_m == want_m)[:-1]]), axis=0)
+    assert agree.mean() > 0.95
+    tol = 3e-4 * max(1.0, d / 64) + 3e-5 * np.abs(want_lr)
+    assert (np.abs(got_lr - want_lr)[agree] <= tol[agree]).all(), float(np.abs(got_lr - want_lr)[agree].max())
+    follows = agree[-1] & (got_m[-1] == want_m[-1])
+    np.testing.assert_allclose(got_x[-1][follows], tr.samples[-1].numpy()[follows], atol=5e-5 * max(1.0, d / 64))
+    # the two kernel families agree wherever they made the same decisions
+    t_lr, t_m, _t_x = got['1']
+    both = np.logical_and.accumulate(np.vstack([np.ones((1, n), bool), (got_m == t_m)[:-1]]), axis=0)
+    assert both.mean() > 0.97
+    assert (np.abs(got_lr - t_lr)[both] <= 2 * tol[both]).all()
+
+
 @pytest.mark.parametrize('d,ck,kind', [(200, {}, 'realnvp'), (24, {'n_hidden': 40}, 'realnvp'), (10, {}, 'c-rqnsf')])
 def test_neutra_hmc_shapes_without_a_fused_kernel_match_oracle(dev, d, ck, kind):
     """NeuTra HMC where nfmc_neutra_hmc_steps_f32 has no kernel (d > ~156: four wave tiles exceed the LDS; conditioners
