@@ -175,7 +175,41 @@ __device__ __forceinline__ float adjusted_potential_grad_row(const float* __rest
 constexpr int kNeutraBlock = 64;
 constexpr int kNeutraSlots = 8;
 
-template <int HP>
+// Rows (chains) per wave.  The kernels keep 3 (gradient) or 4 (trajectory) tiles of RPW x d floats in LDS; at 64 rows they fit
+// the CU's 160 KB up to d ~ 156 / 208, and until round 3 wider events sent NeuTra to torch autograd on the GPU.  With 32 or 16
+// rows per wave (the other lanes idle in the per-row phases, all 64 lanes still share the column phases: tile IO, statistics)
+// every d <= 512 has a kernel.
+static int neutra_rows_per_wave(int d, int tiles_of_d) {
+    for (int rpw = 64; rpw >= 16; rpw >>= 1)
+        if ((size_t)tiles_of_d * rpw * tile_stride(d) * sizeof(float) <= 150 * 1024) return rpw;
+    return 0;
+}
+template <int RPW>
+__device__ __forceinline__ void tile_load_rows(float* __restrict__ tile, int stride, const float* __restrict__ src, int64_t r0,
+                                               int64_t n, int d, bool rev) {
+    const int lane = threadIdx.x & 63;
+    const int64_t rows = n - r0 < RPW ? n - r0 : RPW;
+    const int total = (int)rows * d;
+    const float* s = src + r0 * d;
+    for (int i = lane; i < RPW * d; i += kWave) {
+        const int r = i / d, c = i - r * d;
+        tile[r * stride + (rev ? d - 1 - c : c)] = i < total ? s[i] : 0.f;  // rows beyond n: zeros
+    }
+}
+template <int RPW>
+__device__ __forceinline__ void tile_store_rows(const float* __restrict__ tile, int stride, float* __restrict__ dst, int64_t r0,
+                                                int64_t n, int d, bool rev) {
+    const int lane = threadIdx.x & 63;
+    const int64_t rows = n - r0 < RPW ? n - r0 : RPW;
+    const int total = (int)rows * d;
+    float* o = dst + r0 * d;
+    for (int i = lane; i < total; i += kWave) {
+        const int r = i / d, c = i - r * d;
+        o[i] = tile[r * stride + (rev ? d - 1 - c : c)];
+    }
+}
+
+template <int HP, int RPW>
 __global__ void __launch_bounds__(kNeutraBlock) neutra_potential_grad_kernel(NfmcRealNVP f, NfmcPotential pot,
                                                                              const float* __restrict__ z, int64_t n,
                                                                              float* __restrict__ u_out,
@@ -186,23 +220,25 @@ __global__ void __launch_bounds__(kNeutraBlock) neutra_potential_grad_kernel(Nfm
     const int stride = tile_stride(g.d);
     const int lane = threadIdx.x;
     float* zt = lds;
-    float* wt = lds + 64 * stride;
-    float* gt = lds + 128 * stride;
+    float* wt = lds + RPW * stride;
+    float* gt = lds + 2 * RPW * stride;
     const bool rev = (g.n_coupling & 1) != 0;
     for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        const int64_t r0 = tile * 64;
+        const int64_t r0 = tile * RPW;
         __syncthreads();
-        tile_load(zt, stride, z, r0, n, g.d, rev);
+        tile_load_rows<RPW>(zt, stride, z, r0, n, g.d, rev);
         __syncthreads();
-        const float u = adjusted_potential_grad_row<HP>(zt + lane * stride, wt + lane * stride, gt + lane * stride, f,
-                                                        g, pot);
-        if (r0 + lane < n && u_out) u_out[r0 + lane] = u;
+        if (lane < RPW) {
+            const float u = adjusted_potential_grad_row<HP>(zt + lane * stride, wt + lane * stride, gt + lane * stride, f,
+                                                            g, pot);
+            if (r0 + lane < n && u_out) u_out[r0 + lane] = u;
+        }
         __syncthreads();
-        if (grad_out) tile_store(gt, stride, grad_out, r0, n, g.d, rev);
+        if (grad_out) tile_store_rows<RPW>(gt, stride, grad_out, r0, n, g.d, rev);
     }
 }
 
-template <int HP>
+template <int HP, int RPW>
 __global__ void __launch_bounds__(kNeutraBlock) neutra_hmc_kernel(NfmcNeutraHmcArgs a, int64_t tiles, int dp) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const NfmcRealNVP& f = a.flow;
@@ -211,9 +247,10 @@ __global__ void __launch_bounds__(kNeutraBlock) neutra_hmc_kernel(NfmcNeutraHmcA
     const int stride = tile_stride(d);
     const int lane = threadIdx.x;
     float* zt = lds;
-    float* pt = lds + 64 * stride;
-    float* wt = lds + 128 * stride;
-    float* gt = lds + 192 * stride;
+    float* pt = lds + RPW * stride;
+    float* wt = lds + 2 * RPW * stride;
+    float* gt = lds + 3 * RPW * stride;
+    const bool rowlane = lane < RPW;   // lanes that own a chain (all 64 lanes share the column phases)
     float* zr = zt + lane * stride;
     float* pr = pt + lane * stride;
     float* wr = wt + lane * stride;
@@ -228,18 +265,21 @@ __global__ void __launch_bounds__(kNeutraBlock) neutra_hmc_kernel(NfmcNeutraHmcA
     uint32_t n_acc = 0, n_bad = 0;
 
     for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        const int64_t r0 = tile * 64;
+        const int64_t r0 = tile * RPW;
         const int64_t row = r0 + lane;
-        const bool active = row < n;
-        const int rows = (int)(n - r0 < 64 ? n - r0 : 64);
+        const bool active = rowlane && row < n;
+        const int rows = (int)(n - r0 < RPW ? n - r0 : RPW);
         const uint32_t gchain = (uint32_t)(a.rng.chain_offset + (uint64_t)row);
         __syncthreads();
-        tile_load(zt, stride, a.z, r0, n, d, rev);
+        tile_load_rows<RPW>(zt, stride, a.z, r0, n, d, rev);
         __syncthreads();
-        float u_cur = adjusted_potential_grad_row<HP>(zr, wr, gr, f, g, a.pot);  // U~(z), grad at the current state
+        float u_cur = rowlane ? adjusted_potential_grad_row<HP>(zr, wr, gr, f, g, a.pot) : 0.f;  // U~(z), grad at the current state
         uint4 ur = make_uint4(0, 0, 0, 0);
         StoreCursor keep(a.samples);
         for (int s = 0; s < a.n_steps; ++s) {
+            bool accept = false;
+            float lr = 0.f;
+            if (rowlane) {
             // momentum p = eps / sqrt(m)  (hmc.py:100); tile columns are latent positions: logical c <-> col latent_col(c)
             float kin0 = 0.f;
             if (a.rng.replay_normals) {
@@ -282,8 +322,7 @@ __global__ void __launch_bounds__(kNeutraBlock) neutra_hmc_kernel(NfmcNeutraHmcA
                 u_new = adjusted_potential_grad_row<HP>(zr, wr, gr, f, g, a.pot);
                 for (int c = 0; c < d; ++c) pr[c] = fmaf(-hh, gr[c], pr[c]);
             }
-            bool accept = true;
-            float lr = 0.f;
+            accept = true;
             if (a.adjust) {
                 float kin1 = 0.f;
                 for (int c = 0; c < d; ++c) {
@@ -313,11 +352,12 @@ __global__ void __launch_bounds__(kNeutraBlock) neutra_hmc_kernel(NfmcNeutraHmcA
                 // restore the trajectory's start point from HBM (the tile is only written back on accept)
                 for (int c = 0; c < d; ++c) zr[latent_col(c, g)] = active ? a.z[row * d + c] : 0.f;
             }
+            }   // rowlane
             __syncthreads();
             // write accepted rows back so HBM always holds the current state (row-contiguous stores)
             if (accept)
                 for (int c = 0; c < d; ++c) a.z[row * d + c] = zr[latent_col(c, g)];
-            if (!accept && s + 1 < a.n_steps) u_cur = adjusted_potential_grad_row<HP>(zr, wr, gr, f, g, a.pot);
+            if (rowlane && !accept && s + 1 < a.n_steps) u_cur = adjusted_potential_grad_row<HP>(zr, wr, gr, f, g, a.pot);
             if (active) {
                 if (a.masks_out) a.masks_out[(int64_t)s * n + row] = accept ? 1 : 0;
                 if (a.log_ratio_out) a.log_ratio_out[(int64_t)s * n + row] = lr;
@@ -340,7 +380,7 @@ __global__ void __launch_bounds__(kNeutraBlock) neutra_hmc_kernel(NfmcNeutraHmcA
                     }
                 }
             }
-            if (float* kept = keep.next(n * (int64_t)d)) tile_store(zt, stride, kept, r0, n, d, rev);
+            if (float* kept = keep.next(n * (int64_t)d)) tile_store_rows<RPW>(zt, stride, kept, r0, n, d, rev);
             __syncthreads();
         }
     }
@@ -396,12 +436,22 @@ static int set_lds_n(K kernel, size_t bytes) {
 
 using namespace nfmc;
 
-#define NFMC_HP_DISPATCH_N(HPV, CALL)                    \
-    switch (HPV) {                                       \
-        case 4: { constexpr int HP = 4; CALL; } break;   \
-        case 8: { constexpr int HP = 8; CALL; } break;   \
-        case 16: { constexpr int HP = 16; CALL; } break; \
-        default: { constexpr int HP = 32; CALL; } break; \
+// (conditioner width bucket, rows per wave): one flat chain -- CALL contains a kernel launch, whose macro expands to text
+// with bare commas, so it cannot be handed on to a second dispatch macro
+#define NFMC_HP_DISPATCH_N(HPV, RPWV, CALL) \
+    { const int hp_ = (HPV); \
+    if ((RPWV) == 64 && hp_ == 4) { constexpr int HP = 4, RPW = 64; CALL; } \
+    else if ((RPWV) == 64 && hp_ == 8) { constexpr int HP = 8, RPW = 64; CALL; } \
+    else if ((RPWV) == 64 && hp_ == 16) { constexpr int HP = 16, RPW = 64; CALL; } \
+    else if ((RPWV) == 64 && hp_ == 32) { constexpr int HP = 32, RPW = 64; CALL; } \
+    else if ((RPWV) == 32 && hp_ == 4) { constexpr int HP = 4, RPW = 32; CALL; } \
+    else if ((RPWV) == 32 && hp_ == 8) { constexpr int HP = 8, RPW = 32; CALL; } \
+    else if ((RPWV) == 32 && hp_ == 16) { constexpr int HP = 16, RPW = 32; CALL; } \
+    else if ((RPWV) == 32 && hp_ == 32) { constexpr int HP = 32, RPW = 32; CALL; } \
+    else if ((RPWV) == 16 && hp_ == 4) { constexpr int HP = 4, RPW = 16; CALL; } \
+    else if ((RPWV) == 16 && hp_ == 8) { constexpr int HP = 8, RPW = 16; CALL; } \
+    else if ((RPWV) == 16 && hp_ == 16) { constexpr int HP = 16, RPW = 16; CALL; } \
+    else if ((RPWV) == 16 && hp_ == 32) { constexpr int HP = 32, RPW = 16; CALL; } \
     }
 
 extern "C" int64_t nfmc_neutra_scratch_bytes(int64_t n, int32_t d, int32_t n_hidden, int32_t n_hidden_layers,
@@ -427,13 +477,15 @@ extern "C" int nfmc_neutra_potential_grad_f32(const NfmcRealNVP* flow, const Nfm
     if (rc) return rc;
     if (!pot || !z || n <= 0) return NFMC_EINVAL;
     if (pot->kind != NFMC_POT_QUADRATIC && pot->kind != NFMC_POT_FUNNEL) return NFMC_EUNSUPPORTED;
-    const int64_t tiles = (n + 63) / 64;
+    const int rpw = neutra_rows_per_wave(flow->d, 3);
+    if (!rpw) return NFMC_ESHAPE;
+    const int64_t tiles = (n + rpw - 1) / rpw;
     const int grid = (int)(tiles < 4 * kMaxGrid ? tiles : 4 * kMaxGrid);
-    const size_t lds = (size_t)3 * 64 * tile_stride(flow->d) * sizeof(float);
+    const size_t lds = (size_t)3 * rpw * tile_stride(flow->d) * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
-    NFMC_HP_DISPATCH_N(hp_bucket_n(flow->n_hidden), {
-        if ((rc = set_lds_n(neutra_potential_grad_kernel<HP>, lds))) return rc;
-        hipLaunchKernelGGL((neutra_potential_grad_kernel<HP>), dim3(grid), dim3(kNeutraBlock), lds, st, *flow, *pot, z,
+    NFMC_HP_DISPATCH_N(hp_bucket_n(flow->n_hidden), rpw, {
+        if ((rc = set_lds_n(neutra_potential_grad_kernel<HP, RPW>, lds))) return rc;
+        hipLaunchKernelGGL((neutra_potential_grad_kernel<HP, RPW>), dim3(grid), dim3(kNeutraBlock), lds, st, *flow, *pot, z,
                            n, u_out, grad_out, tiles);
     })
     NFMC_HIP_CHECK_LAUNCH();
@@ -464,15 +516,17 @@ extern "C" int nfmc_neutra_hmc_steps_f32(const NfmcNeutraHmcArgs* args, nfmc_str
     if (!store_ok(a.samples)) return NFMC_EINVAL;
     const int d = a.flow.d;
     const int dp = padded_d(d);
-    const int64_t tiles = (a.n + 63) / 64;
+    const int rpw = neutra_rows_per_wave(d, 4);
+    if (!rpw) return NFMC_ESHAPE;
+    const int64_t tiles = (a.n + rpw - 1) / rpw;
     const int grid = (int)(tiles < kMaxGrid ? tiles : kMaxGrid);
     if (a.stats.sum_x && a.stats.scratch_bytes < (int64_t)grid * (2 * dp + kStatTail) * (int64_t)sizeof(double))
         return NFMC_ESCRATCH;
-    const size_t lds = (size_t)4 * 64 * tile_stride(d) * sizeof(float);
+    const size_t lds = (size_t)4 * rpw * tile_stride(d) * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
-    NFMC_HP_DISPATCH_N(hp_bucket_n(a.flow.n_hidden), {
-        if ((rc = set_lds_n(neutra_hmc_kernel<HP>, lds))) return rc;
-        hipLaunchKernelGGL((neutra_hmc_kernel<HP>), dim3(grid), dim3(kNeutraBlock), lds, st, a, tiles, dp);
+    NFMC_HP_DISPATCH_N(hp_bucket_n(a.flow.n_hidden), rpw, {
+        if ((rc = set_lds_n(neutra_hmc_kernel<HP, RPW>, lds))) return rc;
+        hipLaunchKernelGGL((neutra_hmc_kernel<HP, RPW>), dim3(grid), dim3(kNeutraBlock), lds, st, a, tiles, dp);
     })
     NFMC_HIP_CHECK_LAUNCH();
     if (a.stats.sum_x) {

@@ -1713,6 +1713,47 @@ def test_neutra_hmc_shapes_without_a_fused_kernel_match_oracle(dev, d, ck, kind)
     assert abs(out.statistics.n_accepted_trajectories - tr.n_accepted) <= 4
 
 
+@pytest.mark.parametrize('d,nh', [(200, None), (256, None), (300, 8), (512, None), (511, 16)])
+def test_neutra_hmc_wide_events_run_on_the_fused_kernel(dev, d, nh):
+    """Round 3: the VALU NeuTra kernels hold 32 or 16 chains per wave when 64 rows of the event do not fit the LDS, so every
+    event size up to 512 with a conditioner of width <= 32 has a fused trajectory kernel and a gradient kernel (before,
+    d > ~156 / ~208 went to the split path and torch autograd).  The fused kernel must run (the test fails on the split
+    path), match the oracle on the Philox streams, and `nfmc_neutra_potential_grad_f32` must match autograd of the oracle."""
+    from nfmc_amd.samplers import neutra, mcmc
+    from nfmc_amd.flows import Flow, RealNVP
+    from nfmc_amd.potentials import SumOfSquares
+    from oracle import flow as oflow, potentials as opot, samplers as osamp
+    n, T, L, h = 70, 2, 2, 0.03
+    torch.manual_seed(d)
+    ck = {'n_hidden': nh} if nh else {}
+    of = oflow.perturb_(oflow.Flow(oflow.RealNVP((d,), conditioner_kwargs=ck)), 9, 0.1)
+    f = Flow(RealNVP((d,), conditioner_kwargs=ck))
+    f.load_state_dict(of.state_dict())
+    z0 = 0.5 * torch.randn(n, d)
+    s = neutra.NeuTraHMC((d,), SumOfSquares((d,)), mcmc.HMCKernel(event_size=d, n_leapfrog_steps=L, step_size=h),
+                         mcmc.HMCParameters(), neutra.NeuTraKernel((d,), flow=f), neutra.NeuTraParameters(n_iterations=T))
+
+    def boom(*a, **k):
+        raise AssertionError('NeuTra took the split path: no fused kernel ran')
+    s.inner_sampler.sample = boom
+    s.seed = 78
+    out = s.sample(z0, show_progress=False)
+    tr = osamp.neutra_hmc_sample(z0, opot.sum_squares, of, T, h, None, L, noise=osamp.PhiloxNoise(78))
+    got, want = out.samples.reshape(T, n, d), tr.stacked()
+    same = (got - want).abs().amax(dim=(0, 2)) < 5e-4
+    assert same.float().mean() > 0.9, float(same.float().mean())
+    assert out.statistics.n_attempted_trajectories == n * T
+    assert abs(out.statistics.n_accepted_trajectories - tr.n_accepted) <= 4
+    # the standalone gradient kernel against autograd through the CPU restatement (neutra.py:58-68)
+    u, g = s._potential_grad(z0)
+    zz = z0.clone().requires_grad_(True)
+    x, ld = of.bijection.inverse(zz)
+    ut = opot.sum_squares(x) - ld
+    gt, = torch.autograd.grad(ut.sum(), zz)
+    np.testing.assert_allclose(u.cpu().numpy(), ut.detach().numpy(), rtol=2e-5, atol=2e-4)
+    np.testing.assert_allclose(g.cpu().numpy(), gt.numpy(), atol=2e-4 * max(1.0, float(gt.abs().max())))
+
+
 @pytest.mark.parametrize('strategy', ['jump_mala', 'jump_hmc', 'jump_mh', 'imh', 'adaptive_imh', 'neutra_hmc', 'neutra_mh'])
 def test_every_flow_strategy_runs_on_awkward_shapes(dev, strategy):
     """Event sizes around every tile / layout boundary (2 ... 511, odd, ragged), each flow kind, a conditioner width off
