@@ -102,7 +102,7 @@ CONFIGS = {
     'C4': dict(strategy='neutra_hmc', d=128, n_per_gpu=65536, inner=1, transitions_per_step=1,
                kernel='neutra_leapfrog_mfma_kernel', label='neutra_hmc_steps', bound='mfma',
                workload='BASELINE configs[3]: neutra_hmc + realnvp (conditioner 128 x 2), funnel potential d=128, 65536 '
-                        'chains per GPU, L=10 leapfrog steps (h=0.02); one bench step = one trajectory',
+                        'chains per GPU, L=10 leapfrog steps; one bench step = one trajectory',
                metric='chain-steps/sec (n_chains x iters / s), neutra_hmc + RealNVP, funnel d=128, L=10'),
     'C5': dict(strategy='jump_hmc', d=256, n_per_gpu=32768, inner=5, transitions_per_step=6,
                kernel='hmc_kernel', label='hmc_steps', bound='valu',
@@ -130,6 +130,17 @@ def fitted_flow_state(cfg_name, cfg, dev):
     region.  An unfitted flow accepts ~0.2 % of the jumps; the arithmetic per transition is the same either way."""
     import torch
     from nfmc_amd.flows import Flow, RealNVP
+    if cfg_name not in FLOW_STATE and cfg['strategy'] == 'neutra_hmc':
+        # C4: the state NeuTra's warmup leaves (neutra.py:70-107): a variational (reverse-KL) fit of the flow to the funnel,
+        # 200 epochs of 1024 latents -- the conditioner is 128 wide, so this fit runs on the torch path (fit kernels: <= 32)
+        from nfmc_amd.potentials import Funnel
+        d = cfg['d']
+        pot = Funnel((d,), 3.0)
+        torch.manual_seed(1)
+        f = Flow(RealNVP((d,), conditioner_kwargs={'n_hidden': 128, 'n_layers': 2})).to(dev)
+        f.variational_fit(lambda v: -pot(v), n_epochs=200, lr=0.01, n_samples=1024, early_stopping=False,
+                          keep_best_weights=True, show_progress=False)
+        FLOW_STATE[cfg_name] = {k: v.detach().cpu().clone() for k, v in f.state_dict().items()}
     if cfg_name not in FLOW_STATE:
         d = cfg['d']
         torch.manual_seed(1)
@@ -141,6 +152,12 @@ def fitted_flow_state(cfg_name, cfg, dev):
               show_progress=False)
         FLOW_STATE[cfg_name] = {k: v.detach().cpu().clone() for k, v in f.state_dict().items()}
     return FLOW_STATE[cfg_name]
+
+
+def neutra_step_size(flow_state):
+    """C4's leapfrog step: 0.3 in the latent space of the FITTED flow (acceptance ~0.88: tools/probe_c4_fitted.py); 0.02 with
+    the random initialisation of rounds 1-2, which also needs the chains started at 0.5 x0 not to reject everything."""
+    return 0.3 if flow_state is not None else 0.02
 
 
 def build_sampler(cfg, n_steps, fit_nf=False, flow_seed=1, flow_state=None):
@@ -167,10 +184,13 @@ def build_sampler(cfg, n_steps, fit_nf=False, flow_seed=1, flow_state=None):
         _match_scale_(s.kernel.flow)
         return s
     if st == 'neutra_hmc':
-        return create_sampler(Funnel((d,), 3.0), strategy=st, flow='realnvp',
-                              flow_kwargs={'conditioner_kwargs': {'n_hidden': 128, 'n_layers': 2}},
-                              inner_kernel_kwargs={'n_leapfrog_steps': 10, 'step_size': 0.02},
-                              param_kwargs={'n_iterations': n_steps, 'store_samples': False})
+        s = create_sampler(Funnel((d,), 3.0), strategy=st, flow='realnvp',
+                           flow_kwargs={'conditioner_kwargs': {'n_hidden': 128, 'n_layers': 2}},
+                           inner_kernel_kwargs={'n_leapfrog_steps': 10, 'step_size': neutra_step_size(flow_state)},
+                           param_kwargs={'n_iterations': n_steps, 'store_samples': False})
+        if flow_state is not None:
+            s.kernel.flow.load_state_dict(flow_state)
+        return s
     raise ValueError(st)
 
 
@@ -192,13 +212,13 @@ def _match_scale_(flow, std=0.7071067811865476):
 
 
 def initial_state(cfg, n_total):
-    """x0 ~ N(0, I), f32, from torch.manual_seed(0) on the CPU, so CPU and GPU legs share it.  The
-    funnel's NeuTra run starts closer in (0.5 N(0, I)): an untrained flow + N(0, I) in 128 dimensions puts most chains
-    where a step of 0.02 rejects, which measures nothing."""
+    """x0 ~ N(0, I), f32, from torch.manual_seed(0) on the CPU, so CPU and GPU legs share it.  Only the
+    UNFITTED funnel run (--unfitted-flow) starts closer in (0.5 N(0, I)): an untrained flow + N(0, I) in 128 dimensions
+    puts most chains where a step of 0.02 rejects, which measures nothing."""
     import torch
     gen = torch.Generator(device='cpu').manual_seed(0)
     x0 = torch.randn(n_total, cfg['d'], generator=gen)
-    return 0.5 * x0 if cfg['strategy'] == 'neutra_hmc' else x0
+    return 0.5 * x0 if (cfg['strategy'] == 'neutra_hmc' and cfg.get('_flow_state') is None) else x0
 
 
 # ---------------------------------------------------------------------------------------------------- CPU legs
@@ -207,7 +227,10 @@ def _oracle_flow(cfg):
     from oracle import flow as oflow
     torch.manual_seed(1)
     if cfg['strategy'] == 'neutra_hmc':
-        return oflow.Flow(oflow.RealNVP((cfg['d'],), conditioner_kwargs={'n_hidden': 128, 'n_layers': 2}))
+        f = oflow.Flow(oflow.RealNVP((cfg['d'],), conditioner_kwargs={'n_hidden': 128, 'n_layers': 2}))
+        if cfg.get('_flow_state') is not None:
+            f.load_state_dict(cfg['_flow_state'])
+        return f
     f = oflow.Flow(oflow.RealNVP((cfg['d'],)))
     if cfg.get('_flow_state') is not None:
         f.load_state_dict(cfg['_flow_state'])
@@ -228,7 +251,8 @@ def _oracle_run(cfg, x0, flow, n_steps, noise=None):
     if st == 'imh':
         return osamp.imh_sample(x0, opot.sum_squares, flow, n_steps * cfg['inner'], noise=noise, store=False), \
             n_steps * cfg['inner']
-    return osamp.neutra_hmc_sample(x0, opot.funnel(3.0), flow, n_steps, 0.02, None, 10, noise=noise), n_steps
+    return osamp.neutra_hmc_sample(x0, opot.funnel(3.0), flow, n_steps, neutra_step_size(cfg.get('_flow_state')), None, 10,
+                                   noise=noise), n_steps
 
 
 def cpu_baseline(cfg):
@@ -541,11 +565,11 @@ def main():
 
     n_local = cfg['n_per_gpu']
     n_total = n_local * world
-    x_start = initial_state(cfg, n_total).to(dev)   # resident in HBM before any timed region
     cfg = dict(cfg)
     cfg['_flow_state'] = None
-    if cfg['strategy'] in ('jump_mala', 'jump_hmc') and not args.unfitted_flow:
+    if cfg['strategy'] in ('jump_mala', 'jump_hmc', 'neutra_hmc') and not args.unfitted_flow:
         cfg['_flow_state'] = fitted_flow_state(args.config, cfg, dev)   # deterministic: every rank fits the same flow
+    x_start = initial_state(cfg, n_total).to(dev)   # resident in HBM before any timed region
 
     def run(n_steps, x, time_kernels=False, rounds=None):
         s = build_sampler(cfg, n_steps, fit_nf=args.fit_nf, flow_state=cfg['_flow_state'])
@@ -651,12 +675,14 @@ def main():
                        'n_chains_per_gpu': n_local, 'n_dim': cfg['d'], 'inner_steps': cfg['inner'],
                        'transitions_per_step': cfg['transitions_per_step'], 'store_samples': False,
                        'x0': 'N(0, I), torch.manual_seed(0) on the CPU, uploaded before timing; W warm-up steps carry it '
-                             'to stationarity' + (' (x 0.5 for the funnel)' if cfg['strategy'] == 'neutra_hmc' else ''),
+                             'to stationarity' + (' (x 0.5 for the unfitted funnel run)'
+                                                  if cfg['strategy'] == 'neutra_hmc' and cfg['_flow_state'] is None else ''),
                        'fit_nf': bool(args.fit_nf),
                        'proposal_flow': ('default RealNVP, weights seed 1' + (
-                           ', fitted ONCE before timing by Flow.fit (maximum likelihood, device path) to 4096 draws of the '
-                           'target: the state warmup=True leaves' if cfg['_flow_state'] is not None else
-                           ' (unfitted)' if cfg['strategy'].startswith('jump') else '')),
+                           ', fitted ONCE before timing (jump configs: Flow.fit, maximum likelihood, device path, on 4096 draws of the '
+                           'target; neutra_hmc: Flow.variational_fit, 200 epochs, step size 0.3): the state warmup=True leaves'
+                           if cfg['_flow_state'] is not None else
+                           ' (unfitted)' if cfg['strategy'] != 'imh' else ' (proposal scale matched, bench.py: _match_scale_)')),
                        'sharding': f'chains x{world}, no data-path collective; one statistics all-reduce per sample()'
                                    + ('; refit-buffer all-gather every outer iteration' if args.fit_nf else '')},
             'repetitions': len(reps), 'rep_ms': rep_ms, 'rep_ms_median': statistics.median(rep_ms),
