@@ -96,7 +96,7 @@ CONFIGS = {
                metric='chain-steps/sec (n_chains x iters / s), jump_mala + RealNVP, d=64'),
     'C2': dict(strategy='imh', d=64, n_per_gpu=8192, inner=50, transitions_per_step=50,
                kernel='imh_eval_kernel', label='imh_parallel', bound='valu',
-               workload='BASELINE configs[1]: imh + realnvp (proposal scale matched to the target), U=sum x^2, d=64, 8192 '
+               workload='BASELINE configs[1]: imh + realnvp, U=sum x^2, d=64, 8192 '
                         'chains per GPU; one bench step = 50 independence-MH transitions (20 steps = SURVEY C2\'s T=1000)',
                metric='chain-steps/sec (n_chains x iters / s), imh + RealNVP, d=64'),
     'C4': dict(strategy='neutra_hmc', d=128, n_per_gpu=65536, inner=1, transitions_per_step=1,
@@ -141,6 +141,17 @@ def fitted_flow_state(cfg_name, cfg, dev):
         f.variational_fit(lambda v: -pot(v), n_epochs=200, lr=0.01, n_samples=1024, early_stopping=False,
                           keep_best_weights=True, show_progress=False)
         FLOW_STATE[cfg_name] = {k: v.detach().cpu().clone() for k, v in f.state_dict().items()}
+    if cfg_name not in FLOW_STATE and cfg['strategy'] == 'imh':
+        # C2: the independence sampler's own warmup (imh.py:60-75): a variational fit of the default RealNVP to the target,
+        # on the device (fit kernels), 300 epochs of 1024 latents
+        from nfmc_amd.potentials import SumOfSquares
+        d = cfg['d']
+        pot = SumOfSquares((d,))
+        torch.manual_seed(1)
+        f = Flow(RealNVP((d,))).to(dev)
+        f.variational_fit(lambda v: -pot(v), n_epochs=300, lr=0.02, n_samples=1024, early_stopping=False,
+                          keep_best_weights=True, show_progress=False, potential=pot)
+        FLOW_STATE[cfg_name] = {k: v.detach().cpu().clone() for k, v in f.state_dict().items()}
     if cfg_name not in FLOW_STATE:
         d = cfg['d']
         torch.manual_seed(1)
@@ -181,7 +192,10 @@ def build_sampler(cfg, n_steps, fit_nf=False, flow_seed=1, flow_state=None):
     if st == 'imh':
         s = create_sampler(SumOfSquares((d,)), strategy=st, flow='realnvp',
                            param_kwargs={'n_iterations': n_steps * cfg['inner'], 'store_samples': False})
-        _match_scale_(s.kernel.flow)
+        if flow_state is not None:
+            s.kernel.flow.load_state_dict(flow_state)
+        else:
+            _match_scale_(s.kernel.flow)
         return s
     if st == 'neutra_hmc':
         s = create_sampler(Funnel((d,), 3.0), strategy=st, flow='realnvp',
@@ -234,6 +248,7 @@ def _oracle_flow(cfg):
     f = oflow.Flow(oflow.RealNVP((cfg['d'],)))
     if cfg.get('_flow_state') is not None:
         f.load_state_dict(cfg['_flow_state'])
+        return f
     return _match_scale_(f) if cfg['strategy'] == 'imh' else f
 
 
@@ -567,7 +582,7 @@ def main():
     n_total = n_local * world
     cfg = dict(cfg)
     cfg['_flow_state'] = None
-    if cfg['strategy'] in ('jump_mala', 'jump_hmc', 'neutra_hmc') and not args.unfitted_flow:
+    if not args.unfitted_flow:
         cfg['_flow_state'] = fitted_flow_state(args.config, cfg, dev)   # deterministic: every rank fits the same flow
     x_start = initial_state(cfg, n_total).to(dev)   # resident in HBM before any timed region
 
@@ -680,9 +695,10 @@ def main():
                        'fit_nf': bool(args.fit_nf),
                        'proposal_flow': ('default RealNVP, weights seed 1' + (
                            ', fitted ONCE before timing (jump configs: Flow.fit, maximum likelihood, device path, on 4096 draws of the '
-                           'target; neutra_hmc: Flow.variational_fit, 200 epochs, step size 0.3): the state warmup=True leaves'
+                           'target; imh: Flow.variational_fit on the device, 300 epochs; neutra_hmc: Flow.variational_fit, 200 '
+                           'epochs, step size 0.3): the state warmup=True leaves'
                            if cfg['_flow_state'] is not None else
-                           ' (unfitted)' if cfg['strategy'] != 'imh' else ' (proposal scale matched, bench.py: _match_scale_)')),
+                           ' (unfitted)' if cfg['strategy'] != 'imh' else ' (unfitted, proposal scale matched: _match_scale_)')),
                        'sharding': f'chains x{world}, no data-path collective; one statistics all-reduce per sample()'
                                    + ('; refit-buffer all-gather every outer iteration' if args.fit_nf else '')},
             'repetitions': len(reps), 'rep_ms': rep_ms, 'rep_ms_median': statistics.median(rep_ms),

@@ -290,12 +290,14 @@ int nfmc_flow_mh_supported_f32(const NfmcFlowMhArgs* args);
 
 /* The same run of n_steps independent-MH transitions (FixedIMH.sample, imh.py:200-255) as a data-parallel problem:
  * the proposals of an independence sampler do not depend on the state, so all n * n_steps of them are evaluated at
- * once, a per-chain scan applies the Metropolis tests, and the accepted proposals are replayed, weighted by their
- * dwell times, for the moments / sample store / final state.  Same noise streams and results as
+ * once, a per-chain scan (one lane per chain) applies the Metropolis tests, and proposals are replayed for the moments /
+ * sample store / final state: the accepted ones weighted by their dwell times, or -- when more than about half are
+ * accepted and no samples are stored -- only the corrections to the sums the proposal pass kept over all of them.
+ * Same noise streams and results as
  * nfmc_flow_mh_steps_f32 (states and masks bit for bit; moments up to summation order).  Faster at every
  * chain count measured (3x at n = 1000, 1.15x at n = 65536, d = 64): few chains no longer leave the GPU idle, and the
  * accept uniforms are drawn once per (chain, step) instead of once per lane.  Requires adjusted = 1, n_hidden <= 8, n_steps <= NFMC_IMH_PARALLEL_MAX_STEPS;
- * `work` >= nfmc_imh_parallel_work_bytes(n, d, n_steps) bytes of device scratch. */
+ * `work` >= nfmc_imh_parallel_work_bytes(n, d, n_steps) bytes of device scratch, 16-byte aligned. */
 #define NFMC_IMH_PARALLEL_MAX_STEPS 65536
 int64_t nfmc_imh_parallel_work_bytes(int64_t n, int32_t d, int32_t n_steps);
 int nfmc_imh_parallel_f32(const NfmcFlowMhArgs* args, void* work, int64_t work_bytes, nfmc_stream_t stream);

@@ -392,7 +392,9 @@ inline bool store_ok(const NfmcSampleStore& s) {
 template <int CPL, int LPC>
 __device__ __forceinline__ void block_stats_flush(const float (&sx)[CPL], const float (&sxx)[CPL], uint32_t accepted,
                                                   uint32_t nonfinite, const NfmcStats& st,
-                                                  uint32_t jump_accepted = 0, uint32_t jump_nonfinite = 0) {
+                                                  uint32_t jump_accepted = 0, uint32_t jump_nonfinite = 0,
+                                                  const double* __restrict__ extra = nullptr) {
+    // extra: 2 * DP sums another kernel prepared for this workgroup, added to its slab (imh_parallel.hip)
     double* __restrict__ scratch = st.scratch;
     const bool defer = st.defer != 0;
     const int slot = defer ? st.tail_slot : 0;   // deferred jumps book their counts in the jump slots
@@ -421,6 +423,7 @@ __device__ __forceinline__ void block_stats_flush(const float (&sx)[CPL], const 
         double s = 0.0;
 #pragma unroll
         for (int w = 0; w < kWavesPerBlock; ++w) s += red[w][t];
+        if (extra && t < 2 * DP) s += extra[t];
         out[t] = defer ? out[t] + s : s;   // one owner thread per (workgroup, column): no race, fixed order
     }
 }

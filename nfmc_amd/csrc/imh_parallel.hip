@@ -12,28 +12,54 @@
 
 namespace nfmc {
 
+constexpr int32_t kLastFlag = 1 << 30;   // replay: set in the dwell time of the proposal that is a chain's final state
+constexpr int kScanBlock = 28;           // steps per accept-mask word: two blocks of records in flight per lane + the mask stores stay under the 63
+                                         // operations the memory counter tracks (at 32 the compiler drains the queue every iteration)
+// accept-mask words per chain: an even number of blocks (the scan works on two at a time)
+__host__ __device__ inline int imh_words(int k) { return ((k + 2 * kScanBlock - 1) / (2 * kScanBlock)) * 2; }
+
 struct ImhWork {
-    // chain-major (n, k): a chain's k proposals are contiguous, so the scan's 64 lanes read 64 consecutive words
-    // (step-major made every lane of the scan touch its own cache line: 284 us of a 1.8 ms run at n = 8192, k = 1000)
-    float* u;        // (n, k) U(x')
-    float* f;        // (n, k) log q(x')
-    float* logu;     // (n, k) log of the accept uniform of (chain, step)
-    int32_t* dwell;  // (n, k) number of steps proposal (i, s) was the state of chain i (0: rejected)
-    int32_t* dwell0; // (n)    the same for the initial state
-    int32_t* last;   // (n)    step whose proposal is the final state, -1: the initial state
+    // step-major (k, n): row r = s * n + i.  The scan runs one chain per LANE, so the 64 lanes of a wave read 64
+    // consecutive words of one step; the proposal and replay kernels only need consecutive rows to be cheap to
+    // enumerate.  (Rounds 1-2 scanned one chain per WAVE over chain-major arrays: 173 us at C2 with a quarter of the
+    // proposals accepted, 600 us with the fitted flow's 86 %, sequential per acceptance while 63 lanes idled.)
+    float4* rec;     // (k, n) {U(x'), log q(x'), log of the accept uniform of (chain, step), -}: one 16-byte load per step
+    uint32_t* bits;  // (words, n) accept masks: bit b of word q of chain i = proposal (kScanBlock q + b, i) was accepted.  The replay
+                     // reads a proposal's dwell time (the steps it stayed the state) off them: the distance to the next set bit
+    int32_t* dwell0; // (n)    the steps the initial state lasted (the first accepted step, k when none)
     float* x0;       // (n, d) copy of the initial states
+    double* esum;    // (grid of the proposal kernel, 2 * dp) its workgroups' sums of x' and x'^2 over ALL finite proposals
+    unsigned long long* visit;   // [0] rows the replay visits when it sums the accepted proposals, [1] when it corrects esum
 };
 
-// row r of the chain-major work arrays -> (chain i, step s).  A 64-bit division is ~180 VALU instructions on
-// gfx950 (a quarter of the proposal loop); every launch the host makes has n * k < 2^31 (`small`).
-__device__ __forceinline__ void split_row(int64_t r, int k, bool small, int64_t& i, int& s) {
+// first row of a wave's 64 -> (step, chain): one 32-bit division per 64 rows (a 64-bit one is ~180 VALU instructions
+// on gfx950; every launch the host makes has n * k < 2^31, `small`)
+struct RowBase {
+    int64_t i;
+    int s;
+};
+__device__ __forceinline__ RowBase row_base(int64_t r0, int64_t n, bool small) {
+    RowBase b;
     if (small) {
-        const uint32_t q = (uint32_t)r / (uint32_t)k;
-        i = q;
-        s = (int)((uint32_t)r - q * (uint32_t)k);
+        const uint32_t q = (uint32_t)r0 / (uint32_t)n;
+        b.s = (int)q;
+        b.i = (int64_t)((uint32_t)r0 - q * (uint32_t)n);
     } else {
-        i = r / k;
-        s = (int)(r - i * k);
+        b.s = (int)(r0 / n);
+        b.i = r0 - (int64_t)b.s * n;
+    }
+    return b;
+}
+// row r0 + off (off < 64) -> (chain i, step s)
+__device__ __forceinline__ void split_row(const RowBase& b, int off, int64_t n, int64_t& i, int& s) {
+    i = b.i + off;
+    s = b.s;
+    if (n >= 64) {
+        if (i >= n) i -= n, ++s;
+    } else {
+        const uint32_t q = (uint32_t)i / (uint32_t)n;
+        s += (int)q;
+        i -= (int64_t)q * n;
     }
 }
 
@@ -58,6 +84,42 @@ __device__ __forceinline__ void imh_propose(float (&xp)[CPL], float& f_xp, float
     u_xp = group_allreduce<LPC>(up);                                                          // imh.py:225
 }
 
+__device__ __forceinline__ unsigned long long wave_sum_u32(uint32_t v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += (uint32_t)__shfl_xor((int)v, m, kWave);
+    return (unsigned long long)v;
+}
+
+// a workgroup's sums of x' and x'^2 (fp32 per lane -> fp64 over the chains of the wave and the waves of the workgroup,
+// fixed order) into its slot of ImhWork::esum
+template <int CPL, int LPC>
+__device__ __forceinline__ void block_sums_store(const float (&sx)[CPL], const float (&sxx)[CPL], double* __restrict__ out) {
+    constexpr int DP = CPL * LPC;
+    __shared__ double red[kWavesPerBlock][2 * DP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane % LPC;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        const double p = (double)cross_chain_reduce<LPC>(sx[i]);
+        const double q = (double)cross_chain_reduce<LPC>(sxx[i]);
+        if (lane < LPC) {
+            red[wave][coord_of<CPL, LPC>(g, i)] = p;
+            red[wave][DP + coord_of<CPL, LPC>(g, i)] = q;
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 2 * DP; t += kBlock) {
+        double v = 0.0;
+#pragma unroll
+        for (int wv = 0; wv < kWavesPerBlock; ++wv) v += red[wv][t];
+        out[t] = v;
+    }
+}
+
+// a proposal enters the proposal kernel's running sums when its potential and log density are finite (then so is x');
+// the replay recomputes both bit for bit and applies the same test when it corrects those sums
+__device__ __forceinline__ bool imh_summed(float u_xp, float f_xp) { return fabsf(u_xp) <= 3.0e38f && fabsf(f_xp) <= 3.0e38f; }
+
 template <int CPL, int LPC, int HP, template <int, int, bool> class Pot, bool FAST>
 __global__ void __launch_bounds__(kBlock) imh_eval_kernel(NfmcFlowMhArgs a, ImhWork w, int64_t tiles) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -76,26 +138,33 @@ __global__ void __launch_bounds__(kBlock) imh_eval_kernel(NfmcFlowMhArgs a, ImhW
     pot.init(a.pot, g, d);
     const bool revl = (a.flow.n_coupling & 1) != 0;
     const float base_c = -0.5f * (float)d * kLog2Pi;
+    const bool sums = a.stats.sum_x != nullptr;
+    float sx[CPL], sxx[CPL];
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) sx[q] = sxx[q] = 0.f;
+    if (blockIdx.x == 0 && threadIdx.x == 0) w.visit[0] = w.visit[1] = 0ull;   // the scan (next on the stream) counts into them
     // a wave owns 64 consecutive rows per tile: first every lane draws the accept uniform of ONE row (one Philox call
     // per row instead of one per lane and row: 8 % of the kernel at LPC = 8), then LPC passes evaluate CPW rows each
     for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         const int64_t r0 = (tile * kWavesPerBlock + wave) * kWave;
+        if (r0 >= total) continue;                                    // wave-uniform
+        const RowBase rb0 = row_base(r0, n, small);
+        float logu_lane = 0.f;
         {
             const int64_t r = r0 + lane;
             if (r < total) {
                 int64_t i;
                 int s;
-                split_row(r, a.n_steps, small, i, s);
+                split_row(rb0, lane, n, i, s);
                 float uu;   // the accept uniform of (chain i, step s): imh.py:229
                 if (a.rng.replay_uniforms) {
-                    uu = a.rng.replay_uniforms[(int64_t)s * n + i];
+                    uu = a.rng.replay_uniforms[r];
                 } else {
                     const uint4 rnd = philox4x32_10((uint32_t)(a.rng.chain_offset + (uint64_t)i), a.rng.step0 + (uint32_t)s, 0u,
                                                     kTagJump, (uint32_t)a.rng.seed, (uint32_t)(a.rng.seed >> 32));
                     uu = u32_to_uniform(rnd.x);
                 }
-                w.logu[r] = fast_ln(uu);
-                w.dwell[r] = 0;
+                logu_lane = fast_ln(uu);
             }
         }
         for (int sub = 0; sub < LPC; ++sub) {
@@ -105,110 +174,182 @@ __global__ void __launch_bounds__(kBlock) imh_eval_kernel(NfmcFlowMhArgs a, ImhW
             const bool active = r < total;
             int64_t i;
             int s;
-            split_row(active ? r : total - 1, a.n_steps, small, i, s);
+            split_row(rb0, active ? sub * CPW + cw : (int)(total - 1 - r0), n, i, s);
             float xp[CPL], f_xp, u_xp;
             imh_propose<CPL, LPC, HP>(xp, f_xp, u_xp, a, fl, pot, i, s, g, revl, base_c);
-            if (active && g == 0) {
-                w.u[r] = u_xp;
-                w.f[r] = f_xp;
+            const float logu_row = __shfl(logu_lane, sub * CPW + cw, kWave);   // from the lane that drew this row's uniform
+            if (active && g == 0) w.rec[r] = make_float4(u_xp, f_xp, logu_row, 0.f);
+            if (sums && active && imh_summed(u_xp, f_xp)) {
+#pragma unroll
+                for (int q = 0; q < CPL; ++q) {
+                    sx[q] += xp[q];
+                    sxx[q] = fmaf(xp[q], xp[q], sxx[q]);
+                }
             }
         }
     }
+    if (sums) block_sums_store<CPL, LPC>(sx, sxx, w.esum + (size_t)blockIdx.x * (2 * CPL * LPC));
 }
 
-// One WAVE per chain: the Metropolis scan over the k proposals (imh.py:223-233).  Everything expensive (proposal,
-// uniform, logarithm) was done in parallel by imh_eval_kernel.  The scan is sequential only through acceptances: the
-// 64 lanes test the next 64 steps against the current state at once, the first accepting lane (ballot + ffs) becomes
-// the state and the scan resumes right after it, on the same 64 steps held in registers -- k / 64 memory round trips per
-// chain, plus a few dozen cycles per acceptance.
-__global__ void __launch_bounds__(256) imh_scan_kernel(NfmcFlowMhArgs a, ImhWork w) {
+// One LANE per chain: the Metropolis scan over the k proposals (imh.py:223-233).  Everything expensive (proposal,
+// uniform, logarithm) was done in parallel by imh_eval_kernel; what is left per step is the log ratio in the sequential
+// kernel's order of operations, the test, two selects and one bit of the chain's accept mask.
+//
+// Memory: the records of a block of kScanBlock steps are requested one whole block of arithmetic before their use (two
+// register rings, A and B, in turn).  The requests and the waits are written out (inline `global_load_dwordx3` +
+// `s_waitcnt vmcnt(N)`): left to the compiler, the same loop either waited for ALL requests at the top of every
+// iteration, the one just issued included (rings live across the back edge), or had its loads sunk to just before
+// their use.  N counts what may still be in flight behind the ring that is needed: the other ring's kScanBlock
+// requests and the one mask store between them.  With the optional per-step outputs (OUT) the stores in between are
+// not counted here and the wait is for everything.
+//
+// Rounds 1-2 scanned one chain per WAVE (173 us at C2 with a quarter of the proposals accepted, 600 us with the
+// fitted flow's 86 %); a lane per chain with one dwell-time store per step and compiler-scheduled loads was 136-203 us.
+typedef float ScanRec __attribute__((ext_vector_type(3)));   // {u', f', log uniform}
+
+struct ScanState {
+    float u_x, f_x;
+    int first;                 // first accepted step, -1: none yet
+    uint32_t prev_top;         // the previous word's top bit
+    uint32_t n_acc, n_bad, n_pairs;   // n_pairs: accepted proposals replaced after ONE step (the rows the correcting replay skips)
+};
+
+// rows of ImhWork::rec: the scan requests up to two blocks past the last word's and never looks at what it got there
+__host__ __device__ inline int64_t imh_rec_rows(int k) { return (int64_t)(imh_words(k) + 2) * kScanBlock; }
+
+__device__ __forceinline__ void scan_request(ScanRec (&ring)[kScanBlock], const float4* __restrict__ rec_blk, uint32_t lane_off, int64_t n) {
+    const char* row = (const char*)rec_blk;      // wave-uniform: an SGPR pair, bumped by one row per request
+#pragma unroll
+    for (int j = 0; j < kScanBlock; ++j) {
+        asm volatile("global_load_dwordx3 %0, %1, %2" : "=v"(ring[j]) : "v"(lane_off), "s"(row) : "memory");
+        row += n * (int64_t)sizeof(float4);
+    }
+}
+
+// the ring's requests have landed when at most N younger memory operations are in flight (they complete in order)
+template <int N>
+__device__ __forceinline__ void scan_arrived(ScanRec (&ring)[kScanBlock]) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#pragma unroll
+    for (int j = 0; j < kScanBlock; ++j) asm volatile("" : "+v"(ring[j]));   // every use of the ring follows the wait
+}
+
+template <bool OUT>
+__device__ __forceinline__ void scan_block(const ScanRec (&ring)[kScanBlock], ScanState& st, const NfmcFlowMhArgs& a, uint32_t* __restrict__ bits,
+                                           int blk, int k, int64_t n, int64_t ic) {
+    uint32_t word = 0u;
+#pragma unroll
+    for (int j = 0; j < kScanBlock; ++j) {
+        const int s = blk * kScanBlock + j;
+        const bool live = s < k;                                          // uniform
+        const ScanRec p = ring[j];
+        const float lr = (-p.x) - (-st.u_x) + st.f_x - p.y;              // util.py:392
+        const bool acc = live && p.z < lr;                                // imh.py:229-230; NaN -> reject
+        st.n_bad += live && !(fabsf(lr) <= 3.0e38f) ? 1u : 0u;
+        if (OUT) {
+            const int64_t ro = (int64_t)(live ? s : k - 1) * n + ic;
+            if (live && a.masks_out) a.masks_out[ro] = acc ? 1 : 0;
+            if (live && a.log_ratio_out) a.log_ratio_out[ro] = lr;
+        }
+        word |= acc ? (1u << j) : 0u;
+        st.u_x = acc ? p.x : st.u_x;
+        st.f_x = acc ? p.y : st.f_x;
+    }
+    bits[(int64_t)blk * n + ic] = word;   // the ONE compiler-visible memory operation of a block (scan_arrived counts it)
+    st.n_acc += (uint32_t)__popc(word);
+    st.n_pairs += (uint32_t)__popc(word & (word >> 1)) + (st.prev_top & word & 1u);
+    st.prev_top = word >> (kScanBlock - 1);
+    st.first = (st.first < 0 && word != 0u) ? blk * kScanBlock + (__ffs((int)word) - 1) : st.first;
+}
+
+template <bool OUT>
+__global__ void __launch_bounds__(kWave) imh_scan_kernel(NfmcFlowMhArgs a, ImhWork w) {
     const int64_t n = a.n;
     const int d = a.flow.d;
     const int k = a.n_steps;
-    const int lane = threadIdx.x & 63;
-    const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
-    unsigned long long acc_total = 0, bad_total = 0;   // wave-uniform
-    for (int64_t i = wave0; i < n; i += nwaves) {
-        float u_x = potential_row(w.x0 + i * d, a.pot, d);   // imh.py:224 (every lane: uniform addresses)
-        float f_x = a.logq[i];                                // imh.py:214 (filled by the caller when not cached)
-        int cur = -1;
-        // A window of 64 steps is read ONCE (and the next one requested ahead); every acceptance inside it re-tests the
-        // remaining lanes against the new state from registers.  The first version re-read the window shifted past each
-        // acceptance and wrote one scattered dwell word per acceptance (~600 per chain at C2's acceptance rate): 215 us
-        // of a 1.5 ms call; 173 us now.  What is left is instruction issue: 8192 waves x ~600 acceptances x ~30
-        // instructions of a loop that is sequential per chain.
-        float nu, nf, nl;   // the next window, requested one window ahead
-        {
-            const int64_t r0 = i * k + (lane < k ? lane : k - 1);
-            nu = w.u[r0], nf = w.f[r0], nl = w.logu[r0];
-        }
-        for (int base = 0; base < k; base += 64) {
-            const int s = base + lane;
-            const bool valid = s < k;
-            const int sv = valid ? s : k - 1;
-            const int64_t r = i * k + sv, ro = (int64_t)sv * n + i;   // work arrays (n, k); outputs (k, n)
-            const float pu = nu, pf = nf, pl = nl;
-            if (base + 64 < k) {
-                const int sn = base + 64 + lane;
-                const int64_t rn = i * k + (sn < k ? sn : k - 1);
-                nu = w.u[rn], nf = w.f[rn], nl = w.logu[rn];
-            }
-            int start = 0;                                            // lanes below are decided already
-            int dw = 0;   // dwell time of this lane's proposal when it is accepted AND replaced within this window
-            while (start < 64) {
-                const float lr = (-pu) - (-u_x) + f_x - pf;          // util.py:392
-                const bool open = valid && lane >= start;
-                const bool acc = open && pl < lr;                     // imh.py:229-230; NaN -> reject
-                const bool bad = open && !(fabsf(lr) <= 3.0e38f);
-                const unsigned long long am = __ballot(acc), bm = __ballot(bad);
-                const int j = am ? __ffsll((long long)am) - 1 : 63;  // lanes start..j are decided by this round
-                const unsigned long long decided = j == 63 ? ~0ull : ((2ull << j) - 1ull);
-                bad_total += (unsigned long long)__popcll(bm & decided);
-                if (open && lane <= j) {
-                    if (a.masks_out) a.masks_out[ro] = (acc && lane == j) ? 1 : 0;
-                    if (a.log_ratio_out) a.log_ratio_out[ro] = lr;
-                }
-                if (!am) break;
-                const int s_acc = base + j;
-                // steps the previous state stayed: into the owning lane's register when that proposal sits in this window
-                // (written with the window, one coalesced store), else one store by lane 0 -- at most one per window
-                // instead of one scattered 4-byte store per acceptance (~600 per chain at C2)
-                if (cur >= base) {
-                    if (lane == cur - base) dw = s_acc - cur;
-                } else if (lane == 0) {
-                    if (cur < 0) w.dwell0[i] = s_acc;                    // steps before the first acceptance
-                    else w.dwell[i * k + cur] = s_acc - cur;             // steps this proposal stayed the state
-                }
-                // j is wave-uniform (from the ballot): v_readlane, not a ds_bpermute round trip through the LDS per acceptance
-                u_x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pu), j));
-                f_x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pf), j));
-                cur = s_acc;
-                acc_total++;
-                start = j + 1;
-            }
-            // single writer per element: the proposal that is still the state at the end of the window gets its dwell time
-            // from lane 0 later (a later window's `else` branch above, or the tail below); every other element of the
-            // window -- rejected (0) or accepted and replaced inside it (dw) -- is written here, one coalesced store
-            if (valid && !(cur >= base && lane == cur - base)) w.dwell[r] = dw;
-        }
-        if (lane == 0) {
-            if (cur < 0) w.dwell0[i] = k;
-            else w.dwell[i * k + cur] = k - cur;
-            w.last[i] = cur;
-            a.logq[i] = f_x;                                              // imh.py:233
-        }
+    const int64_t i = (int64_t)blockIdx.x * kWave + threadIdx.x;
+    const bool valid = i < n;
+    const int64_t ic = valid ? i : n - 1;   // lanes past the last chain redo chain n - 1 and store the same words (no branch below)
+    ScanState st;
+    st.u_x = potential_row(w.x0 + ic * d, a.pot, d);   // imh.py:224
+    st.f_x = a.logq[ic];                                // imh.py:214 (filled by the caller when not cached)
+    st.first = -1;
+    st.prev_top = st.n_acc = st.n_bad = st.n_pairs = 0u;
+    const int words = imh_words(k);
+    const float4* __restrict__ rec0 = w.rec + (int64_t)blockIdx.x * kWave;          // this wave's 64 chains, row 0
+    const uint32_t lane_off = (uint32_t)(ic - (int64_t)blockIdx.x * kWave) * (uint32_t)sizeof(float4);
+    const int64_t blk_rows = (int64_t)kScanBlock * n;
+    constexpr int kBehind = OUT ? 0 : kScanBlock + 1;   // the other ring's requests + one mask store
+    ScanRec ring_a[kScanBlock], ring_b[kScanBlock];
+    __builtin_amdgcn_s_waitcnt(0);                      // nothing of the prologue in flight: the counts below start from zero
+    scan_request(ring_a, rec0, lane_off, n);
+    scan_request(ring_b, rec0 + blk_rows, lane_off, n);
+    scan_arrived<0>(ring_a);
+    scan_arrived<0>(ring_b);
+    scan_block<OUT>(ring_a, st, a, w.bits, 0, k, n, ic);
+    for (int blk = 0; blk < words; blk += 2) {
+        scan_request(ring_a, rec0 + (blk + 2) * blk_rows, lane_off, n);
+        scan_block<OUT>(ring_b, st, a, w.bits, blk + 1, k, n, ic);
+        scan_request(ring_b, rec0 + (blk + 3) * blk_rows, lane_off, n);
+        scan_arrived<kBehind>(ring_a);
+        scan_block<OUT>(ring_a, st, a, w.bits, blk + 2, k, n, ic);      // past the end: no live step, a zero word
+        scan_arrived<OUT ? 0 : 1>(ring_b);
     }
+    w.dwell0[ic] = st.first < 0 ? k : st.first;
+    a.logq[ic] = st.f_x;                                              // imh.py:233
+    if (!valid) st.n_acc = st.n_bad = st.n_pairs = 0u;
     // integer counters: atomic adds are exact, the totals do not depend on the order
-    if (lane == 0 && a.stats.counters) {
-        if (acc_total) atomicAdd(a.stats.counters + NFMC_CNT_ACCEPTED, acc_total);
-        if (bad_total) atomicAdd(a.stats.counters + NFMC_CNT_NONFINITE, bad_total);
+    const unsigned long long acc_w = wave_sum_u32(st.n_acc), bad_w = wave_sum_u32(st.n_bad), pair_w = wave_sum_u32(st.n_pairs);
+    const unsigned long long chains_w = wave_sum_u32(valid ? 1u : 0u);
+    if (threadIdx.x == 0) {
+        if (a.stats.counters) {
+            if (acc_w) atomicAdd(a.stats.counters + NFMC_CNT_ACCEPTED, acc_w);
+            if (bad_w) atomicAdd(a.stats.counters + NFMC_CNT_NONFINITE, bad_w);
+        }
+        // rows a summing replay visits: the accepted proposals; a correcting one: all but those that lasted one step
+        if (acc_w) atomicAdd(w.visit + 0, acc_w);
+        atomicAdd(w.visit + 1, chains_w * (unsigned long long)k - pair_w);
     }
 }
 
-// Replay of the proposals that were accepted (and of the initial states), weighted by their dwell times.
+// The two words of accept masks a lane of the replay needs for its row (the row's step and the next block's), loaded
+// together.  (Requesting them one tile ahead, behind the flow passes of the tile in hand, cost three registers, a
+// wave of occupancy, and gained nothing: 477 us either way.)
+struct ImhLook {
+    uint32_t w0, w1;
+};
+
+// more than kScanBlock rejections after an accepted step: rare, out of line (its registers would cost the replay a wave
+// of occupancy)
+__device__ __attribute__((noinline)) int imh_dwell_far(const uint32_t* __restrict__ bits, int64_t i, int s, int q, int k, int64_t n) {
+    const int words = (k + kScanBlock - 1) / kScanBlock;
+    for (int q2 = q + 2; q2 < words; ++q2) {
+        const uint32_t w2 = bits[(int64_t)q2 * n + i];
+        if (w2) return q2 * kScanBlock + (__ffs((int)w2) - 1) - s;
+    }
+    return (k - s) | kLastFlag;
+}
+
+// dwell time of proposal (s, i): 0 when it was rejected, else the distance to the chain's next accepted step (to the
+// end, flagged, when there is none)
+__device__ __forceinline__ int imh_dwell(const ImhLook& l, const uint32_t* __restrict__ bits, int64_t i, int s, int k, int64_t n) {
+    const int q = s / kScanBlock, b = s - q * kScanBlock;
+    if (((l.w0 >> b) & 1u) == 0u) return 0;
+    const unsigned long long rest = (((unsigned long long)l.w1 << kScanBlock) | l.w0) >> (b + 1);
+    if (rest) return __ffsll((long long)rest);
+    return imh_dwell_far(bits, i, s, q, k, n);
+}
+
+// Replay of proposals for the moments, the sample store and the final states.  Two ways, chosen per call from the
+// scan's counts (the same for every workgroup, and a function of the chains' data only, so a run repeats bit for bit):
+//   SUM      visit the ACCEPTED proposals, weight = steps each stayed the state (few acceptances: few rows);
+//   CORRECT  start from the proposal kernel's sums over ALL proposals and visit only those whose weight is not 1 --
+//            rejected (-1), kept for c > 1 steps (c - 1) -- plus every chain's final state (many acceptances: few rows).
+// With a sample store every kept step needs its row, so SUM is used.
+// The aligned 8-coordinates-per-lane layouts with narrow conditioners sit at 129-131 registers, one past four waves per
+// SIMD; held to 128 (at most 16 bytes of scratch) they run 10 % faster (C2: 477 -> 430 us).  The other layouts would spill.
 template <int CPL, int LPC, int HP, template <int, int, bool> class Pot, bool FAST>
-__global__ void __launch_bounds__(kBlock) imh_replay_kernel(NfmcFlowMhArgs a, ImhWork w, int64_t tiles) {
+__global__ void __launch_bounds__(kBlock, (CPL == 8 && HP == 4 && FAST) ? 4 : 1) imh_replay_kernel(NfmcFlowMhArgs a, ImhWork w, int64_t tiles, int eval_grid) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int CPW = kWave / LPC;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -216,6 +357,7 @@ __global__ void __launch_bounds__(kBlock) imh_replay_kernel(NfmcFlowMhArgs a, Im
     const int d = a.flow.d;
     const int64_t n = a.n, total = n * (int64_t)a.n_steps + n;   // proposals, then the n initial states
     const bool small = total < (1ll << 31);
+    const bool correct = a.stats.sum_x && !a.samples.base && w.visit[1] < w.visit[0];
     using Flow = FlowB<CPL, LPC, HP, false, (FAST && CPL >= 8)>;
     Flow::Img::stage(lds, a.flow, kBlock);
     __syncthreads();
@@ -228,48 +370,70 @@ __global__ void __launch_bounds__(kBlock) imh_replay_kernel(NfmcFlowMhArgs a, Im
     float sx[CPL], sxx[CPL];
 #pragma unroll
     for (int q = 0; q < CPL; ++q) sx[q] = sxx[q] = 0.f;
-    // a wave looks at 64 consecutive rows at a time (one coalesced load of their dwell counts) and runs the flow pass
-    // only for the rows that were ever a chain's state, CPW of them per pass: at the usual acceptance rates almost
-    // every 64-row chunk is skipped after the load (8 rows per look cost 151 us at n = 8192, k = 1000)
+    // a wave looks at 64 consecutive rows at a time (their dwell times off the accept masks) and runs the flow pass
+    // only for the rows it has to visit, CPW of them per pass: most 64-row chunks need one or two passes
     for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         const int64_t r0 = (tile * kWavesPerBlock + wave) * kWave;
+        if (r0 >= total) continue;                                // wave-uniform
+        const RowBase rb0 = row_base(r0, n, small);
         int c_lane = 0;
+        bool want = false;
         {
             const int64_t r = r0 + lane;
-            if (r < total) c_lane = r >= total - n ? w.dwell0[r - (total - n)] : w.dwell[r];
+            if (r < total) {
+                if (r >= total - n) {
+                    c_lane = w.dwell0[r - (total - n)];
+                    want = c_lane > 0;
+                } else {
+                    int64_t i;
+                    int s;
+                    split_row(rb0, lane, n, i, s);
+                    ImhLook here;
+                    here.w0 = w.bits[(int64_t)(s / kScanBlock) * n + i];
+                    here.w1 = w.bits[(int64_t)(s / kScanBlock + 1) * n + i];   // the scan writes one (zero) word past the last
+                    c_lane = imh_dwell(here, w.bits, i, s, a.n_steps, n);
+                    want = correct ? c_lane != 1 : c_lane > 0;    // the flagged dwell time of a final state is never 1
+                }
+            }
         }
-        unsigned long long todo = __ballot(c_lane > 0);
+        unsigned long long todo = __ballot(want);
         while (todo) {
             unsigned long long m = todo;                      // this group's row: the cw-th set bit
             for (int t = 0; t < cw; ++t) m &= m - 1ull;
             const int bit = m ? __ffsll((long long)m) - 1 : -1;
-            const int c = __shfl(c_lane, bit < 0 ? 0 : bit, kWave) * (bit >= 0 ? 1 : 0);
-            const int64_t r = r0 + (bit < 0 ? 0 : bit);
-            const bool initial = bit >= 0 && r >= total - n;
+            const int word = __shfl(c_lane, bit < 0 ? 0 : bit, kWave);
+            const bool have = bit >= 0;
+            const int c = have ? (word & ~kLastFlag) : 0;
+            const bool is_last = have && (word & kLastFlag) != 0;
+            const int64_t r = r0 + (have ? bit : 0);
+            const bool initial = have && r >= total - n;
             int s = 0;
             int64_t i = 0;
-            if (bit >= 0) {
+            if (have) {
                 if (initial) i = r - (total - n);
-                else split_row(r, a.n_steps, small, i, s);
+                else split_row(rb0, bit, n, i, s);
             }
             float xs[CPL];
-            if (__ballot(!initial && c > 0) != 0ull) {
+            float wgt = (float)c;
+            if (__ballot(have && !initial) != 0ull) {
                 float f_xp, u_xp;
                 imh_propose<CPL, LPC, HP>(xs, f_xp, u_xp, a, fl, pot, i, s, g, revl, base_c);
+                if (correct && imh_summed(u_xp, f_xp)) wgt -= 1.f;   // the proposal kernel counted it once
             }
             if (initial) load_row<CPL, LPC, FAST>(w.x0, i, d, g, true, xs);
-            if (c > 0) {
-                const float cf = (float)c;
+            if (have) {
+                if (wgt != 0.f) {
 #pragma unroll
-                for (int q = 0; q < CPL; ++q) {
-                    sx[q] = fmaf(cf, xs[q], sx[q]);
-                    sxx[q] = fmaf(cf * xs[q], xs[q], sxx[q]);
+                    for (int q = 0; q < CPL; ++q) {
+                        sx[q] = fmaf(wgt, xs[q], sx[q]);
+                        sxx[q] = fmaf(wgt * xs[q], xs[q], sxx[q]);
+                    }
                 }
                 if (!initial) {
                     if (a.samples.base)
                         for (int t = s; t < s + c; ++t)
                             if (float* kept = store_row_of(a.samples, t, n * (int64_t)d)) store_row<CPL, LPC, FAST>(kept, i, d, g, true, xs);
-                    if (w.last[i] == s) store_row<CPL, LPC, FAST>(a.x, i, d, g, true, xs);
+                    if (is_last) store_row<CPL, LPC, FAST>(a.x, i, d, g, true, xs);
                 } else if (a.samples.base) {
                     for (int t = 0; t < c; ++t)
                         if (float* kept = store_row_of(a.samples, t, n * (int64_t)d)) store_row<CPL, LPC, FAST>(kept, i, d, g, true, xs);
@@ -278,7 +442,9 @@ __global__ void __launch_bounds__(kBlock) imh_replay_kernel(NfmcFlowMhArgs a, Im
             for (int t = 0; t < CPW && todo; ++t) todo &= todo - 1ull;   // CPW rows done
         }
     }
-    if (a.stats.sum_x) block_stats_flush<CPL, LPC>(sx, sxx, 0u, 0u, a.stats);
+    if (a.stats.sum_x)
+        block_stats_flush<CPL, LPC>(sx, sxx, 0u, 0u, a.stats, 0u, 0u,
+                                    correct && (int)blockIdx.x < eval_grid ? w.esum + (size_t)blockIdx.x * (2 * CPL * LPC) : nullptr);
 }
 
 struct PCfg {
@@ -312,9 +478,11 @@ static int launch_imh(const NfmcFlowMhArgs& a, const ImhWork& w, hipStream_t st,
             if (e != hipSuccess) return (int)e;                                                                   \
         }                                                                                                         \
         hipLaunchKernelGGL(ka, dim3(grid_a), dim3(kBlock), lds, st, a, w, tiles_a);                               \
-        const int gs = (int)((a.n + 3) / 4 < 4096 ? (a.n + 3) / 4 : 4096);   /* one wave per chain */              \
-        hipLaunchKernelGGL(imh_scan_kernel, dim3(gs), dim3(256), 0, st, a, w);                                    \
-        hipLaunchKernelGGL(kc, dim3(gc), dim3(kBlock), lds, st, a, w, tiles_c);                                   \
+        if (a.masks_out || a.log_ratio_out)                                                                       \
+            hipLaunchKernelGGL(imh_scan_kernel<true>, dim3((unsigned)((a.n + kWave - 1) / kWave)), dim3(kWave), 0, st, a, w); \
+        else   /* one lane per chain */                                                                           \
+            hipLaunchKernelGGL(imh_scan_kernel<false>, dim3((unsigned)((a.n + kWave - 1) / kWave)), dim3(kWave), 0, st, a, w); \
+        hipLaunchKernelGGL(kc, dim3(gc), dim3(kBlock), lds, st, a, w, tiles_c, grid_a);                           \
     }
     const int d = a.flow.d;
     const bool fast = d == dp && (d % 4) == 0 && a.pot.a == nullptr && a.pot.b == nullptr && (((uintptr_t)a.x) & 15u) == 0 &&
@@ -332,11 +500,36 @@ static int launch_imh(const NfmcFlowMhArgs& a, const ImhWork& w, hipStream_t st,
 
 using namespace nfmc;
 
-static int64_t imh_work_floats(int64_t n, int32_t d, int32_t k) { return 4 * n * (int64_t)k + 2 * n + n * (int64_t)d + 8; }
+// smallest register layout that holds d coordinates; CPL = 4 first (more lanes per row for small batches)
+static PCfg imh_layout(int d) {
+    PCfg c = {0, 0};
+    for (const PCfg& k : kPCfgs) {
+        if (k.cpl * k.lpc < d) continue;
+        if (c.cpl == 0 || k.cpl * k.lpc < c.cpl * c.lpc) c = k;
+    }
+    return c;
+}
+
+// work buffer: rec (imh_rec_rows(k) x n x 16 bytes), bits ((imh_words(k) + 1) x n words), dwell0 (n), pad to 16 bytes, x0 (n d floats), pad to 8,
+// esum (kMaxGrid x 2 dp doubles), visit (2 counters)
+struct ImhLayout {
+    int64_t x0_off, esum_off, visit_off, bytes;
+};
+static ImhLayout imh_work_layout(int64_t n, int32_t d, int32_t k) {
+    const int64_t kn = n * (int64_t)k;
+    const PCfg c = imh_layout(d);
+    const int64_t dp = c.cpl ? c.cpl * c.lpc : d;
+    ImhLayout l;
+    l.x0_off = ((4 * imh_rec_rows(k) + (int64_t)imh_words(k) + 2) * n * 4 + 15) & ~15ll;
+    l.esum_off = (l.x0_off + n * (int64_t)d * 4 + 7) & ~7ll;
+    l.visit_off = l.esum_off + (int64_t)kMaxGrid * 2 * dp * 8;
+    l.bytes = l.visit_off + 16;
+    return l;
+}
 
 extern "C" int64_t nfmc_imh_parallel_work_bytes(int64_t n, int32_t d, int32_t n_steps) {
     if (n <= 0 || d <= 0 || n_steps <= 0) return 0;
-    return imh_work_floats(n, d, n_steps) * 4 + 64;
+    return imh_work_layout(n, d, n_steps).bytes + 64;
 }
 
 static int imh_parallel_run(const NfmcFlowMhArgs* args, void* work, int64_t work_bytes, nfmc_stream_t stream, bool dry);
@@ -365,17 +558,17 @@ static int imh_parallel_run(const NfmcFlowMhArgs* args, void* work, int64_t work
     if (a.stats.sum_x && a.stats.defer && a.stats.tail_slot != 0) return NFMC_EINVAL;
     if ((a.rng.replay_normals != nullptr) != (a.rng.replay_uniforms != nullptr)) return NFMC_EINVAL;
     if (!dry && work_bytes < nfmc_imh_parallel_work_bytes(a.n, f.d, a.n_steps)) return NFMC_ESCRATCH;
+    if (!dry && (((uintptr_t)work) & 15u) != 0) return NFMC_EINVAL;   // the layout below assumes a 16-byte aligned base
     hipStream_t st = (hipStream_t)stream;
     const int64_t kn = a.n * (int64_t)a.n_steps;
     ImhWork w;
-    w.u = (float*)work;
-    w.f = w.u + kn;
-    w.logu = w.f + kn;
-    w.dwell = (int32_t*)(w.logu + kn);
-    w.dwell0 = w.dwell + kn;
-    w.last = w.dwell0 + a.n;
-    w.x0 = (float*)(w.last + a.n);
-    w.x0 += (4 - ((4 * kn + 2 * a.n) & 3)) & 3;   // keep the copy of the states 16-byte aligned (vector IO)
+    w.rec = (float4*)work;
+    w.bits = (uint32_t*)(w.rec + imh_rec_rows(a.n_steps) * a.n);
+    w.dwell0 = (int32_t*)(w.bits + (int64_t)(imh_words(a.n_steps) + 1) * a.n);
+    const ImhLayout wl = imh_work_layout(a.n, f.d, a.n_steps);
+    w.x0 = (float*)((char*)work + wl.x0_off);       // 16-byte aligned (vector IO)
+    w.esum = (double*)((char*)work + wl.esum_off);
+    w.visit = (unsigned long long*)((char*)work + wl.visit_off);
     if (!dry) {
         if (!a.logq_cached) {   // flow.log_prob(x0): imh.py:214
             const int rc = nfmc_realnvp_forward_f32(&f, a.x, a.n, nullptr, nullptr, a.logq, stream);
@@ -385,11 +578,7 @@ static int imh_parallel_run(const NfmcFlowMhArgs* args, void* work, int64_t work
         if (e != hipSuccess) return (int)e;
     }
     const int d = f.d, hp = f.n_hidden <= 4 ? 4 : 8;
-    PCfg c = {0, 0};
-    for (const PCfg& k : kPCfgs) {   // smallest capacity; CPL = 4 first (more lanes per row for small batches)
-        if (k.cpl * k.lpc < d) continue;
-        if (c.cpl == 0 || k.cpl * k.lpc < c.cpl * c.lpc) c = k;
-    }
+    const PCfg c = imh_layout(d);
     if (!c.cpl) return NFMC_EUNSUPPORTED;
     int rc = NFMC_EUNSUPPORTED, grid = 0, dp = 0;
 #define M(CPL, LPC)                   \
