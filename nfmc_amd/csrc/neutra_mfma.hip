@@ -618,7 +618,8 @@ int nfmc::nfmc_mfma_supported(int32_t d, int32_t n_hidden, int32_t n_hidden_laye
 int nfmc::nfmc_neutra_potential_grad_mfma_f32(const NfmcRealNVP* flow, const NfmcPotential* pot, const float* z,
                                                    int64_t n, float* u_out, float* grad_out, nfmc_stream_t stream) {
     if (!flow || !pot || !z || n <= 0) return NFMC_EINVAL;
-    if (!nfmc_mfma_supported(flow->d, flow->n_hidden, flow->n_hidden_layers)) return NFMC_EUNSUPPORTED;
+    if (!nfmc_mfma_supported(flow->d, flow->n_hidden, flow->n_hidden_layers))   // d = 256 / 512: the streamed kernel, else no kernel
+        return nfmc_neutra_potential_grad_wide_f32(flow, pot, z, n, u_out, grad_out, stream);
     const int td = flow->d / 16, th = nfmc_realnvp_padded_hidden(flow->n_hidden) / 16, nhl = flow->n_hidden_layers;
     int rc = 0;
     NFMC_MFMA_DISPATCH(td, th, nhl, rc = (launch_grad<TD, TH, NHL>(*flow, *pot, z, n, u_out, grad_out, (hipStream_t)stream)))

@@ -1,0 +1,422 @@
+// K5 on the matrix cores for WIDE EVENTS: the adjusted potential U~(z) = U(f^-1(z)) - logdet_inv(z) and its gradient for
+// RealNVP conditioners of width 33..128 at d = 256 and d = 512 (neutra.py:58-68 has no shape limit; the register-resident
+// kernels of neutra_mfma.hip hold the state and gradient tiles of a chain in VGPRs and stop at d = 128).
+//
+// Same GEMM scheme as mfma_device.hpp (v_mfma_f32_16x16x4_f32, weights = A from an LDS image, 16 chains of a wave = N,
+// every per-chain vector in the C layout), but the state x and the gradient g of the wave's chains are STREAMED: they live
+// in a scratch slab in HBM / L2 in tile-position order, and a GEMM phase loads the 16-byte tiles it needs (B operands of
+// the first conditioner layer, target tiles in the affine epilogues, gradient accumulators of the last transposed
+// product) and stores what it changed.  Only the conditioner's hidden activations (<= 3 x 8 tiles) stay in registers, so
+// the register budget does not depend on d.  A lane only ever reads back tiles it wrote itself.
+//
+// The operands no longer fit an LDS image whole (W3 is 2 d_b x hp: 256-512 rows), so they are staged in slices of 128
+// source or target coordinates:
+//   W1 (hp x d_a)     column slices, accumulated into the same hidden tiles               d_a / 128 images
+//   W3 (2 d_b x hp)   groups of 4 target tiles: their 64 alpha rows + 64 beta rows        d_b / 64 images
+//   W3^T              the same groups, in the second image; the reverse sweep FUSES the W3 product, the affine backward
+//                     and the W3^T product per target tile, so du / dv never exist as whole vectors
+//   W1^T (d_a x hp)   row slices, accumulating into gradient tiles streamed through the epilogue
+// One image at a time, a barrier before and after each staging (the register-resident kernels overlap the next copy with
+// the current GEMM; here the copy is 1/4 of a GEMM's time and the path is the fallback for shapes that used to run
+// through torch autograd).  The reverse sweep recomputes the hidden stack (no checkpoints).
+#include "mfma_flow.hpp"
+
+namespace nfmc {
+
+constexpr int kWideSlice = 128;                 // source / target coordinates per weight image
+constexpr size_t kWideLdsBytes = (size_t)(2 * kImgFloats + 2 * kVecFloats) * sizeof(float);
+
+__device__ __forceinline__ f32x4 rev4(const f32x4 a) {
+    f32x4 t;
+    t[0] = a[3], t[1] = a[2], t[2] = a[1], t[3] = a[0];
+    return t;
+}
+
+// img[r * ld + c] = W[(row0 + (rrev ? R - 1 - r : r)) * ldw + col0 + (crev ? K - 1 - c : c)],  r < R, c < K = 4 << k4log.
+// All threads of the workgroup; col0, ldw and K are multiples of 4 and W is 16-byte aligned (16-byte pieces).
+__device__ __forceinline__ void stage_any(float* __restrict__ img, int ld, const float* __restrict__ W, int ldw, int R, int k4log, int row0,
+                                          bool rrev, int col0, bool crev) {
+    const int k4 = 1 << k4log, K = k4 << 2, N = R << k4log;
+    for (int idx = threadIdx.x; idx < N; idx += kMfmaBlock) {
+        const int r = idx >> k4log, c = (idx & (k4 - 1)) << 2;
+        const float* src = W + (size_t)(row0 + (rrev ? R - 1 - r : r)) * ldw + col0 + (crev ? K - 4 - c : c);
+        f32x4 v = *reinterpret_cast<const f32x4*>(src);
+        if (crev) v = rev4(v);
+        *reinterpret_cast<f32x4*>(img + r * ld + c) = v;
+    }
+}
+
+__device__ __forceinline__ int log2i(int v) { return 31 - __builtin_clz(v); }
+
+struct WideCtx {
+    float *img0, *img1, *vec0;   // LDS
+    float* xs;                   // this lane's chain in the state slab: element (16 m + 4 q + t) of tile m at xs[16 m + t]
+    float* gs;                   // the same in the gradient slab
+    int d, D2, nslice, ngroup;   // D2 = d / 2; slices of 128 source coordinates; groups of 64 target coordinates
+    int col, q;
+    float mscale, log1m;
+};
+
+__device__ __forceinline__ f32x4 tile_ld(const float* p, int m) { return *reinterpret_cast<const f32x4*>(p + 16 * m); }
+__device__ __forceinline__ void tile_st(float* p, int m, const f32x4 v) { *reinterpret_cast<f32x4*>(p + 16 * m) = v; }
+
+// h1 = tanh(W1 x_src + b1), hl = the last hidden layer's activations (h1 itself with one hidden layer)
+template <int TH, int NHL>
+__device__ __forceinline__ void wide_hidden(const WideCtx& c, const MLayer& L, bool REV, f32x4 (&h1)[TH], f32x4 (&h2)[TH]) {
+    constexpr int hp = 16 * TH;
+    const float* xsrc = c.xs + 16 * (REV ? c.D2 / 16 : 0);
+    for (int ks = 0; ks < c.nslice; ++ks) {
+        __syncthreads();   // the previous phase has finished reading image 0
+        stage_any(c.img0, kWideSlice + 4, L.W1, c.D2, hp, 5, 0, false, REV ? c.D2 - kWideSlice * (ks + 1) : kWideSlice * ks, REV);
+        if (ks == 0)
+            for (int i = threadIdx.x; i < hp; i += kMfmaBlock) c.vec0[i] = L.b1[i];
+        f32x4 src[8];
+#pragma unroll
+        for (int ms = 0; ms < 8; ++ms) src[ms] = tile_ld(xsrc, 8 * ks + ms);
+        __syncthreads();
+        const float* img = c.img0;
+        const float* vec = c.vec0;
+        const int col = c.col, q = c.q;
+        const bool first = ks == 0, last = ks + 1 == c.nslice;
+        gemm_phase<8, TH>([&](int mo) { return img + (16 * mo + col) * (kWideSlice + 4) + 4 * q; },
+                          [&](int mo) {
+                              if (first) h1[mo] = vec_tile(vec, mo, q);
+                          },
+                          [&](int mo) -> f32x4& { return h1[mo]; }, [&](int) -> const f32x4(&)[8] { return src; },
+                          [&](int mo) {
+                              if (last) h1[mo] = tanh4(h1[mo]);
+                          });
+    }
+    if constexpr (NHL > 1) {
+        __syncthreads();
+        stage_any(c.img0, hp + 4, L.Wh, hp, hp, log2i(hp / 4), 0, false, 0, false);
+        for (int i = threadIdx.x; i < hp; i += kMfmaBlock) c.vec0[i] = L.bh[i];
+        __syncthreads();
+        const float* img = c.img0;
+        const float* vec = c.vec0;
+        const int col = c.col, q = c.q;
+        gemm_phase<TH, TH>([&](int mo) { return img + (16 * mo + col) * (hp + 4) + 4 * q; },
+                           [&](int mo) { h2[mo] = vec_tile(vec, mo, q); }, [&](int mo) -> f32x4& { return h2[mo]; },
+                           [&](int) -> const f32x4(&)[TH] { return h1; }, [&](int mo) { h2[mo] = tanh4(h2[mo]); });
+    }
+}
+
+// the alpha and beta rows (and biases) of target group gq -> image 0 rows [0, 64) and [64, 128), vec0[0, 128)
+template <int TH>
+__device__ __forceinline__ void wide_stage_w3(const WideCtx& c, const MLayer& L, bool REV, int gq) {
+    constexpr int hp = 16 * TH;
+    const int r0 = REV ? c.D2 - 64 * (gq + 1) : 64 * gq;   // a reversed layer's target position p is output row D2 - 1 - p
+    stage_any(c.img0, hp + 4, L.W3, hp, 64, log2i(hp / 4), r0, REV, 0, false);
+    stage_any(c.img0 + 64 * (hp + 4), hp + 4, L.W3, hp, 64, log2i(hp / 4), c.D2 + r0, REV, 0, false);
+    for (int i = threadIdx.x; i < 128; i += kMfmaBlock) {
+        const int r = i & 63, blk = i >> 6;
+        c.vec0[i] = L.b3[blk * c.D2 + r0 + (REV ? 63 - r : r)];
+    }
+}
+
+// ---- one coupling layer, inverse direction, on the streamed state: v_b = (y_b - beta) / alpha.  Returns this lane's share
+// of logdet_inverse.
+template <int TH, int NHL>
+__device__ __forceinline__ float wide_coupling_inverse(const WideCtx& c, const MLayer& L, bool REV) {
+    constexpr int hp = 16 * TH;
+    f32x4 h1[TH], h2[TH];
+    wide_hidden<TH, NHL>(c, L, REV, h1, h2);
+    const f32x4(&hl)[TH] = NHL > 1 ? h2 : h1;
+    float* xt = c.xs + 16 * (REV ? 0 : c.D2 / 16);
+    float ld = 0.f;
+    for (int gq = 0; gq < c.ngroup; ++gq) {
+        __syncthreads();
+        wide_stage_w3<TH>(c, L, REV, gq);
+        __syncthreads();
+        const float* img = c.img0;
+        const float* vec = c.vec0;
+        const int col = c.col, q = c.q;
+        const float mscale = c.mscale, log1m = c.log1m;
+        f32x4 ua2[2], ub2[2], y2[2];
+        gemm_phase<TH, 8>(
+            [&](int i) { return img + (16 * ((i & 1) * 4 + (i >> 1)) + col) * (hp + 4) + 4 * q; },
+            [&](int i) {
+                ((i & 1) ? ub2 : ua2)[(i >> 1) & 1] = vec_tile(vec, (i & 1) * 4 + (i >> 1), q);
+                if ((i & 1) == 0) y2[(i >> 1) & 1] = tile_ld(xt, 4 * gq + (i >> 1));   // arrives under the two steps' MFMAs
+            },
+            [&](int i) -> f32x4& { return ((i & 1) ? ub2 : ua2)[(i >> 1) & 1]; },
+            [&](int) -> const f32x4(&)[TH] { return hl; },
+            [&](int i) {
+                if ((i & 1) == 0) return;
+                const int mt = i >> 1;
+                const f32x4 ua = ua2[mt & 1], ub = ub2[mt & 1];
+                f32x4 v = y2[mt & 1];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float alpha = fast_exp(fmaf(0.5f, ua[t], log1m)) + mscale;
+                    v[t] = (v[t] - 0.5f * ub[t]) * __builtin_amdgcn_rcpf(alpha);
+                    ld -= fast_ln(alpha);
+                }
+                tile_st(xt, 4 * gq + mt, v);
+            });
+    }
+    return ld;
+}
+
+// ---- reverse sweep through one inverse coupling layer on the streamed state and gradient (the arithmetic of
+// coupling_inverse_backward_c in neutra_mfma.hip, without checkpoints): per target tile the W3 product, the elementwise
+// backward of the affine map (state tile restored, gradient tile rescaled, du / dv) and the W3^T product into dL/dh are
+// done back to back; then W_h^T, tanh' and W1^T into the source half of the gradient.
+template <int TH, int NHL>
+__device__ __forceinline__ void wide_coupling_backward(const WideCtx& c, const MLayer& L, bool REV) {
+    constexpr int hp = 16 * TH;
+    f32x4 h1[TH], h2[TH];
+    wide_hidden<TH, NHL>(c, L, REV, h1, h2);
+    f32x4(&hl)[TH] = NHL > 1 ? h2 : h1;
+    float* xt = c.xs + 16 * (REV ? 0 : c.D2 / 16);
+    float* gt = c.gs + 16 * (REV ? 0 : c.D2 / 16);
+    f32x4 dh[TH];
+#pragma unroll
+    for (int mo = 0; mo < TH; ++mo)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) dh[mo][t] = 0.f;
+    const int col = c.col, q = c.q;
+    const float mscale = c.mscale, log1m = c.log1m;
+    for (int gq = 0; gq < c.ngroup; ++gq) {
+        __syncthreads();
+        wide_stage_w3<TH>(c, L, REV, gq);
+        // W3^T of the same four target tiles -> image 1, a tile's 16 alpha columns next to its 16 beta columns
+        for (int mt = 0; mt < 4; ++mt) {
+            const int p0 = 64 * gq + 16 * mt;                      // target position of the tile's first coordinate
+            const int c0 = REV ? c.D2 - p0 - 16 : p0;              // a reversed layer's position p is column D2 - 1 - p
+            stage_any(c.img1 + 32 * mt, kWideSlice + 4, L.W3T, 2 * c.D2, hp, 2, 0, false, c0, REV);
+            stage_any(c.img1 + 32 * mt + 16, kWideSlice + 4, L.W3T, 2 * c.D2, hp, 2, 0, false, c.D2 + c0, REV);
+        }
+        __syncthreads();
+        const float* img = c.img0;
+        const float* imgT = c.img1;
+        const float* vec = c.vec0;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            f32x4 uab[2];
+            const f32x4 y = tile_ld(xt, 4 * gq + mt), gy = tile_ld(gt, 4 * gq + mt);
+            gemm_phase<TH, 2>([&](int i) { return img + (16 * (i * 4 + mt) + col) * (hp + 4) + 4 * q; },
+                              [&](int i) { uab[i] = vec_tile(vec, i * 4 + mt, q); }, [&](int i) -> f32x4& { return uab[i]; },
+                              [&](int) -> const f32x4(&)[TH] { return hl; }, [&](int) {});
+            f32x4 duv[2], xn, gn;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float alpha = fast_exp(fmaf(0.5f, uab[0][t], log1m)) + mscale;
+                const float beta = 0.5f * uab[1][t];
+                const float ra = __builtin_amdgcn_rcpf(alpha);
+                const float gv = gy[t] * ra;
+                const float d_alpha = fmaf(-gv, y[t], ra);
+                duv[0][t] = 0.5f * d_alpha * (alpha - mscale);
+                duv[1][t] = -0.5f * gv;
+                gn[t] = gv;
+                xn[t] = fmaf(alpha, y[t], beta);
+            }
+            tile_st(xt, 4 * gq + mt, xn);
+            tile_st(gt, 4 * gq + mt, gn);
+            gemm_phase<2, TH>([&](int mo) { return imgT + (16 * mo + col) * (kWideSlice + 4) + 4 * q + 32 * mt; }, [&](int) {},
+                              [&](int mo) -> f32x4& { return dh[mo]; }, [&](int) -> const f32x4(&)[2] { return duv; }, [&](int) {});
+        }
+    }
+#pragma unroll
+    for (int mo = 0; mo < TH; ++mo)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) dh[mo][t] *= (1.f - hl[mo][t] * hl[mo][t]);
+    if constexpr (NHL > 1) {
+        __syncthreads();
+        stage_any(c.img0, hp + 4, L.WhT, hp, hp, log2i(hp / 4), 0, false, 0, false);
+        __syncthreads();
+        const float* img = c.img0;
+        gemm_phase<TH, TH>([&](int mo) { return img + (16 * mo + col) * (hp + 4) + 4 * q; },
+                           [&](int mo) {
+#pragma unroll
+                               for (int t = 0; t < 4; ++t) hl[mo][t] = 0.f;
+                           },
+                           [&](int mo) -> f32x4& { return hl[mo]; }, [&](int) -> const f32x4(&)[TH] { return dh; }, [&](int) {});
+#pragma unroll
+        for (int mo = 0; mo < TH; ++mo)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) dh[mo][t] = hl[mo][t] * (1.f - h1[mo][t] * h1[mo][t]);
+    }
+    float* gsrc = c.gs + 16 * (REV ? c.D2 / 16 : 0);
+    for (int ks = 0; ks < c.nslice; ++ks) {
+        __syncthreads();
+        stage_any(c.img0, hp + 4, L.W1T, hp, kWideSlice, log2i(hp / 4), REV ? c.D2 - kWideSlice * (ks + 1) : kWideSlice * ks, REV, 0, false);
+        __syncthreads();
+        const float* img = c.img0;
+        f32x4 acc2[2];
+        gemm_phase<TH, 8>([&](int ms) { return img + (16 * ms + col) * (hp + 4) + 4 * q; },
+                          [&](int ms) { acc2[ms & 1] = tile_ld(gsrc, 8 * ks + ms); }, [&](int ms) -> f32x4& { return acc2[ms & 1]; },
+                          [&](int) -> const f32x4(&)[TH] { return dh; }, [&](int ms) { tile_st(gsrc, 8 * ks + ms, acc2[ms & 1]); });
+    }
+}
+
+// one ElementwiseAffine layer on every tile: inverse (x - shift) exp(-ls) [returns sum of -ls], or the reverse sweep's
+// forward x exp(ls) + shift with the gradient scaled by exp(-ls)
+template <bool BACKWARD>
+__device__ __forceinline__ float wide_ea(const WideCtx& c, const float* __restrict__ g_ls, const float* __restrict__ g_sh, bool rev) {
+    float ld = 0.f;
+    for (int m = 0; m < c.d / 16; ++m) {
+        const f32x4 ls = rev ? vec_tile_rev(g_ls, m, c.q, c.d) : vec_tile(g_ls, m, c.q);
+        const f32x4 sh = rev ? vec_tile_rev(g_sh, m, c.q, c.d) : vec_tile(g_sh, m, c.q);
+        f32x4 x = tile_ld(c.xs, m);
+        if constexpr (BACKWARD) {
+            f32x4 g = tile_ld(c.gs, m);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                g[t] *= fast_exp(-ls[t]);
+                x[t] = fmaf(fast_exp(ls[t]), x[t], sh[t]);
+            }
+            tile_st(c.gs, m, g);
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                x[t] = (x[t] - sh[t]) * fast_exp(-ls[t]);
+                ld -= ls[t];
+            }
+        }
+        tile_st(c.xs, m, x);
+    }
+    return ld;
+}
+
+// closed-form potential and its gradient on the streamed state (potential_value_grad_c's arithmetic, tile by tile)
+__device__ __forceinline__ float wide_potential_grad(const WideCtx& c, const NfmcPotential& p, int lane) {
+    const int TD = c.d / 16;
+    if (p.kind == NFMC_POT_FUNNEL) {
+        const f32x4 t0 = tile_ld(c.xs, 0);
+        const float x0 = __shfl(t0[0], lane & 15, kWave);   // coordinate 0 = tile 0, register 0, lane group 0
+        float s = 0.f;
+        for (int m = 0; m < TD; ++m) {
+            const f32x4 x = tile_ld(c.xs, m);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) s = fmaf(x[t], (m == 0 && t == 0 && c.q == 0) ? 0.f : x[t], s);
+        }
+        s = chain_sum(s);
+        const float inv_s2 = 1.f / (p.a_scalar * p.a_scalar);
+        const float e = fast_exp(-x0);
+        const float hd = 0.5f * (float)(c.d - 1);
+        for (int m = 0; m < TD; ++m) {
+            const f32x4 x = tile_ld(c.xs, m);
+            f32x4 g;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) g[t] = x[t] * e;
+            if (m == 0 && c.q == 0) g[0] = x0 * inv_s2 - 0.5f * e * s + hd;
+            tile_st(c.gs, m, g);
+        }
+        return 0.5f * x0 * x0 * inv_s2 + 0.5f * e * s + hd * x0;
+    }
+    float u = 0.f;
+    for (int m = 0; m < TD; ++m) {
+        f32x4 a, b;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            a[t] = p.a_scalar;
+            b[t] = p.b_scalar;
+        }
+        if (p.a) a = vec_tile(p.a, m, c.q);
+        if (p.b) b = vec_tile(p.b, m, c.q);
+        const f32x4 x = tile_ld(c.xs, m);
+        f32x4 g;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float dlt = x[t] - b[t];
+            u = fmaf(a[t] * dlt, dlt, u);
+            g[t] = 2.f * a[t] * dlt;
+        }
+        tile_st(c.gs, m, g);
+    }
+    return chain_sum(u);
+}
+
+// slab: (tiles * 128) private rows of d floats for the state, then as many for the gradient (rows past n belong to the
+// idle lanes of the last tile: they run on a copy of row n - 1 and are never read)
+template <int TH, int NHL>
+__global__ void __launch_bounds__(kMfmaBlock, 2) neutra_grad_wide_kernel(NfmcRealNVP f, NfmcPotential pot, const float* __restrict__ z,
+                                                                      int64_t n, float* __restrict__ u_out, float* __restrict__ grad_out,
+                                                                      float* __restrict__ slab, int64_t tiles) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int hp = 16 * TH;
+    const int d = f.d;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool rev_last = (f.n_coupling & 1) != 0;
+    WideCtx c;
+    c.img0 = lds;
+    c.img1 = lds + kImgFloats;
+    c.vec0 = lds + 2 * kImgFloats;
+    c.d = d, c.D2 = d / 2, c.nslice = (d / 2) / kWideSlice, c.ngroup = (d / 2) / 64;
+    c.col = lane & 15, c.q = lane >> 4;
+    c.mscale = f.min_scale;
+    c.log1m = __logf(1.f - f.min_scale);
+    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int64_t row = tile * kMfmaChains + wave * 16 + c.col;
+        const bool active = row < n;
+        const float* zr = z + (active ? row : n - 1) * d;
+        c.xs = slab + row * d + 4 * c.q;
+        c.gs = slab + (tiles * kMfmaChains + row) * d + 4 * c.q;
+        // z at tile positions in latent order (flows with an odd number of reversals: position p holds logical d - 1 - p)
+        for (int m = 0; m < d / 16; ++m) tile_st(c.xs, m, rev_last ? vec_tile_rev(zr, m, c.q, d) : vec_tile(zr, m, c.q));
+        float ldp = wide_ea<false>(c, f.ea1_log_scale, f.ea1_shift, rev_last);
+        for (int l = f.n_coupling - 1; l >= 0; --l)
+            ldp += wide_coupling_inverse<TH, NHL>(c, mfma_layer(f.weights + l * f.layer_stride, d, hp, NHL), (l & 1) == 0);
+        ldp += wide_ea<false>(c, f.ea0_log_scale, f.ea0_shift, false);
+        const float u = wide_potential_grad(c, pot, lane);
+        wide_ea<true>(c, f.ea0_log_scale, f.ea0_shift, false);
+        for (int l = 0; l < f.n_coupling; ++l)
+            wide_coupling_backward<TH, NHL>(c, mfma_layer(f.weights + l * f.layer_stride, d, hp, NHL), (l & 1) == 0);
+        wide_ea<true>(c, f.ea1_log_scale, f.ea1_shift, rev_last);
+        const float ut = u - chain_sum(ldp);
+        if (active) {
+            if (u_out && c.q == 0) u_out[row] = ut;
+            if (grad_out) {
+                float* gr = grad_out + row * d;
+                for (int m = 0; m < d / 16; ++m) {
+                    const f32x4 g = tile_ld(c.gs, m);
+                    const int p0 = 16 * m + 4 * c.q;
+                    if (!rev_last) *reinterpret_cast<f32x4*>(gr + p0) = g;
+                    else *reinterpret_cast<f32x4*>(gr + (d - 4 - p0)) = rev4(g);
+                }
+            }
+        }
+    }
+}
+
+}  // namespace nfmc
+
+using namespace nfmc;
+
+int nfmc::nfmc_mfma_wide_supported(int32_t d, int32_t n_hidden, int32_t n_hidden_layers) {
+    return (d == 256 || d == 512) && n_hidden > 32 && n_hidden <= 128 && n_hidden_layers >= 1 && n_hidden_layers <= 2;
+}
+
+int nfmc::nfmc_neutra_potential_grad_wide_f32(const NfmcRealNVP* flow, const NfmcPotential* pot, const float* z, int64_t n,
+                                                   float* u_out, float* grad_out, nfmc_stream_t stream) {
+    if (!flow || !pot || !z || n <= 0) return NFMC_EINVAL;
+    if (!nfmc_mfma_wide_supported(flow->d, flow->n_hidden, flow->n_hidden_layers)) return NFMC_EUNSUPPORTED;
+    if (pot->kind != NFMC_POT_QUADRATIC && pot->kind != NFMC_POT_FUNNEL) return NFMC_EUNSUPPORTED;
+    if ((((uintptr_t)z) & 15u) || (((uintptr_t)grad_out) & 15u)) return NFMC_EUNSUPPORTED;   // 16-byte tile IO
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t tiles = (n + kMfmaChains - 1) / kMfmaChains;
+    const int grid = (int)(tiles < kCkMaxGrid ? tiles : kCkMaxGrid);
+    const size_t slab_bytes = (size_t)2 * tiles * kMfmaChains * flow->d * sizeof(float);
+    float* slab = nullptr;
+    hipError_t e = hipMallocAsync((void**)&slab, slab_bytes, st);   // stream-ordered: the entry point has no scratch argument
+    if (e != hipSuccess) return (int)e;
+    const int th = nfmc_realnvp_padded_hidden(flow->n_hidden) / 16, nhl = flow->n_hidden_layers;
+    int rc = NFMC_OK;
+#define NFMC_WIDE(THV, NHLV)                                                                                                    \
+    if (th == THV && nhl == NHLV) {                                                                                             \
+        auto kern = neutra_grad_wide_kernel<THV, NHLV>;                                                                         \
+        e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWideLdsBytes);             \
+        if (e != hipSuccess) rc = (int)e;                                                                                       \
+        else hipLaunchKernelGGL(kern, dim3(grid), dim3(kMfmaBlock), kWideLdsBytes, st, *flow, *pot, z, n, u_out, grad_out, slab, tiles); \
+    }
+    NFMC_WIDE(4, 1) else NFMC_WIDE(4, 2) else NFMC_WIDE(8, 1) else NFMC_WIDE(8, 2) else rc = NFMC_EUNSUPPORTED;
+#undef NFMC_WIDE
+    if (rc == NFMC_OK) {
+        e = hipGetLastError();
+        if (e != hipSuccess) rc = (int)e;
+    }
+    e = hipFreeAsync(slab, st);
+    if (rc == NFMC_OK && e != hipSuccess) rc = (int)e;
+    return rc;
+}

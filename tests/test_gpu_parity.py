@@ -980,6 +980,45 @@ def test_neutra_mfma_potential_and_gradient_match_autograd(dev, d, nl, nh, cl, p
     np.testing.assert_allclose(g.cpu().numpy(), g_ref.numpy(), atol=3e-4 * (1 + float(g_ref.abs().max())), rtol=0)
 
 
+@pytest.mark.parametrize('d,nl,nh,cl,pot', [(256, 2, 128, 2, 'funnel'), (256, 3, 64, 1, 'sumsq'), (256, 1, 100, 2, 'sumsq'),
+                                             (512, 2, 128, 2, 'sumsq'), (512, 3, 40, 1, 'funnel'), (512, 2, 64, 2, 'funnel')])
+def test_neutra_wide_event_mfma_potential_and_gradient_match_autograd(dev, d, nl, nh, cl, pot):
+    """Round 3: d = 256 / 512 with conditioners of width 33..128 on the matrix cores with the state and gradient STREAMED
+    through a scratch slab (csrc/neutra_mfma_wide.hip; the register-resident kernels stop at d = 128, these shapes used to
+    fall back to torch autograd through the restatement).  Odd and even numbers of coupling layers (latent order reversed
+    or not), one and two hidden layers, padded widths, a batch that is not a multiple of the 128-chain workgroup tile."""
+    from nfmc_amd import hip
+    from nfmc_amd.flows import Flow, RealNVP
+    from nfmc_amd.potentials import SumOfSquares, Funnel
+    from oracle import flow as oflow, potentials as opot, samplers as osamp
+    ck = {'n_layers': cl, 'n_hidden': nh}
+    torch.manual_seed(d + nl + nh)
+    of = oflow.perturb_(oflow.Flow(oflow.RealNVP((d,), n_layers=nl, conditioner_kwargs=ck)), 3, 0.1, 0.8)
+    f = Flow(RealNVP((d,), n_layers=nl, conditioner_kwargs=ck))
+    f.load_state_dict(of.state_dict())
+    target_cpu = opot.sum_squares if pot == 'sumsq' else opot.funnel(3.0)
+    target = SumOfSquares((d,)) if pot == 'sumsq' else Funnel((d,), 3.0)
+    n = 300
+    z = (0.6 * torch.randn(n, d)).requires_grad_(True)
+    u_ref = osamp.neutra_adjusted_target(of, target_cpu, (d,))(z)
+    g_ref, = torch.autograd.grad(u_ref.sum(), z)
+    st, _keep = f.bijection.packed(dev)
+    pd = target.descriptor(dev)
+    zd = z.detach().to(dev).contiguous()
+    u = torch.full((n,), float('nan'), device=dev)
+    g = torch.full((n, d), float('nan'), device=dev)
+    hip.check(hip.lib().nfmc_neutra_potential_grad_f32(C.byref(st), C.byref(pd), hip.ptr(zd), n, hip.ptr(u), hip.ptr(g),
+                                                       hip.stream()), 'neutra_potential_grad')
+    np.testing.assert_allclose(u.cpu().numpy(), u_ref.detach().numpy(), atol=3e-4 * (1 + float(u_ref.detach().abs().max())), rtol=0)
+    np.testing.assert_allclose(g.cpu().numpy(), g_ref.numpy(), atol=3e-4 * (1 + float(g_ref.abs().max())), rtol=0)
+    # twice the same: nothing depends on what the slab held
+    u2 = torch.empty_like(u)
+    g2 = torch.empty_like(g)
+    hip.check(hip.lib().nfmc_neutra_potential_grad_f32(C.byref(st), C.byref(pd), hip.ptr(zd), n, hip.ptr(u2), hip.ptr(g2),
+                                                       hip.stream()), 'neutra_potential_grad')
+    assert torch.equal(u, u2) and torch.equal(g, g2)
+
+
 @pytest.mark.parametrize('d,nh,cl,nl', [(64, 64, 1, 2), (128, 128, 2, 2), (64, 128, 2, 3)])
 def test_neutra_hmc_mfma_native_stream_matches_oracle(dev, d, nh, cl, nl):
     from nfmc_amd.samplers import neutra, mcmc
