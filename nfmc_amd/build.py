@@ -31,7 +31,7 @@ FLAGS = ['-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC', '-fno-gpu-rdc', 
 # into independent 128-bit values instead.
 UNIT_FLAGS = {'neutra_mfma.hip': ['-mllvm', '-amdgpu-promote-alloca-to-vector-limit=16'],
               'flow_mfma.hip': ['-mllvm', '-amdgpu-promote-alloca-to-vector-limit=16'],
-              'neutra_mfma_wide.hip': ['-mllvm', '-amdgpu-promote-alloca-to-vector-limit=16']}
+              'mfma_wide.hip': ['-mllvm', '-amdgpu-promote-alloca-to-vector-limit=16']}
 
 
 def sources():

@@ -258,6 +258,12 @@ static bool use_mfma_flow(const NfmcRealNVP* f) {
            !getenv("NFMC_FLOW_NO_MFMA");
 }
 
+// d = 256 / 512 with a wide conditioner: the streamed matrix-core kernels (mfma_wide.hip)
+static bool use_mfma_wide(const NfmcRealNVP* f) {
+    return f->n_bins == 0 && f->n_coupling > 0 && nfmc_mfma_wide_supported(f->d, f->n_hidden, f->n_hidden_layers) &&
+           !getenv("NFMC_FLOW_NO_MFMA");
+}
+
 static bool al16(const void* p) { return ((uintptr_t)p & 15u) == 0; }   // NULL counts as aligned
 
 static int hp_bucket(int h) { return h <= 4 ? 4 : (h <= 8 ? 8 : (h <= 16 ? 16 : 32)); }
@@ -320,6 +326,7 @@ extern "C" int nfmc_realnvp_forward_f32(const NfmcRealNVP* flow, const float* x,
     if (rc) return rc;
     if (!x || n <= 0) return NFMC_EINVAL;
     if (use_mfma_flow(flow) && al16(x) && al16(z)) return nfmc_realnvp_forward_mfma_f32(flow, x, n, z, logdet, log_prob, stream);
+    if (use_mfma_wide(flow) && al16(x) && al16(z)) return nfmc_realnvp_forward_wide_f32(flow, x, n, z, logdet, log_prob, stream);
     const int64_t tiles = (n + 63) / 64;
     const int grid = (int)(tiles < 4 * kMaxGrid ? tiles : 4 * kMaxGrid);
     const size_t lds = (size_t)64 * tile_stride(flow->d) * sizeof(float) + hbuf_bytes(flow->n_hidden);
@@ -343,6 +350,7 @@ extern "C" int nfmc_realnvp_inverse_f32(const NfmcRealNVP* flow, const float* z,
     if (int rr = rng_default_only(r)) return rr;
     r.replay_normals = nullptr;  // explicit latents come through `z`
     if (use_mfma_flow(flow) && al16(x) && al16(z)) return nfmc_realnvp_inverse_mfma_f32(flow, z, n, x, logdet, log_q, &r, stream);
+    if (use_mfma_wide(flow) && al16(x) && al16(z)) return nfmc_realnvp_inverse_wide_f32(flow, z, n, x, logdet, log_q, &r, stream);
     const int64_t tiles = (n + 63) / 64;
     const int grid = (int)(tiles < 4 * kMaxGrid ? tiles : 4 * kMaxGrid);
     const size_t lds = (size_t)64 * tile_stride(flow->d) * sizeof(float) + hbuf_bytes(flow->n_hidden);

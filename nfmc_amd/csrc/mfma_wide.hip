@@ -1,6 +1,8 @@
-// K5 on the matrix cores for WIDE EVENTS: the adjusted potential U~(z) = U(f^-1(z)) - logdet_inv(z) and its gradient for
-// RealNVP conditioners of width 33..128 at d = 256 and d = 512 (neutra.py:58-68 has no shape limit; the register-resident
-// kernels of neutra_mfma.hip hold the state and gradient tiles of a chain in VGPRs and stop at d = 128).
+// The matrix-core path for WIDE EVENTS, d = 256 and d = 512 with RealNVP conditioners of width 33..128:
+//   K3 / K4   bijection.forward / inverse, Flow.log_prob / sample             (jump.py:205,218; imh.py:214,221)
+//   K5        the adjusted potential U~(z) = U(f^-1(z)) - logdet_inv(z) and its gradient   (neutra.py:58-68)
+// The reference has no shape limit at these call sites; the register-resident kernels of flow_mfma.hip / neutra_mfma.hip
+// hold the state (and gradient) tiles of a chain in VGPRs and stop at d = 128.
 //
 // Same GEMM scheme as mfma_device.hpp (v_mfma_f32_16x16x4_f32, weights = A from an LDS image, 16 chains of a wave = N,
 // every per-chain vector in the C layout), but the state x and the gradient g of the wave's chains are STREAMED: they live
@@ -60,6 +62,37 @@ struct WideCtx {
 __device__ __forceinline__ f32x4 tile_ld(const float* p, int m) { return *reinterpret_cast<const f32x4*>(p + 16 * m); }
 __device__ __forceinline__ void tile_st(float* p, int m, const f32x4 v) { *reinterpret_cast<f32x4*>(p + 16 * m) = v; }
 
+__device__ __forceinline__ void wide_ctx_init(WideCtx& c, float* lds, const NfmcRealNVP& f, int lane) {
+    c.img0 = lds;
+    c.img1 = lds + kImgFloats;
+    c.vec0 = lds + 2 * kImgFloats;
+    c.d = f.d, c.D2 = f.d / 2, c.nslice = (f.d / 2) / kWideSlice, c.ngroup = (f.d / 2) / 64;
+    c.col = lane & 15, c.q = lane >> 4;
+    c.mscale = f.min_scale;
+    c.log1m = __logf(1.f - f.min_scale);
+    c.gs = nullptr;
+}
+
+__device__ __forceinline__ float wide_sum_squares(const WideCtx& c) {
+    float ss = 0.f;
+    for (int m = 0; m < c.d / 16; ++m) {
+        const f32x4 v = tile_ld(c.xs, m);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) ss = fmaf(v[t], v[t], ss);
+    }
+    return chain_sum(ss);
+}
+
+// slab row -> (n, d) array; `rev`: the array is in LOGICAL latent order and tile position p holds logical d - 1 - p
+__device__ __forceinline__ void wide_store_row(const float* src, float* __restrict__ dst_row, int d, int q, bool rev) {
+    for (int m = 0; m < d / 16; ++m) {
+        const f32x4 v = tile_ld(src, m);
+        const int p0 = 16 * m + 4 * q;
+        if (!rev) *reinterpret_cast<f32x4*>(dst_row + p0) = v;
+        else *reinterpret_cast<f32x4*>(dst_row + (d - 4 - p0)) = rev4(v);
+    }
+}
+
 // h1 = tanh(W1 x_src + b1), hl = the last hidden layer's activations (h1 itself with one hidden layer)
 template <int TH, int NHL>
 __device__ __forceinline__ void wide_hidden(const WideCtx& c, const MLayer& L, bool REV, f32x4 (&h1)[TH], f32x4 (&h2)[TH]) {
@@ -114,10 +147,10 @@ __device__ __forceinline__ void wide_stage_w3(const WideCtx& c, const MLayer& L,
     }
 }
 
-// ---- one coupling layer, inverse direction, on the streamed state: v_b = (y_b - beta) / alpha.  Returns this lane's share
-// of logdet_inverse.
-template <int TH, int NHL>
-__device__ __forceinline__ float wide_coupling_inverse(const WideCtx& c, const MLayer& L, bool REV) {
+// ---- one coupling layer on the streamed state.  INVERSE: v_b = (y_b - beta) / alpha, else z_b = alpha x_b + beta.
+// Returns this lane's share of the layer's logdet in THAT direction.
+template <int TH, int NHL, bool INVERSE>
+__device__ __forceinline__ float wide_coupling(const WideCtx& c, const MLayer& L, bool REV) {
     constexpr int hp = 16 * TH;
     f32x4 h1[TH], h2[TH];
     wide_hidden<TH, NHL>(c, L, REV, h1, h2);
@@ -149,8 +182,13 @@ __device__ __forceinline__ float wide_coupling_inverse(const WideCtx& c, const M
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const float alpha = fast_exp(fmaf(0.5f, ua[t], log1m)) + mscale;
-                    v[t] = (v[t] - 0.5f * ub[t]) * __builtin_amdgcn_rcpf(alpha);
-                    ld -= fast_ln(alpha);
+                    if constexpr (INVERSE) {
+                        v[t] = (v[t] - 0.5f * ub[t]) * __builtin_amdgcn_rcpf(alpha);
+                        ld -= fast_ln(alpha);
+                    } else {
+                        v[t] = fmaf(alpha, v[t], 0.5f * ub[t]);
+                        ld += fast_ln(alpha);
+                    }
                 }
                 tile_st(xt, 4 * gq + mt, v);
             });
@@ -250,10 +288,12 @@ __device__ __forceinline__ void wide_coupling_backward(const WideCtx& c, const M
     }
 }
 
-// one ElementwiseAffine layer on every tile: inverse (x - shift) exp(-ls) [returns sum of -ls], or the reverse sweep's
-// forward x exp(ls) + shift with the gradient scaled by exp(-ls)
-template <bool BACKWARD>
+// one ElementwiseAffine layer on every tile: inverse (x - shift) exp(-ls) [returns the sum of -ls], forward
+// x exp(ls) + shift [the sum of ls], or the reverse sweep's forward with the gradient scaled by exp(-ls)
+enum { kEaInverse = 0, kEaBackward = 1, kEaForward = 2 };
+template <int MODE>
 __device__ __forceinline__ float wide_ea(const WideCtx& c, const float* __restrict__ g_ls, const float* __restrict__ g_sh, bool rev) {
+    constexpr bool BACKWARD = MODE == kEaBackward;
     float ld = 0.f;
     for (int m = 0; m < c.d / 16; ++m) {
         const f32x4 ls = rev ? vec_tile_rev(g_ls, m, c.q, c.d) : vec_tile(g_ls, m, c.q);
@@ -267,6 +307,12 @@ __device__ __forceinline__ float wide_ea(const WideCtx& c, const float* __restri
                 x[t] = fmaf(fast_exp(ls[t]), x[t], sh[t]);
             }
             tile_st(c.gs, m, g);
+        } else if constexpr (MODE == kEaForward) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                x[t] = fmaf(fast_exp(ls[t]), x[t], sh[t]);
+                ld += ls[t];
+            }
         } else {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -340,13 +386,7 @@ __global__ void __launch_bounds__(kMfmaBlock, 2) neutra_grad_wide_kernel(NfmcRea
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool rev_last = (f.n_coupling & 1) != 0;
     WideCtx c;
-    c.img0 = lds;
-    c.img1 = lds + kImgFloats;
-    c.vec0 = lds + 2 * kImgFloats;
-    c.d = d, c.D2 = d / 2, c.nslice = (d / 2) / kWideSlice, c.ngroup = (d / 2) / 64;
-    c.col = lane & 15, c.q = lane >> 4;
-    c.mscale = f.min_scale;
-    c.log1m = __logf(1.f - f.min_scale);
+    wide_ctx_init(c, lds, f, lane);
     for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         const int64_t row = tile * kMfmaChains + wave * 16 + c.col;
         const bool active = row < n;
@@ -355,27 +395,104 @@ __global__ void __launch_bounds__(kMfmaBlock, 2) neutra_grad_wide_kernel(NfmcRea
         c.gs = slab + (tiles * kMfmaChains + row) * d + 4 * c.q;
         // z at tile positions in latent order (flows with an odd number of reversals: position p holds logical d - 1 - p)
         for (int m = 0; m < d / 16; ++m) tile_st(c.xs, m, rev_last ? vec_tile_rev(zr, m, c.q, d) : vec_tile(zr, m, c.q));
-        float ldp = wide_ea<false>(c, f.ea1_log_scale, f.ea1_shift, rev_last);
+        float ldp = wide_ea<kEaInverse>(c, f.ea1_log_scale, f.ea1_shift, rev_last);
         for (int l = f.n_coupling - 1; l >= 0; --l)
-            ldp += wide_coupling_inverse<TH, NHL>(c, mfma_layer(f.weights + l * f.layer_stride, d, hp, NHL), (l & 1) == 0);
-        ldp += wide_ea<false>(c, f.ea0_log_scale, f.ea0_shift, false);
+            ldp += wide_coupling<TH, NHL, true>(c, mfma_layer(f.weights + l * f.layer_stride, d, hp, NHL), (l & 1) == 0);
+        ldp += wide_ea<kEaInverse>(c, f.ea0_log_scale, f.ea0_shift, false);
         const float u = wide_potential_grad(c, pot, lane);
-        wide_ea<true>(c, f.ea0_log_scale, f.ea0_shift, false);
+        wide_ea<kEaBackward>(c, f.ea0_log_scale, f.ea0_shift, false);
         for (int l = 0; l < f.n_coupling; ++l)
             wide_coupling_backward<TH, NHL>(c, mfma_layer(f.weights + l * f.layer_stride, d, hp, NHL), (l & 1) == 0);
-        wide_ea<true>(c, f.ea1_log_scale, f.ea1_shift, rev_last);
+        wide_ea<kEaBackward>(c, f.ea1_log_scale, f.ea1_shift, rev_last);
         const float ut = u - chain_sum(ldp);
         if (active) {
             if (u_out && c.q == 0) u_out[row] = ut;
-            if (grad_out) {
-                float* gr = grad_out + row * d;
-                for (int m = 0; m < d / 16; ++m) {
-                    const f32x4 g = tile_ld(c.gs, m);
-                    const int p0 = 16 * m + 4 * c.q;
-                    if (!rev_last) *reinterpret_cast<f32x4*>(gr + p0) = g;
-                    else *reinterpret_cast<f32x4*>(gr + (d - 4 - p0)) = rev4(g);
-                }
+            if (grad_out) wide_store_row(c.gs, grad_out + row * d, d, c.q, rev_last);
+        }
+    }
+}
+
+// x -> z, logdet_forward, log_prob (realnvp_forward_mfma_kernel's contract); slab: tiles * 128 private rows of d floats
+template <int TH, int NHL>
+__global__ void __launch_bounds__(kMfmaBlock, 2) realnvp_forward_wide_kernel(NfmcRealNVP f, const float* __restrict__ x, int64_t n,
+                                                                          float* __restrict__ z, float* __restrict__ logdet,
+                                                                          float* __restrict__ log_prob, float* __restrict__ slab,
+                                                                          int64_t tiles) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int hp = 16 * TH;
+    const int d = f.d;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool rev_last = (f.n_coupling & 1) != 0;
+    WideCtx c;
+    wide_ctx_init(c, lds, f, lane);
+    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int64_t row = tile * kMfmaChains + wave * 16 + c.col;
+        const bool active = row < n;
+        const float* xr = x + (active ? row : n - 1) * d;
+        c.xs = slab + row * d + 4 * c.q;
+        for (int m = 0; m < d / 16; ++m) tile_st(c.xs, m, vec_tile(xr, m, c.q));
+        float ldp = wide_ea<kEaForward>(c, f.ea0_log_scale, f.ea0_shift, false);
+        for (int l = 0; l < f.n_coupling; ++l)
+            ldp += wide_coupling<TH, NHL, false>(c, mfma_layer(f.weights + l * f.layer_stride, d, hp, NHL), (l & 1) == 0);
+        ldp += wide_ea<kEaForward>(c, f.ea1_log_scale, f.ea1_shift, rev_last);
+        const float ld = chain_sum(ldp);
+        const float ss = wide_sum_squares(c);
+        if (active) {
+            if (c.q == 0) {
+                if (logdet) logdet[row] = ld;
+                if (log_prob) log_prob[row] = -0.5f * ss - 0.5f * (float)d * kLog2Pi + ld;
             }
+            if (z) wide_store_row(c.xs, z + row * d, d, c.q, rev_last);
+        }
+    }
+}
+
+// z (given, or drawn from the chain's latent stream) -> x, logdet_inverse, log q(x) (realnvp_inverse_mfma_kernel's contract)
+template <int TH, int NHL>
+__global__ void __launch_bounds__(kMfmaBlock, 2) realnvp_inverse_wide_kernel(NfmcRealNVP f, const float* __restrict__ z, int64_t n,
+                                                                          float* __restrict__ x, float* __restrict__ logdet,
+                                                                          float* __restrict__ log_q, NfmcRng rng, float* __restrict__ slab,
+                                                                          int64_t tiles) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int hp = 16 * TH;
+    const int d = f.d;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool rev_last = (f.n_coupling & 1) != 0;
+    WideCtx c;
+    wide_ctx_init(c, lds, f, lane);
+    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int64_t row = tile * kMfmaChains + wave * 16 + c.col;
+        const bool active = row < n;
+        const int64_t rrow = active ? row : n - 1;
+        c.xs = slab + row * d + 4 * c.q;
+        if (z) {
+            const float* zr = z + rrow * d;
+            for (int m = 0; m < d / 16; ++m) tile_st(c.xs, m, rev_last ? vec_tile_rev(zr, m, c.q, d) : vec_tile(zr, m, c.q));
+        } else {   // Philox stream kTagLatent, one block per 4 consecutive logical coordinates (draw_latent_c's rule)
+            const uint32_t gchain = (uint32_t)(rng.chain_offset + (uint64_t)rrow);
+            for (int m = 0; m < d / 16; ++m) {
+                const int p0 = 16 * m + 4 * c.q;
+                const int blk = rev_last ? (d - 4 - p0) >> 2 : p0 >> 2;
+                float w[4];
+                philox_normal4(gchain, rng.step0, (uint32_t)blk, kTagLatent, (uint32_t)rng.seed, (uint32_t)(rng.seed >> 32), w);
+                f32x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = rev_last ? w[3 - j] : w[j];
+                tile_st(c.xs, m, v);
+            }
+        }
+        const float ss = wide_sum_squares(c);
+        float ldp = wide_ea<kEaInverse>(c, f.ea1_log_scale, f.ea1_shift, rev_last);
+        for (int l = f.n_coupling - 1; l >= 0; --l)
+            ldp += wide_coupling<TH, NHL, true>(c, mfma_layer(f.weights + l * f.layer_stride, d, hp, NHL), (l & 1) == 0);
+        ldp += wide_ea<kEaInverse>(c, f.ea0_log_scale, f.ea0_shift, false);
+        const float ld = chain_sum(ldp);
+        if (active) {
+            if (c.q == 0) {
+                if (logdet) logdet[row] = ld;
+                if (log_q) log_q[row] = -0.5f * ss - 0.5f * (float)d * kLog2Pi - ld;
+            }
+            if (x) wide_store_row(c.xs, x + row * d, d, c.q, false);
         }
     }
 }
@@ -388,6 +505,63 @@ int nfmc::nfmc_mfma_wide_supported(int32_t d, int32_t n_hidden, int32_t n_hidden
     return (d == 256 || d == 512) && n_hidden > 32 && n_hidden <= 128 && n_hidden_layers >= 1 && n_hidden_layers <= 2;
 }
 
+// the scratch slab of one launch: stream-ordered allocation (the C entry points of these passes have no scratch argument)
+static int wide_slab(float** slab, int64_t tiles, int d, int copies, hipStream_t st) {
+    hipError_t e = hipMallocAsync((void**)slab, (size_t)copies * tiles * kMfmaChains * d * sizeof(float), st);
+    return e == hipSuccess ? NFMC_OK : (int)e;
+}
+
+#define NFMC_WIDE_DISPATCH(KERNEL, ...)                                                                                        \
+    {                                                                                                                           \
+        const int th = nfmc_realnvp_padded_hidden(flow->n_hidden) / 16, nhl = flow->n_hidden_layers;                            \
+        hipError_t e = hipSuccess;                                                                                              \
+        if (th == 4 && nhl == 1) NFMC_WIDE_LAUNCH(KERNEL, 4, 1, __VA_ARGS__)                                                    \
+        else if (th == 4 && nhl == 2) NFMC_WIDE_LAUNCH(KERNEL, 4, 2, __VA_ARGS__)                                               \
+        else if (th == 8 && nhl == 1) NFMC_WIDE_LAUNCH(KERNEL, 8, 1, __VA_ARGS__)                                               \
+        else if (th == 8 && nhl == 2) NFMC_WIDE_LAUNCH(KERNEL, 8, 2, __VA_ARGS__)                                               \
+        else rc = NFMC_EUNSUPPORTED;                                                                                            \
+        if (rc == NFMC_OK && e != hipSuccess) rc = (int)e;                                                                      \
+        if (rc == NFMC_OK && (e = hipGetLastError()) != hipSuccess) rc = (int)e;                                                \
+    }
+#define NFMC_WIDE_LAUNCH(KERNEL, THV, NHLV, ...)                                                                       \
+    {                                                                                                                   \
+        auto kern = KERNEL<THV, NHLV>;                                                                                  \
+        e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWideLdsBytes);     \
+        if (e == hipSuccess) hipLaunchKernelGGL(kern, dim3(grid), dim3(kMfmaBlock), kWideLdsBytes, st, __VA_ARGS__);    \
+    }
+
+int nfmc::nfmc_realnvp_forward_wide_f32(const NfmcRealNVP* flow, const float* x, int64_t n, float* z, float* logdet, float* log_prob,
+                                             nfmc_stream_t stream) {
+    if (!flow || !x || n <= 0) return NFMC_EINVAL;
+    if (!nfmc_mfma_wide_supported(flow->d, flow->n_hidden, flow->n_hidden_layers)) return NFMC_EUNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t tiles = (n + kMfmaChains - 1) / kMfmaChains;
+    const int grid = (int)(tiles < kCkMaxGrid ? tiles : kCkMaxGrid);
+    float* slab = nullptr;
+    int rc = wide_slab(&slab, tiles, flow->d, 1, st);
+    if (rc) return rc;
+    NFMC_WIDE_DISPATCH(realnvp_forward_wide_kernel, *flow, x, n, z, logdet, log_prob, slab, tiles)
+    const hipError_t fe = hipFreeAsync(slab, st);
+    return rc == NFMC_OK && fe != hipSuccess ? (int)fe : rc;
+}
+
+int nfmc::nfmc_realnvp_inverse_wide_f32(const NfmcRealNVP* flow, const float* z, int64_t n, float* x, float* logdet, float* log_q,
+                                             const NfmcRng* rng, nfmc_stream_t stream) {
+    if (!flow || n <= 0 || (!z && !rng)) return NFMC_EINVAL;
+    if (!nfmc_mfma_wide_supported(flow->d, flow->n_hidden, flow->n_hidden_layers)) return NFMC_EUNSUPPORTED;
+    NfmcRng r = {};
+    if (rng) r = *rng;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t tiles = (n + kMfmaChains - 1) / kMfmaChains;
+    const int grid = (int)(tiles < kCkMaxGrid ? tiles : kCkMaxGrid);
+    float* slab = nullptr;
+    int rc = wide_slab(&slab, tiles, flow->d, 1, st);
+    if (rc) return rc;
+    NFMC_WIDE_DISPATCH(realnvp_inverse_wide_kernel, *flow, z, n, x, logdet, log_q, r, slab, tiles)
+    const hipError_t fe = hipFreeAsync(slab, st);
+    return rc == NFMC_OK && fe != hipSuccess ? (int)fe : rc;
+}
+
 int nfmc::nfmc_neutra_potential_grad_wide_f32(const NfmcRealNVP* flow, const NfmcPotential* pot, const float* z, int64_t n,
                                                    float* u_out, float* grad_out, nfmc_stream_t stream) {
     if (!flow || !pot || !z || n <= 0) return NFMC_EINVAL;
@@ -397,26 +571,10 @@ int nfmc::nfmc_neutra_potential_grad_wide_f32(const NfmcRealNVP* flow, const Nfm
     hipStream_t st = (hipStream_t)stream;
     const int64_t tiles = (n + kMfmaChains - 1) / kMfmaChains;
     const int grid = (int)(tiles < kCkMaxGrid ? tiles : kCkMaxGrid);
-    const size_t slab_bytes = (size_t)2 * tiles * kMfmaChains * flow->d * sizeof(float);
     float* slab = nullptr;
-    hipError_t e = hipMallocAsync((void**)&slab, slab_bytes, st);   // stream-ordered: the entry point has no scratch argument
-    if (e != hipSuccess) return (int)e;
-    const int th = nfmc_realnvp_padded_hidden(flow->n_hidden) / 16, nhl = flow->n_hidden_layers;
-    int rc = NFMC_OK;
-#define NFMC_WIDE(THV, NHLV)                                                                                                    \
-    if (th == THV && nhl == NHLV) {                                                                                             \
-        auto kern = neutra_grad_wide_kernel<THV, NHLV>;                                                                         \
-        e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWideLdsBytes);             \
-        if (e != hipSuccess) rc = (int)e;                                                                                       \
-        else hipLaunchKernelGGL(kern, dim3(grid), dim3(kMfmaBlock), kWideLdsBytes, st, *flow, *pot, z, n, u_out, grad_out, slab, tiles); \
-    }
-    NFMC_WIDE(4, 1) else NFMC_WIDE(4, 2) else NFMC_WIDE(8, 1) else NFMC_WIDE(8, 2) else rc = NFMC_EUNSUPPORTED;
-#undef NFMC_WIDE
-    if (rc == NFMC_OK) {
-        e = hipGetLastError();
-        if (e != hipSuccess) rc = (int)e;
-    }
-    e = hipFreeAsync(slab, st);
-    if (rc == NFMC_OK && e != hipSuccess) rc = (int)e;
-    return rc;
+    int rc = wide_slab(&slab, tiles, flow->d, 2, st);   // state and gradient
+    if (rc) return rc;
+    NFMC_WIDE_DISPATCH(neutra_grad_wide_kernel, *flow, *pot, z, n, u_out, grad_out, slab, tiles)
+    const hipError_t fe = hipFreeAsync(slab, st);
+    return rc == NFMC_OK && fe != hipSuccess ? (int)fe : rc;
 }

@@ -313,7 +313,8 @@ def test_imh_golden_python_callable_split_path(dev):
 # ------------------------------------------------------------------------------------------ flow known answers
 FLOW_CASES = [(6, 2, None, 2), (7, 3, 5, 3), (25, 2, None, 2), (64, 2, None, 2), (64, 4, 16, 2), (100, 3, 7, 1),
               (8, 1, 32, 2), (256, 2, 4, 2), (2, 2, 4, 2), (3, 5, 9, 2),
-              (100, 4, 100, 5), (64, 2, 64, 1), (128, 2, 128, 2), (30, 2, 40, 3)]   # wide conditioners
+              (100, 4, 100, 5), (64, 2, 64, 1), (128, 2, 128, 2), (30, 2, 40, 3),   # wide conditioners
+              (256, 2, 128, 2), (256, 3, 40, 1), (512, 2, 128, 2), (512, 3, 64, 2), (512, 1, 100, 1)]   # ... at d = 256 / 512: mfma_wide.hip
 
 
 @pytest.mark.parametrize('d,nl,nh,cl', [(6, 2, None, 2), (64, 3, 16, 2), (64, 2, 64, 2), (33, 4, 7, 1)])
@@ -1740,6 +1741,40 @@ def test_neutra_hmc_shapes_without_a_fused_kernel_match_oracle(dev, d, ck, kind)
     f = Flow(cls((d,), conditioner_kwargs=ck))
     f.load_state_dict(of.state_dict())
     z0 = 0.5 * torch.randn(n, d)
+    s = neutra.NeuTraHMC((d,), SumOfSquares((d,)), mcmc.HMCKernel(event_size=d, n_leapfrog_steps=L, step_size=h),
+                         mcmc.HMCParameters(), neutra.NeuTraKernel((d,), flow=f), neutra.NeuTraParameters(n_iterations=T))
+    s.seed = 78
+    out = s.sample(z0, show_progress=False)
+    tr = osamp.neutra_hmc_sample(z0, opot.sum_squares, of, T, h, None, L, noise=osamp.PhiloxNoise(78))
+    got, want = out.samples.reshape(T, n, d), tr.stacked()
+    same = (got - want).abs().amax(dim=(0, 2)) < 5e-4
+    assert same.float().mean() > 0.9, float(same.float().mean())
+    assert out.statistics.n_attempted_trajectories == n * T
+    assert abs(out.statistics.n_accepted_trajectories - tr.n_accepted) <= 4
+
+
+@pytest.mark.parametrize('d,nh,cl,nl', [(256, 128, 2, 2), (512, 64, 1, 3)])
+def test_neutra_hmc_wide_events_and_wide_conditioners_stay_off_torch_autograd(dev, d, nh, cl, nl, monkeypatch):
+    """NeuTra HMC at d = 256 / 512 with a conditioner wider than 32: no fused trajectory kernel, so the sampler composes the
+    transition from the inner HMC's split path -- but the adjusted potential and its gradient now come from the streamed
+    matrix-core kernel (csrc/mfma_wide.hip), not from torch autograd through the restatement (the test fails if the
+    restatement is touched), and the trajectory still follows the oracle on the Philox streams."""
+    from nfmc_amd.samplers import neutra, mcmc
+    from nfmc_amd import flow_training
+    from nfmc_amd.flows import Flow, RealNVP
+    from nfmc_amd.potentials import SumOfSquares
+    from oracle import flow as oflow, potentials as opot, samplers as osamp
+    n, T, L, h = 150, 2, 10, 0.02
+    ck = {'n_hidden': nh, 'n_layers': cl}
+    torch.manual_seed(d + nh)
+    of = oflow.perturb_(oflow.Flow(oflow.RealNVP((d,), n_layers=nl, conditioner_kwargs=ck)), 9, 0.05)
+    f = Flow(RealNVP((d,), n_layers=nl, conditioner_kwargs=ck))
+    f.load_state_dict(of.state_dict())
+    z0 = 0.5 * torch.randn(n, d)
+
+    def boom(*a, **k):
+        raise AssertionError('the torch restatement of the flow was differentiated: no gradient kernel served this shape')
+    monkeypatch.setattr(flow_training, 'inverse_torch', boom)
     s = neutra.NeuTraHMC((d,), SumOfSquares((d,)), mcmc.HMCKernel(event_size=d, n_leapfrog_steps=L, step_size=h),
                          mcmc.HMCParameters(), neutra.NeuTraKernel((d,), flow=f), neutra.NeuTraParameters(n_iterations=T))
     s.seed = 78
