@@ -334,9 +334,10 @@ int64_t nfmc_neutra_scratch_bytes(int64_t n, int32_t d, int32_t n_hidden, int32_
 int nfmc_neutra_hmc_steps_f32(const NfmcNeutraHmcArgs* args, nfmc_stream_t stream);
 
 /* Adjusted potential and its gradient alone (tests; split path).  n_hidden <= 32: every d <= 512.  n_hidden 33..128
- * (matrix cores): d = 64 / 128 register-resident, d = 256 / 512 with the state and the gradient streamed through a
- * scratch slab the entry point allocates and frees in stream order (hipMallocAsync; csrc/mfma_wide.hip); other d:
- * NFMC_EUNSUPPORTED.  nfmc_realnvp_forward_f32 / nfmc_realnvp_inverse_f32 use the same streamed kernels at d = 256 / 512. */
+ * (matrix cores): d = 64 / 128 register-resident, every other multiple of 32 up to 512 with the state and the gradient
+ * streamed through a scratch slab the entry point allocates and frees in stream order (hipMallocAsync;
+ * csrc/mfma_wide.hip); other d: NFMC_EUNSUPPORTED.  nfmc_realnvp_forward_f32 / nfmc_realnvp_inverse_f32 use the same
+ * streamed kernels at those d. */
 int nfmc_neutra_potential_grad_f32(const NfmcRealNVP* flow, const NfmcPotential* pot, const float* z, int64_t n,
                                    float* u_out, float* grad_out, nfmc_stream_t stream);
 

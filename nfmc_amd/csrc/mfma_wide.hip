@@ -1,4 +1,5 @@
-// The matrix-core path for WIDE EVENTS, d = 256 and d = 512 with RealNVP conditioners of width 33..128:
+// The matrix-core path for WIDE EVENTS: d = 256 and d = 512 -- and every other multiple of 32 that the register-resident
+// kernels do not serve -- with RealNVP conditioners of width 33..128:
 //   K3 / K4   bijection.forward / inverse, Flow.log_prob / sample             (jump.py:205,218; imh.py:214,221)
 //   K5        the adjusted potential U~(z) = U(f^-1(z)) - logdet_inv(z) and its gradient   (neutra.py:58-68)
 // The reference has no shape limit at these call sites; the register-resident kernels of flow_mfma.hip / neutra_mfma.hip
@@ -34,16 +35,22 @@ __device__ __forceinline__ f32x4 rev4(const f32x4 a) {
     return t;
 }
 
-// img[r * ld + c] = W[(row0 + (rrev ? R - 1 - r : r)) * ldw + col0 + (crev ? K - 1 - c : c)],  r < R, c < K = 4 << k4log.
-// All threads of the workgroup; col0, ldw and K are multiples of 4 and W is 16-byte aligned (16-byte pieces).
-__device__ __forceinline__ void stage_any(float* __restrict__ img, int ld, const float* __restrict__ W, int ldw, int R, int k4log, int row0,
-                                          bool rrev, int col0, bool crev) {
-    const int k4 = 1 << k4log, K = k4 << 2, N = R << k4log;
+// img[r * ld + c] = W[srow(r) * ldw + scol(c)] for r < Rv, c < Kv and 0 elsewhere (r < R, c < K = 4 << k4log), where
+// srow(r) = rrev ? row0 - r : row0 + r and scol(c) = crev ? col0 - c : col0 + c (row0 / col0: the source index of image
+// index 0).  All threads of the workgroup; Kv, ldw and the first source column of every 4-piece are multiples of 4 and W is
+// 16-byte aligned.
+__device__ __forceinline__ void stage_any(float* __restrict__ img, int ld, const float* __restrict__ W, int ldw, int R, int k4log, int Rv,
+                                          int Kv, int row0, bool rrev, int col0, bool crev) {
+    const int k4 = 1 << k4log, N = R << k4log;
     for (int idx = threadIdx.x; idx < N; idx += kMfmaBlock) {
         const int r = idx >> k4log, c = (idx & (k4 - 1)) << 2;
-        const float* src = W + (size_t)(row0 + (rrev ? R - 1 - r : r)) * ldw + col0 + (crev ? K - 4 - c : c);
-        f32x4 v = *reinterpret_cast<const f32x4*>(src);
-        if (crev) v = rev4(v);
+        f32x4 v;
+        v[0] = v[1] = v[2] = v[3] = 0.f;
+        if (r < Rv && c < Kv) {
+            const float* src = W + (size_t)(rrev ? row0 - r : row0 + r) * ldw + (crev ? col0 - c - 3 : col0 + c);
+            v = *reinterpret_cast<const f32x4*>(src);
+            if (crev) v = rev4(v);
+        }
         *reinterpret_cast<f32x4*>(img + r * ld + c) = v;
     }
 }
@@ -54,7 +61,7 @@ struct WideCtx {
     float *img0, *img1, *vec0;   // LDS
     float* xs;                   // this lane's chain in the state slab: element (16 m + 4 q + t) of tile m at xs[16 m + t]
     float* gs;                   // the same in the gradient slab
-    int d, D2, nslice, ngroup;   // D2 = d / 2; slices of 128 source coordinates; groups of 64 target coordinates
+    int d, D2, TS, nslice, ngroup;   // D2 = d / 2 = 16 TS; slices of 128 source coordinates, groups of 64 target coordinates (the last may be partial)
     int col, q;
     float mscale, log1m;
 };
@@ -66,7 +73,7 @@ __device__ __forceinline__ void wide_ctx_init(WideCtx& c, float* lds, const Nfmc
     c.img0 = lds;
     c.img1 = lds + kImgFloats;
     c.vec0 = lds + 2 * kImgFloats;
-    c.d = f.d, c.D2 = f.d / 2, c.nslice = (f.d / 2) / kWideSlice, c.ngroup = (f.d / 2) / 64;
+    c.d = f.d, c.D2 = f.d / 2, c.TS = f.d / 32, c.nslice = (f.d / 2 + kWideSlice - 1) / kWideSlice, c.ngroup = (f.d / 2 + 63) / 64;
     c.col = lane & 15, c.q = lane >> 4;
     c.mscale = f.min_scale;
     c.log1m = __logf(1.f - f.min_scale);
@@ -100,12 +107,17 @@ __device__ __forceinline__ void wide_hidden(const WideCtx& c, const MLayer& L, b
     const float* xsrc = c.xs + 16 * (REV ? c.D2 / 16 : 0);
     for (int ks = 0; ks < c.nslice; ++ks) {
         __syncthreads();   // the previous phase has finished reading image 0
-        stage_any(c.img0, kWideSlice + 4, L.W1, c.D2, hp, 5, 0, false, REV ? c.D2 - kWideSlice * (ks + 1) : kWideSlice * ks, REV);
+        // source positions [128 ks, 128 ks + 128) of the half; a reversed layer's position p is column D2 - 1 - p
+        stage_any(c.img0, kWideSlice + 4, L.W1, c.D2, hp, 5, hp, c.D2 - kWideSlice * ks, 0, false,
+                  REV ? c.D2 - 1 - kWideSlice * ks : kWideSlice * ks, REV);
         if (ks == 0)
             for (int i = threadIdx.x; i < hp; i += kMfmaBlock) c.vec0[i] = L.b1[i];
         f32x4 src[8];
 #pragma unroll
-        for (int ms = 0; ms < 8; ++ms) src[ms] = tile_ld(xsrc, 8 * ks + ms);
+        for (int ms = 0; ms < 8; ++ms) {
+            if (8 * ks + ms < c.TS) src[ms] = tile_ld(xsrc, 8 * ks + ms);
+            else src[ms][0] = src[ms][1] = src[ms][2] = src[ms][3] = 0.f;   // past the half (d_a not a multiple of 128)
+        }
         __syncthreads();
         const float* img = c.img0;
         const float* vec = c.vec0;
@@ -122,7 +134,7 @@ __device__ __forceinline__ void wide_hidden(const WideCtx& c, const MLayer& L, b
     }
     if constexpr (NHL > 1) {
         __syncthreads();
-        stage_any(c.img0, hp + 4, L.Wh, hp, hp, log2i(hp / 4), 0, false, 0, false);
+        stage_any(c.img0, hp + 4, L.Wh, hp, hp, log2i(hp / 4), hp, hp, 0, false, 0, false);
         for (int i = threadIdx.x; i < hp; i += kMfmaBlock) c.vec0[i] = L.bh[i];
         __syncthreads();
         const float* img = c.img0;
@@ -138,12 +150,13 @@ __device__ __forceinline__ void wide_hidden(const WideCtx& c, const MLayer& L, b
 template <int TH>
 __device__ __forceinline__ void wide_stage_w3(const WideCtx& c, const MLayer& L, bool REV, int gq) {
     constexpr int hp = 16 * TH;
-    const int r0 = REV ? c.D2 - 64 * (gq + 1) : 64 * gq;   // a reversed layer's target position p is output row D2 - 1 - p
-    stage_any(c.img0, hp + 4, L.W3, hp, 64, log2i(hp / 4), r0, REV, 0, false);
-    stage_any(c.img0 + 64 * (hp + 4), hp + 4, L.W3, hp, 64, log2i(hp / 4), c.D2 + r0, REV, 0, false);
+    const int rv = c.D2 - 64 * gq;                            // target positions [64 gq, 64 gq + 64) of the half that exist
+    const int r0 = REV ? c.D2 - 1 - 64 * gq : 64 * gq;        // a reversed layer's target position p is output row D2 - 1 - p
+    stage_any(c.img0, hp + 4, L.W3, hp, 64, log2i(hp / 4), rv, hp, r0, REV, 0, false);
+    stage_any(c.img0 + 64 * (hp + 4), hp + 4, L.W3, hp, 64, log2i(hp / 4), rv, hp, c.D2 + r0, REV, 0, false);
     for (int i = threadIdx.x; i < 128; i += kMfmaBlock) {
         const int r = i & 63, blk = i >> 6;
-        c.vec0[i] = L.b3[blk * c.D2 + r0 + (REV ? 63 - r : r)];
+        c.vec0[i] = r < rv ? L.b3[blk * c.D2 + (REV ? r0 - r : r0 + r)] : 0.f;
     }
 }
 
@@ -170,13 +183,13 @@ __device__ __forceinline__ float wide_coupling(const WideCtx& c, const MLayer& L
             [&](int i) { return img + (16 * ((i & 1) * 4 + (i >> 1)) + col) * (hp + 4) + 4 * q; },
             [&](int i) {
                 ((i & 1) ? ub2 : ua2)[(i >> 1) & 1] = vec_tile(vec, (i & 1) * 4 + (i >> 1), q);
-                if ((i & 1) == 0) y2[(i >> 1) & 1] = tile_ld(xt, 4 * gq + (i >> 1));   // arrives under the two steps' MFMAs
+                if ((i & 1) == 0 && 4 * gq + (i >> 1) < c.TS) y2[(i >> 1) & 1] = tile_ld(xt, 4 * gq + (i >> 1));   // arrives under the two steps' MFMAs
             },
             [&](int i) -> f32x4& { return ((i & 1) ? ub2 : ua2)[(i >> 1) & 1]; },
             [&](int) -> const f32x4(&)[TH] { return hl; },
             [&](int i) {
-                if ((i & 1) == 0) return;
                 const int mt = i >> 1;
+                if ((i & 1) == 0 || 4 * gq + mt >= c.TS) return;   // the pair's first step; a tile past the half
                 const f32x4 ua = ua2[mt & 1], ub = ub2[mt & 1];
                 f32x4 v = y2[mt & 1];
 #pragma unroll
@@ -221,9 +234,10 @@ __device__ __forceinline__ void wide_coupling_backward(const WideCtx& c, const M
         // W3^T of the same four target tiles -> image 1, a tile's 16 alpha columns next to its 16 beta columns
         for (int mt = 0; mt < 4; ++mt) {
             const int p0 = 64 * gq + 16 * mt;                      // target position of the tile's first coordinate
-            const int c0 = REV ? c.D2 - p0 - 16 : p0;              // a reversed layer's position p is column D2 - 1 - p
-            stage_any(c.img1 + 32 * mt, kWideSlice + 4, L.W3T, 2 * c.D2, hp, 2, 0, false, c0, REV);
-            stage_any(c.img1 + 32 * mt + 16, kWideSlice + 4, L.W3T, 2 * c.D2, hp, 2, 0, false, c.D2 + c0, REV);
+            const int kv = p0 < c.D2 ? 16 : 0;                     // a tile past the half: zeros
+            const int c0 = REV ? c.D2 - 1 - p0 : p0;               // a reversed layer's position p is column D2 - 1 - p
+            stage_any(c.img1 + 32 * mt, kWideSlice + 4, L.W3T, 2 * c.D2, hp, 2, hp, kv, 0, false, c0, REV);
+            stage_any(c.img1 + 32 * mt + 16, kWideSlice + 4, L.W3T, 2 * c.D2, hp, 2, hp, kv, 0, false, c.D2 + c0, REV);
         }
         __syncthreads();
         const float* img = c.img0;
@@ -231,6 +245,7 @@ __device__ __forceinline__ void wide_coupling_backward(const WideCtx& c, const M
         const float* vec = c.vec0;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
+            if (4 * gq + mt >= c.TS) break;   // uniform: the half ends inside this group
             f32x4 uab[2];
             const f32x4 y = tile_ld(xt, 4 * gq + mt), gy = tile_ld(gt, 4 * gq + mt);
             gemm_phase<TH, 2>([&](int i) { return img + (16 * (i * 4 + mt) + col) * (hp + 4) + 4 * q; },
@@ -261,7 +276,7 @@ __device__ __forceinline__ void wide_coupling_backward(const WideCtx& c, const M
         for (int t = 0; t < 4; ++t) dh[mo][t] *= (1.f - hl[mo][t] * hl[mo][t]);
     if constexpr (NHL > 1) {
         __syncthreads();
-        stage_any(c.img0, hp + 4, L.WhT, hp, hp, log2i(hp / 4), 0, false, 0, false);
+        stage_any(c.img0, hp + 4, L.WhT, hp, hp, log2i(hp / 4), hp, hp, 0, false, 0, false);
         __syncthreads();
         const float* img = c.img0;
         gemm_phase<TH, TH>([&](int mo) { return img + (16 * mo + col) * (hp + 4) + 4 * q; },
@@ -278,13 +293,19 @@ __device__ __forceinline__ void wide_coupling_backward(const WideCtx& c, const M
     float* gsrc = c.gs + 16 * (REV ? c.D2 / 16 : 0);
     for (int ks = 0; ks < c.nslice; ++ks) {
         __syncthreads();
-        stage_any(c.img0, hp + 4, L.W1T, hp, kWideSlice, log2i(hp / 4), REV ? c.D2 - kWideSlice * (ks + 1) : kWideSlice * ks, REV, 0, false);
+        stage_any(c.img0, hp + 4, L.W1T, hp, kWideSlice, log2i(hp / 4), c.D2 - kWideSlice * ks, hp,
+                  REV ? c.D2 - 1 - kWideSlice * ks : kWideSlice * ks, REV, 0, false);
         __syncthreads();
         const float* img = c.img0;
         f32x4 acc2[2];
         gemm_phase<TH, 8>([&](int ms) { return img + (16 * ms + col) * (hp + 4) + 4 * q; },
-                          [&](int ms) { acc2[ms & 1] = tile_ld(gsrc, 8 * ks + ms); }, [&](int ms) -> f32x4& { return acc2[ms & 1]; },
-                          [&](int) -> const f32x4(&)[TH] { return dh; }, [&](int ms) { tile_st(gsrc, 8 * ks + ms, acc2[ms & 1]); });
+                          [&](int ms) {
+                              if (8 * ks + ms < c.TS) acc2[ms & 1] = tile_ld(gsrc, 8 * ks + ms);
+                          },
+                          [&](int ms) -> f32x4& { return acc2[ms & 1]; }, [&](int) -> const f32x4(&)[TH] { return dh; },
+                          [&](int ms) {
+                              if (8 * ks + ms < c.TS) tile_st(gsrc, 8 * ks + ms, acc2[ms & 1]);
+                          });
     }
 }
 
@@ -502,7 +523,9 @@ __global__ void __launch_bounds__(kMfmaBlock, 2) realnvp_inverse_wide_kernel(Nfm
 using namespace nfmc;
 
 int nfmc::nfmc_mfma_wide_supported(int32_t d, int32_t n_hidden, int32_t n_hidden_layers) {
-    return (d == 256 || d == 512) && n_hidden > 32 && n_hidden <= 128 && n_hidden_layers >= 1 && n_hidden_layers <= 2;
+    // whole 16-coordinate tiles per half; d = 64 / 128 belong to the register-resident kernels (nfmc_mfma_supported)
+    return d >= 32 && d <= 512 && d % 32 == 0 && d != 64 && d != 128 && n_hidden > 32 && n_hidden <= 128 && n_hidden_layers >= 1 &&
+           n_hidden_layers <= 2;
 }
 
 // the scratch slab of one launch: stream-ordered allocation (the C entry points of these passes have no scratch argument)

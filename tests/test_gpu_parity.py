@@ -314,7 +314,8 @@ def test_imh_golden_python_callable_split_path(dev):
 FLOW_CASES = [(6, 2, None, 2), (7, 3, 5, 3), (25, 2, None, 2), (64, 2, None, 2), (64, 4, 16, 2), (100, 3, 7, 1),
               (8, 1, 32, 2), (256, 2, 4, 2), (2, 2, 4, 2), (3, 5, 9, 2),
               (100, 4, 100, 5), (64, 2, 64, 1), (128, 2, 128, 2), (30, 2, 40, 3),   # wide conditioners
-              (256, 2, 128, 2), (256, 3, 40, 1), (512, 2, 128, 2), (512, 3, 64, 2), (512, 1, 100, 1)]   # ... at d = 256 / 512: mfma_wide.hip
+              (256, 2, 128, 2), (256, 3, 40, 1), (512, 2, 128, 2), (512, 3, 64, 2), (512, 1, 100, 1),   # ... at d = 32 k: mfma_wide.hip
+              (32, 2, 64, 2), (96, 3, 128, 1), (160, 2, 100, 2), (320, 3, 64, 2), (448, 2, 128, 2)]
 
 
 @pytest.mark.parametrize('d,nl,nh,cl', [(6, 2, None, 2), (64, 3, 16, 2), (64, 2, 64, 2), (33, 4, 7, 1)])
@@ -982,12 +983,15 @@ def test_neutra_mfma_potential_and_gradient_match_autograd(dev, d, nl, nh, cl, p
 
 
 @pytest.mark.parametrize('d,nl,nh,cl,pot', [(256, 2, 128, 2, 'funnel'), (256, 3, 64, 1, 'sumsq'), (256, 1, 100, 2, 'sumsq'),
-                                             (512, 2, 128, 2, 'sumsq'), (512, 3, 40, 1, 'funnel'), (512, 2, 64, 2, 'funnel')])
+                                             (512, 2, 128, 2, 'sumsq'), (512, 3, 40, 1, 'funnel'), (512, 2, 64, 2, 'funnel'),
+                                             (32, 2, 64, 2, 'funnel'), (96, 3, 128, 1, 'sumsq'), (160, 2, 100, 2, 'funnel'),
+                                             (192, 3, 64, 2, 'sumsq'), (320, 2, 128, 2, 'funnel'), (448, 3, 40, 1, 'sumsq')])
 def test_neutra_wide_event_mfma_potential_and_gradient_match_autograd(dev, d, nl, nh, cl, pot):
-    """Round 3: d = 256 / 512 with conditioners of width 33..128 on the matrix cores with the state and gradient STREAMED
-    through a scratch slab (csrc/neutra_mfma_wide.hip; the register-resident kernels stop at d = 128, these shapes used to
-    fall back to torch autograd through the restatement).  Odd and even numbers of coupling layers (latent order reversed
-    or not), one and two hidden layers, padded widths, a batch that is not a multiple of the 128-chain workgroup tile."""
+    """Round 3: every d that is a multiple of 32 (other than 64 / 128, which the register-resident kernels serve) with
+    conditioners of width 33..128 on the matrix cores with the state and gradient STREAMED through a scratch slab
+    (csrc/mfma_wide.hip; these shapes used to fall back to torch autograd through the restatement).  Odd and even numbers
+    of coupling layers (latent order reversed or not), one and two hidden layers, padded widths, halves that are not whole
+    128-coordinate slices or 64-coordinate groups, a batch that is not a multiple of the 128-chain workgroup tile."""
     from nfmc_amd import hip
     from nfmc_amd.flows import Flow, RealNVP
     from nfmc_amd.potentials import SumOfSquares, Funnel
