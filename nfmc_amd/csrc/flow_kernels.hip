@@ -388,6 +388,10 @@ extern "C" int nfmc_flow_mh_supported_f32(const NfmcFlowMhArgs* args) {
     if (rc != NFMC_EUNSUPPORTED) return rc;
     if (rng_rounds(a.rng) != 10) return NFMC_EUNSUPPORTED;   // the opt-in stream exists in the register kernels only
     if (use_mfma_flow(&a.flow) && al16(a.x) && al16(a.samples.base)) return NFMC_OK;
+    // wide conditioners at the streamed matrix-core shapes (mfma_wide.hip): the caller composes the step from the flow's
+    // own passes, which run there (d = 256, H = 128 x 2, 65536 chains: 0.53 ms per pass against 5.3 for the
+    // one-chain-per-lane kernel this entry point would use; nfmc_flow_mh_steps_f32 itself still takes the call)
+    if (use_mfma_wide(&a.flow)) return NFMC_EUNSUPPORTED;
     return flow_mh_tile_lds(a.flow) <= kMaxLdsBytes ? NFMC_OK : NFMC_EUNSUPPORTED;
 }
 

@@ -1397,10 +1397,12 @@ def test_two_chains_per_lane_group_equals_one_chain_kernel(dev, d, n, strategy, 
     np.testing.assert_allclose(a.second_moment.numpy(), b.second_moment.numpy(), atol=1e-5)
 
 
-@pytest.mark.parametrize('d,nh,cl,strategy', [(64, 64, 1, 'imh'), (128, 128, 2, 'jump_mala'), (64, 40, 2, 'jump_hmc')])
+@pytest.mark.parametrize('d,nh,cl,strategy', [(64, 64, 1, 'imh'), (128, 128, 2, 'jump_mala'), (64, 40, 2, 'jump_hmc'),
+                                              (256, 128, 2, 'jump_mala'), (160, 64, 1, 'imh')])
 def test_wide_flow_metropolis_on_matrix_cores_equals_valu_kernels(dev, d, nh, cl, strategy, monkeypatch):
-    """Wide conditioners at d = 64 / 128: forward / inverse / flow-MH run on the matrix cores (flow_mfma.hip); the
-    one-chain-per-lane kernels (NFMC_FLOW_NO_MFMA=1) simulate the same chains from the same Philox streams."""
+    """Wide conditioners at d = 64 / 128: forward / inverse / flow-MH run on the matrix cores (flow_mfma.hip); at the other
+    multiples of 32 the step is composed from the streamed matrix-core passes (mfma_wide.hip).  The one-chain-per-lane
+    kernels (NFMC_FLOW_NO_MFMA=1) simulate the same chains from the same Philox streams."""
     from nfmc_amd.sample import create_sampler
     from nfmc_amd.flows import Flow, RealNVP
     from nfmc_amd.potentials import SumOfSquares
