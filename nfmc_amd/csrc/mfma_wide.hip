@@ -39,19 +39,31 @@ __device__ __forceinline__ f32x4 rev4(const f32x4 a) {
 // srow(r) = rrev ? row0 - r : row0 + r and scol(c) = crev ? col0 - c : col0 + c (row0 / col0: the source index of image
 // index 0).  All threads of the workgroup; Kv, ldw and the first source column of every 4-piece are multiples of 4 and W is
 // 16-byte aligned.
+template <int kBatch>
 __device__ __forceinline__ void stage_any(float* __restrict__ img, int ld, const float* __restrict__ W, int ldw, int R, int k4log, int Rv,
                                           int Kv, int row0, bool rrev, int col0, bool crev) {
     const int k4 = 1 << k4log, N = R << k4log;
-    for (int idx = threadIdx.x; idx < N; idx += kMfmaBlock) {
-        const int r = idx >> k4log, c = (idx & (k4 - 1)) << 2;
-        f32x4 v;
-        v[0] = v[1] = v[2] = v[3] = 0.f;
-        if (r < Rv && c < Kv) {
-            const float* src = W + (size_t)(rrev ? row0 - r : row0 + r) * ldw + (crev ? col0 - c - 3 : col0 + c);
-            v = *reinterpret_cast<const f32x4*>(src);
-            if (crev) v = rev4(v);
+    // The weights sit in L2: a copy is latency, not bandwidth.  kBatch 16-byte pieces per thread are requested before the
+    // first is stored (as a plain loop every piece was load -> wait -> store: 8 dependent round trips per 128 x 128 image);
+    // kBatch is what the calling kernel's register budget leaves (4 in the flow passes, 2 or 1 in the gradient kernel).
+    for (int base = threadIdx.x; base < N; base += kBatch * kMfmaBlock) {
+        f32x4 v[kBatch];
+#pragma unroll
+        for (int b = 0; b < kBatch; ++b) {
+            const int idx = base + b * kMfmaBlock;
+            const int r = idx >> k4log, c = (idx & (k4 - 1)) << 2;
+            v[b][0] = v[b][1] = v[b][2] = v[b][3] = 0.f;
+            if (idx < N && r < Rv && c < Kv) {
+                const float* src = W + (size_t)(rrev ? row0 - r : row0 + r) * ldw + (crev ? col0 - c - 3 : col0 + c);
+                v[b] = *reinterpret_cast<const f32x4*>(src);
+            }
         }
-        *reinterpret_cast<f32x4*>(img + r * ld + c) = v;
+#pragma unroll
+        for (int b = 0; b < kBatch; ++b) {
+            const int idx = base + b * kMfmaBlock;
+            const int r = idx >> k4log, c = (idx & (k4 - 1)) << 2;
+            if (idx < N) *reinterpret_cast<f32x4*>(img + r * ld + c) = crev ? rev4(v[b]) : v[b];
+        }
     }
 }
 
@@ -69,6 +81,22 @@ struct WideCtx {
 __device__ __forceinline__ f32x4 tile_ld(const float* p, int m) { return *reinterpret_cast<const f32x4*>(p + 16 * m); }
 __device__ __forceinline__ void tile_st(float* p, int m, const f32x4 v) { *reinterpret_cast<f32x4*>(p + 16 * m) = v; }
 
+// A pass over the TD tiles of a streamed vector, four tiles at a time: the four loads are requested before the first
+// tile is used (a plain loop was load -> wait -> use -> store per tile: one exposed memory round trip per tile, 16-32 per
+// pass, and the passes between the GEMM phases were most of the first version's time).
+template <class Load, class Body>
+__device__ __forceinline__ void wide_tiles(int TD, Load load, Body body) {
+    for (int m0 = 0; m0 < TD; m0 += 4) {
+        f32x4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (m0 + j < TD) v[j] = load(m0 + j);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (m0 + j < TD) body(m0 + j, v[j]);
+    }
+}
+
 __device__ __forceinline__ void wide_ctx_init(WideCtx& c, float* lds, const NfmcRealNVP& f, int lane) {
     c.img0 = lds;
     c.img1 = lds + kImgFloats;
@@ -82,33 +110,33 @@ __device__ __forceinline__ void wide_ctx_init(WideCtx& c, float* lds, const Nfmc
 
 __device__ __forceinline__ float wide_sum_squares(const WideCtx& c) {
     float ss = 0.f;
-    for (int m = 0; m < c.d / 16; ++m) {
-        const f32x4 v = tile_ld(c.xs, m);
+    wide_tiles(c.d / 16, [&](int m) { return tile_ld(c.xs, m); },
+               [&](int, const f32x4& v) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) ss = fmaf(v[t], v[t], ss);
-    }
+                   for (int t = 0; t < 4; ++t) ss = fmaf(v[t], v[t], ss);
+               });
     return chain_sum(ss);
 }
 
 // slab row -> (n, d) array; `rev`: the array is in LOGICAL latent order and tile position p holds logical d - 1 - p
 __device__ __forceinline__ void wide_store_row(const float* src, float* __restrict__ dst_row, int d, int q, bool rev) {
-    for (int m = 0; m < d / 16; ++m) {
-        const f32x4 v = tile_ld(src, m);
-        const int p0 = 16 * m + 4 * q;
-        if (!rev) *reinterpret_cast<f32x4*>(dst_row + p0) = v;
-        else *reinterpret_cast<f32x4*>(dst_row + (d - 4 - p0)) = rev4(v);
-    }
+    wide_tiles(d / 16, [&](int m) { return tile_ld(src, m); },
+               [&](int m, const f32x4& v) {
+                   const int p0 = 16 * m + 4 * q;
+                   if (!rev) *reinterpret_cast<f32x4*>(dst_row + p0) = v;
+                   else *reinterpret_cast<f32x4*>(dst_row + (d - 4 - p0)) = rev4(v);
+               });
 }
 
 // h1 = tanh(W1 x_src + b1), hl = the last hidden layer's activations (h1 itself with one hidden layer)
-template <int TH, int NHL>
+template <int TH, int NHL, int SB>
 __device__ __forceinline__ void wide_hidden(const WideCtx& c, const MLayer& L, bool REV, f32x4 (&h1)[TH], f32x4 (&h2)[TH]) {
     constexpr int hp = 16 * TH;
     const float* xsrc = c.xs + 16 * (REV ? c.D2 / 16 : 0);
     for (int ks = 0; ks < c.nslice; ++ks) {
         __syncthreads();   // the previous phase has finished reading image 0
         // source positions [128 ks, 128 ks + 128) of the half; a reversed layer's position p is column D2 - 1 - p
-        stage_any(c.img0, kWideSlice + 4, L.W1, c.D2, hp, 5, hp, c.D2 - kWideSlice * ks, 0, false,
+        stage_any<SB>(c.img0, kWideSlice + 4, L.W1, c.D2, hp, 5, hp, c.D2 - kWideSlice * ks, 0, false,
                   REV ? c.D2 - 1 - kWideSlice * ks : kWideSlice * ks, REV);
         if (ks == 0)
             for (int i = threadIdx.x; i < hp; i += kMfmaBlock) c.vec0[i] = L.b1[i];
@@ -134,7 +162,7 @@ __device__ __forceinline__ void wide_hidden(const WideCtx& c, const MLayer& L, b
     }
     if constexpr (NHL > 1) {
         __syncthreads();
-        stage_any(c.img0, hp + 4, L.Wh, hp, hp, log2i(hp / 4), hp, hp, 0, false, 0, false);
+        stage_any<SB>(c.img0, hp + 4, L.Wh, hp, hp, log2i(hp / 4), hp, hp, 0, false, 0, false);
         for (int i = threadIdx.x; i < hp; i += kMfmaBlock) c.vec0[i] = L.bh[i];
         __syncthreads();
         const float* img = c.img0;
@@ -147,13 +175,13 @@ __device__ __forceinline__ void wide_hidden(const WideCtx& c, const MLayer& L, b
 }
 
 // the alpha and beta rows (and biases) of target group gq -> image 0 rows [0, 64) and [64, 128), vec0[0, 128)
-template <int TH>
+template <int TH, int SB>
 __device__ __forceinline__ void wide_stage_w3(const WideCtx& c, const MLayer& L, bool REV, int gq) {
     constexpr int hp = 16 * TH;
     const int rv = c.D2 - 64 * gq;                            // target positions [64 gq, 64 gq + 64) of the half that exist
     const int r0 = REV ? c.D2 - 1 - 64 * gq : 64 * gq;        // a reversed layer's target position p is output row D2 - 1 - p
-    stage_any(c.img0, hp + 4, L.W3, hp, 64, log2i(hp / 4), rv, hp, r0, REV, 0, false);
-    stage_any(c.img0 + 64 * (hp + 4), hp + 4, L.W3, hp, 64, log2i(hp / 4), rv, hp, c.D2 + r0, REV, 0, false);
+    stage_any<SB>(c.img0, hp + 4, L.W3, hp, 64, log2i(hp / 4), rv, hp, r0, REV, 0, false);
+    stage_any<SB>(c.img0 + 64 * (hp + 4), hp + 4, L.W3, hp, 64, log2i(hp / 4), rv, hp, c.D2 + r0, REV, 0, false);
     for (int i = threadIdx.x; i < 128; i += kMfmaBlock) {
         const int r = i & 63, blk = i >> 6;
         c.vec0[i] = r < rv ? L.b3[blk * c.D2 + (REV ? r0 - r : r0 + r)] : 0.f;
@@ -162,17 +190,17 @@ __device__ __forceinline__ void wide_stage_w3(const WideCtx& c, const MLayer& L,
 
 // ---- one coupling layer on the streamed state.  INVERSE: v_b = (y_b - beta) / alpha, else z_b = alpha x_b + beta.
 // Returns this lane's share of the layer's logdet in THAT direction.
-template <int TH, int NHL, bool INVERSE>
+template <int TH, int NHL, bool INVERSE, int SB>
 __device__ __forceinline__ float wide_coupling(const WideCtx& c, const MLayer& L, bool REV) {
     constexpr int hp = 16 * TH;
     f32x4 h1[TH], h2[TH];
-    wide_hidden<TH, NHL>(c, L, REV, h1, h2);
+    wide_hidden<TH, NHL, SB>(c, L, REV, h1, h2);
     const f32x4(&hl)[TH] = NHL > 1 ? h2 : h1;
     float* xt = c.xs + 16 * (REV ? 0 : c.D2 / 16);
     float ld = 0.f;
     for (int gq = 0; gq < c.ngroup; ++gq) {
         __syncthreads();
-        wide_stage_w3<TH>(c, L, REV, gq);
+        wide_stage_w3<TH, SB>(c, L, REV, gq);
         __syncthreads();
         const float* img = c.img0;
         const float* vec = c.vec0;
@@ -213,11 +241,11 @@ __device__ __forceinline__ float wide_coupling(const WideCtx& c, const MLayer& L
 // coupling_inverse_backward_c in neutra_mfma.hip, without checkpoints): per target tile the W3 product, the elementwise
 // backward of the affine map (state tile restored, gradient tile rescaled, du / dv) and the W3^T product into dL/dh are
 // done back to back; then W_h^T, tanh' and W1^T into the source half of the gradient.
-template <int TH, int NHL>
+template <int TH, int NHL, int SB>
 __device__ __forceinline__ void wide_coupling_backward(const WideCtx& c, const MLayer& L, bool REV) {
     constexpr int hp = 16 * TH;
     f32x4 h1[TH], h2[TH];
-    wide_hidden<TH, NHL>(c, L, REV, h1, h2);
+    wide_hidden<TH, NHL, SB>(c, L, REV, h1, h2);
     f32x4(&hl)[TH] = NHL > 1 ? h2 : h1;
     float* xt = c.xs + 16 * (REV ? 0 : c.D2 / 16);
     float* gt = c.gs + 16 * (REV ? 0 : c.D2 / 16);
@@ -230,14 +258,14 @@ __device__ __forceinline__ void wide_coupling_backward(const WideCtx& c, const M
     const float mscale = c.mscale, log1m = c.log1m;
     for (int gq = 0; gq < c.ngroup; ++gq) {
         __syncthreads();
-        wide_stage_w3<TH>(c, L, REV, gq);
+        wide_stage_w3<TH, SB>(c, L, REV, gq);
         // W3^T of the same four target tiles -> image 1, a tile's 16 alpha columns next to its 16 beta columns
         for (int mt = 0; mt < 4; ++mt) {
             const int p0 = 64 * gq + 16 * mt;                      // target position of the tile's first coordinate
             const int kv = p0 < c.D2 ? 16 : 0;                     // a tile past the half: zeros
             const int c0 = REV ? c.D2 - 1 - p0 : p0;               // a reversed layer's position p is column D2 - 1 - p
-            stage_any(c.img1 + 32 * mt, kWideSlice + 4, L.W3T, 2 * c.D2, hp, 2, hp, kv, 0, false, c0, REV);
-            stage_any(c.img1 + 32 * mt + 16, kWideSlice + 4, L.W3T, 2 * c.D2, hp, 2, hp, kv, 0, false, c.D2 + c0, REV);
+            stage_any<SB>(c.img1 + 32 * mt, kWideSlice + 4, L.W3T, 2 * c.D2, hp, 2, hp, kv, 0, false, c0, REV);
+            stage_any<SB>(c.img1 + 32 * mt + 16, kWideSlice + 4, L.W3T, 2 * c.D2, hp, 2, hp, kv, 0, false, c.D2 + c0, REV);
         }
         __syncthreads();
         const float* img = c.img0;
@@ -276,7 +304,7 @@ __device__ __forceinline__ void wide_coupling_backward(const WideCtx& c, const M
         for (int t = 0; t < 4; ++t) dh[mo][t] *= (1.f - hl[mo][t] * hl[mo][t]);
     if constexpr (NHL > 1) {
         __syncthreads();
-        stage_any(c.img0, hp + 4, L.WhT, hp, hp, log2i(hp / 4), hp, hp, 0, false, 0, false);
+        stage_any<SB>(c.img0, hp + 4, L.WhT, hp, hp, log2i(hp / 4), hp, hp, 0, false, 0, false);
         __syncthreads();
         const float* img = c.img0;
         gemm_phase<TH, TH>([&](int mo) { return img + (16 * mo + col) * (hp + 4) + 4 * q; },
@@ -293,7 +321,7 @@ __device__ __forceinline__ void wide_coupling_backward(const WideCtx& c, const M
     float* gsrc = c.gs + 16 * (REV ? c.D2 / 16 : 0);
     for (int ks = 0; ks < c.nslice; ++ks) {
         __syncthreads();
-        stage_any(c.img0, hp + 4, L.W1T, hp, kWideSlice, log2i(hp / 4), c.D2 - kWideSlice * ks, hp,
+        stage_any<SB>(c.img0, hp + 4, L.W1T, hp, kWideSlice, log2i(hp / 4), c.D2 - kWideSlice * ks, hp,
                   REV ? c.D2 - 1 - kWideSlice * ks : kWideSlice * ks, REV, 0, false);
         __syncthreads();
         const float* img = c.img0;
@@ -316,64 +344,63 @@ template <int MODE>
 __device__ __forceinline__ float wide_ea(const WideCtx& c, const float* __restrict__ g_ls, const float* __restrict__ g_sh, bool rev) {
     constexpr bool BACKWARD = MODE == kEaBackward;
     float ld = 0.f;
-    for (int m = 0; m < c.d / 16; ++m) {
-        const f32x4 ls = rev ? vec_tile_rev(g_ls, m, c.q, c.d) : vec_tile(g_ls, m, c.q);
-        const f32x4 sh = rev ? vec_tile_rev(g_sh, m, c.q, c.d) : vec_tile(g_sh, m, c.q);
-        f32x4 x = tile_ld(c.xs, m);
-        if constexpr (BACKWARD) {
-            f32x4 g = tile_ld(c.gs, m);
+    wide_tiles(c.d / 16, [&](int m) { return tile_ld(c.xs, m); },
+               [&](int m, f32x4 x) {
+                   const f32x4 ls = rev ? vec_tile_rev(g_ls, m, c.q, c.d) : vec_tile(g_ls, m, c.q);
+                   const f32x4 sh = rev ? vec_tile_rev(g_sh, m, c.q, c.d) : vec_tile(g_sh, m, c.q);
+                   if constexpr (BACKWARD) {
+                       f32x4 g = tile_ld(c.gs, m);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                g[t] *= fast_exp(-ls[t]);
-                x[t] = fmaf(fast_exp(ls[t]), x[t], sh[t]);
-            }
-            tile_st(c.gs, m, g);
-        } else if constexpr (MODE == kEaForward) {
+                       for (int t = 0; t < 4; ++t) {
+                           g[t] *= fast_exp(-ls[t]);
+                           x[t] = fmaf(fast_exp(ls[t]), x[t], sh[t]);
+                       }
+                       tile_st(c.gs, m, g);
+                   } else if constexpr (MODE == kEaForward) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                x[t] = fmaf(fast_exp(ls[t]), x[t], sh[t]);
-                ld += ls[t];
-            }
-        } else {
+                       for (int t = 0; t < 4; ++t) {
+                           x[t] = fmaf(fast_exp(ls[t]), x[t], sh[t]);
+                           ld += ls[t];
+                       }
+                   } else {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                x[t] = (x[t] - sh[t]) * fast_exp(-ls[t]);
-                ld -= ls[t];
-            }
-        }
-        tile_st(c.xs, m, x);
-    }
+                       for (int t = 0; t < 4; ++t) {
+                           x[t] = (x[t] - sh[t]) * fast_exp(-ls[t]);
+                           ld -= ls[t];
+                       }
+                   }
+                   tile_st(c.xs, m, x);
+               });
     return ld;
 }
 
 // closed-form potential and its gradient on the streamed state (potential_value_grad_c's arithmetic, tile by tile)
 __device__ __forceinline__ float wide_potential_grad(const WideCtx& c, const NfmcPotential& p, int lane) {
     const int TD = c.d / 16;
+    auto xtile = [&](int m) { return tile_ld(c.xs, m); };
     if (p.kind == NFMC_POT_FUNNEL) {
         const f32x4 t0 = tile_ld(c.xs, 0);
         const float x0 = __shfl(t0[0], lane & 15, kWave);   // coordinate 0 = tile 0, register 0, lane group 0
         float s = 0.f;
-        for (int m = 0; m < TD; ++m) {
-            const f32x4 x = tile_ld(c.xs, m);
+        wide_tiles(TD, xtile, [&](int m, const f32x4& x) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) s = fmaf(x[t], (m == 0 && t == 0 && c.q == 0) ? 0.f : x[t], s);
-        }
+        });
         s = chain_sum(s);
         const float inv_s2 = 1.f / (p.a_scalar * p.a_scalar);
         const float e = fast_exp(-x0);
         const float hd = 0.5f * (float)(c.d - 1);
-        for (int m = 0; m < TD; ++m) {
-            const f32x4 x = tile_ld(c.xs, m);
+        wide_tiles(TD, xtile, [&](int m, const f32x4& x) {
             f32x4 g;
 #pragma unroll
             for (int t = 0; t < 4; ++t) g[t] = x[t] * e;
             if (m == 0 && c.q == 0) g[0] = x0 * inv_s2 - 0.5f * e * s + hd;
             tile_st(c.gs, m, g);
-        }
+        });
         return 0.5f * x0 * x0 * inv_s2 + 0.5f * e * s + hd * x0;
     }
     float u = 0.f;
-    for (int m = 0; m < TD; ++m) {
+    wide_tiles(TD, xtile, [&](int m, const f32x4& x) {
         f32x4 a, b;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -382,7 +409,6 @@ __device__ __forceinline__ float wide_potential_grad(const WideCtx& c, const Nfm
         }
         if (p.a) a = vec_tile(p.a, m, c.q);
         if (p.b) b = vec_tile(p.b, m, c.q);
-        const f32x4 x = tile_ld(c.xs, m);
         f32x4 g;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -391,7 +417,7 @@ __device__ __forceinline__ float wide_potential_grad(const WideCtx& c, const Nfm
             g[t] = 2.f * a[t] * dlt;
         }
         tile_st(c.gs, m, g);
-    }
+    });
     return chain_sum(u);
 }
 
@@ -403,6 +429,7 @@ __global__ void __launch_bounds__(kMfmaBlock, 2) neutra_grad_wide_kernel(NfmcRea
                                                                       float* __restrict__ slab, int64_t tiles) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int hp = 16 * TH;
+    constexpr int kSB = (TH == 8 && NHL == 2) ? 1 : 2;   // staging pieces in flight: what is left of 256 registers (no scratch)
     const int d = f.d;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool rev_last = (f.n_coupling & 1) != 0;
@@ -415,15 +442,16 @@ __global__ void __launch_bounds__(kMfmaBlock, 2) neutra_grad_wide_kernel(NfmcRea
         c.xs = slab + row * d + 4 * c.q;
         c.gs = slab + (tiles * kMfmaChains + row) * d + 4 * c.q;
         // z at tile positions in latent order (flows with an odd number of reversals: position p holds logical d - 1 - p)
-        for (int m = 0; m < d / 16; ++m) tile_st(c.xs, m, rev_last ? vec_tile_rev(zr, m, c.q, d) : vec_tile(zr, m, c.q));
+        wide_tiles(d / 16, [&](int m) { return rev_last ? vec_tile_rev(zr, m, c.q, d) : vec_tile(zr, m, c.q); },
+                   [&](int m, const f32x4& v) { tile_st(c.xs, m, v); });
         float ldp = wide_ea<kEaInverse>(c, f.ea1_log_scale, f.ea1_shift, rev_last);
         for (int l = f.n_coupling - 1; l >= 0; --l)
-            ldp += wide_coupling<TH, NHL, true>(c, mfma_layer(f.weights + l * f.layer_stride, d, hp, NHL), (l & 1) == 0);
+            ldp += wide_coupling<TH, NHL, true, kSB>(c, mfma_layer(f.weights + l * f.layer_stride, d, hp, NHL), (l & 1) == 0);
         ldp += wide_ea<kEaInverse>(c, f.ea0_log_scale, f.ea0_shift, false);
         const float u = wide_potential_grad(c, pot, lane);
         wide_ea<kEaBackward>(c, f.ea0_log_scale, f.ea0_shift, false);
         for (int l = 0; l < f.n_coupling; ++l)
-            wide_coupling_backward<TH, NHL>(c, mfma_layer(f.weights + l * f.layer_stride, d, hp, NHL), (l & 1) == 0);
+            wide_coupling_backward<TH, NHL, kSB>(c, mfma_layer(f.weights + l * f.layer_stride, d, hp, NHL), (l & 1) == 0);
         wide_ea<kEaBackward>(c, f.ea1_log_scale, f.ea1_shift, rev_last);
         const float ut = u - chain_sum(ldp);
         if (active) {
@@ -451,10 +479,10 @@ __global__ void __launch_bounds__(kMfmaBlock, 2) realnvp_forward_wide_kernel(Nfm
         const bool active = row < n;
         const float* xr = x + (active ? row : n - 1) * d;
         c.xs = slab + row * d + 4 * c.q;
-        for (int m = 0; m < d / 16; ++m) tile_st(c.xs, m, vec_tile(xr, m, c.q));
+        wide_tiles(d / 16, [&](int m) { return vec_tile(xr, m, c.q); }, [&](int m, const f32x4& v) { tile_st(c.xs, m, v); });
         float ldp = wide_ea<kEaForward>(c, f.ea0_log_scale, f.ea0_shift, false);
         for (int l = 0; l < f.n_coupling; ++l)
-            ldp += wide_coupling<TH, NHL, false>(c, mfma_layer(f.weights + l * f.layer_stride, d, hp, NHL), (l & 1) == 0);
+            ldp += wide_coupling<TH, NHL, false, 4>(c, mfma_layer(f.weights + l * f.layer_stride, d, hp, NHL), (l & 1) == 0);
         ldp += wide_ea<kEaForward>(c, f.ea1_log_scale, f.ea1_shift, rev_last);
         const float ld = chain_sum(ldp);
         const float ss = wide_sum_squares(c);
@@ -488,7 +516,8 @@ __global__ void __launch_bounds__(kMfmaBlock, 2) realnvp_inverse_wide_kernel(Nfm
         c.xs = slab + row * d + 4 * c.q;
         if (z) {
             const float* zr = z + rrow * d;
-            for (int m = 0; m < d / 16; ++m) tile_st(c.xs, m, rev_last ? vec_tile_rev(zr, m, c.q, d) : vec_tile(zr, m, c.q));
+            wide_tiles(d / 16, [&](int m) { return rev_last ? vec_tile_rev(zr, m, c.q, d) : vec_tile(zr, m, c.q); },
+                       [&](int m, const f32x4& v) { tile_st(c.xs, m, v); });
         } else {   // Philox stream kTagLatent, one block per 4 consecutive logical coordinates (draw_latent_c's rule)
             const uint32_t gchain = (uint32_t)(rng.chain_offset + (uint64_t)rrow);
             for (int m = 0; m < d / 16; ++m) {
@@ -505,7 +534,7 @@ __global__ void __launch_bounds__(kMfmaBlock, 2) realnvp_inverse_wide_kernel(Nfm
         const float ss = wide_sum_squares(c);
         float ldp = wide_ea<kEaInverse>(c, f.ea1_log_scale, f.ea1_shift, rev_last);
         for (int l = f.n_coupling - 1; l >= 0; --l)
-            ldp += wide_coupling<TH, NHL, true>(c, mfma_layer(f.weights + l * f.layer_stride, d, hp, NHL), (l & 1) == 0);
+            ldp += wide_coupling<TH, NHL, true, 4>(c, mfma_layer(f.weights + l * f.layer_stride, d, hp, NHL), (l & 1) == 0);
         ldp += wide_ea<kEaInverse>(c, f.ea0_log_scale, f.ea0_shift, false);
         const float ld = chain_sum(ldp);
         if (active) {
@@ -530,6 +559,19 @@ int nfmc::nfmc_mfma_wide_supported(int32_t d, int32_t n_hidden, int32_t n_hidden
 
 // the scratch slab of one launch: stream-ordered allocation (the C entry points of these passes have no scratch argument)
 static int wide_slab(float** slab, int64_t tiles, int d, int copies, hipStream_t st) {
+    // keep freed slabs in the device's default pool across synchronisations (its default threshold of 0 hands the memory
+    // back at every sync: a real allocation of tens of MB per call)
+    static bool pooled = false;
+    if (!pooled) {
+        int dev = 0;
+        hipMemPool_t pool = nullptr;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
+            uint64_t keep = ~0ull;
+            (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+        }
+        (void)hipGetLastError();
+        pooled = true;
+    }
     hipError_t e = hipMallocAsync((void**)slab, (size_t)copies * tiles * kMfmaChains * d * sizeof(float), st);
     return e == hipSuccess ? NFMC_OK : (int)e;
 }
