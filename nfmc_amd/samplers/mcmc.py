@@ -611,11 +611,28 @@ class HMC(MetropolisSampler):
         L = self.kernel.n_leapfrog_steps
         n_grads = 2 * L * n                                   # hmc.py:122-125
         n_calls = n_grads + (2 * n if self.params.adjustment else 0)
+        # hmc.py:69,71 evaluates the gradient twice at every interior position (the second half step of one leapfrog, the
+        # first of the next) and hmc.py:103-110 the target again at both ends: 2 L + 2 calls, in that order -- kept for a
+        # user's callable, which may count or fail per call (tests/golden/hmc_fail_d5).  A caller that knows its target is a
+        # deterministic function (NeuTra's adjusted target on the flow kernels) sets `one_evaluation_per_position`: L + 1
+        # value-and-gradient calls return the same numbers (the fused kernels do the same; the reported n_calls / n_grads
+        # stay the reference's formulas).
+        merged = bool(getattr(self, 'one_evaluation_per_position', False))
+        u0 = u1 = None
         try:
-            for _ in range(L):
-                p = p - h / 2 * _guarded(_value_and_grad, self.target, q, self.event_shape)[1]
-                q = q + h * (p * m)
-                p = p - h / 2 * _guarded(_value_and_grad, self.target, q, self.event_shape)[1]
+            if merged:
+                u0, g = _guarded(_value_and_grad, self.target, q, self.event_shape)
+                u1 = u0
+                for _ in range(L):
+                    p = p - h / 2 * g
+                    q = q + h * (p * m)
+                    u1, g = _guarded(_value_and_grad, self.target, q, self.event_shape)
+                    p = p - h / 2 * g
+            else:
+                for _ in range(L):
+                    p = p - h / 2 * _guarded(_value_and_grad, self.target, q, self.event_shape)[1]
+                    q = q + h * (p * m)
+                    p = p - h / 2 * _guarded(_value_and_grad, self.target, q, self.event_shape)[1]
         except TargetFailure:
             return self._rejected_step(xf, n_calls, n_grads)  # hmc.py:117-120
         n_calls = n_grads
@@ -625,8 +642,11 @@ class HMC(MetropolisSampler):
         if self.params.adjustment:
             try:
                 with torch.no_grad():
-                    h0 = _guarded(self.target, xf.reshape(n, *self.event_shape)).reshape(-1) + 0.5 * (p0 ** 2 * m).sum(-1)
-                    h1 = _guarded(self.target, q.reshape(n, *self.event_shape)).reshape(-1) + 0.5 * (p ** 2 * m).sum(-1)
+                    if not merged:
+                        u0 = _guarded(self.target, xf.reshape(n, *self.event_shape)).reshape(-1)
+                        u1 = _guarded(self.target, q.reshape(n, *self.event_shape)).reshape(-1)
+                    h0 = u0.reshape(-1) + 0.5 * (p0 ** 2 * m).sum(-1)
+                    h1 = u1.reshape(-1) + 0.5 * (p ** 2 * m).sum(-1)
             except TargetFailure:
                 return self._rejected_step(xf, n_grads + 2 * n, n_grads)
             self._last_log_ratio = (h0 - h1).float().contiguous()

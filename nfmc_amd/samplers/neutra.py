@@ -150,6 +150,9 @@ class NeuTra(Sampler):
             # adjusted target (neutra.py:116-127)
             inner.seed, inner.shard, inner.replay = self.seed, self.shard, self.replay
             inner.rng_rounds = self.rng_rounds
+            # a closed-form target on the gradient kernel is a deterministic function of z: the split path's HMC evaluates
+            # the adjusted target once per position (a user's callable keeps the reference's 2 L + 2 calls per trajectory)
+            inner.one_evaluation_per_position = pot is not None and self._grad_kernel_ok
             out = inner.sample(x0, show_progress=show_progress, time_limit_seconds=time_limit_seconds)
             out.kernel.flow = self.kernel.flow
             return out
