@@ -296,7 +296,7 @@ int nfmc_flow_mh_supported_f32(const NfmcFlowMhArgs* args);
  * Same noise streams and results as
  * nfmc_flow_mh_steps_f32 (states and masks bit for bit; moments up to summation order).  Faster at every
  * chain count measured (3x at n = 1000, 1.15x at n = 65536, d = 64): few chains no longer leave the GPU idle, and the
- * accept uniforms are drawn once per (chain, step) instead of once per lane.  Requires adjusted = 1, n_hidden <= 8, n_steps <= NFMC_IMH_PARALLEL_MAX_STEPS;
+ * accept uniforms are drawn once per (chain, step) instead of once per lane.  Requires adjusted = 1, n_hidden <= 8 (affine or 8-bin spline couplings), n_steps <= NFMC_IMH_PARALLEL_MAX_STEPS;
  * `work` >= nfmc_imh_parallel_work_bytes(n, d, n_steps) bytes of device scratch, 16-byte aligned. */
 #define NFMC_IMH_PARALLEL_MAX_STEPS 65536
 int64_t nfmc_imh_parallel_work_bytes(int64_t n, int32_t d, int32_t n_steps);

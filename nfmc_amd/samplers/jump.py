@@ -144,7 +144,7 @@ def imh_parallel_ok(run: Run, flow, pot, logq) -> bool:
     LDS (nfmc_imh_parallel_supported_f32 decides).  It wins most when the chains alone do not fill the GPU (sequential
     transitions are latency-bound there), and still by 10-15 % when they do.  NFMC_IMH_PARALLEL=0 turns it off."""
     bij = getattr(flow, 'bijection', None)
-    if not flow_is_native(flow) or bij.n_hidden > 8 or bij.n_bins != 0 or bij.d > 512:
+    if not flow_is_native(flow) or bij.n_hidden > 8 or bij.d > 512:   # affine and spline couplings (imh_parallel_rqs.hip)
         return False
     # d = 64, 1000 steps, parallel vs sequential: 1.0 vs 3.0 ms at n = 1000, 1.98 vs 3.0 at 8192, 5.7 vs 6.7 at 32768,
     # 10.6 vs 12.3 at 65536 (one accept-uniform draw per row instead of per lane, no per-step select / moments)

@@ -1729,6 +1729,28 @@ def test_spline_flow_metropolis_on_the_register_layout_matches_oracle(dev, d, nh
     both = np.logical_and.accumulate(np.vstack([np.ones((1, n), bool), (got_m == t_m)[:-1]]), axis=0)
     assert both.mean() > 0.97
     assert (np.abs(got_lr - t_lr)[both] <= 2 * tol[both]).all()
+    # the data-parallel independence sampler with the same spline flow (imh_parallel_rqs.hip): the sequential register
+    # kernel's decisions, and its log-ratios and states to rounding (the spline arithmetic is compiled in two contexts;
+    # fused multiply-adds are contracted differently, unlike the affine flow, whose two paths agree bit for bit)
+    monkeypatch.delenv('NFMC_FLOW_TILE_PATH')
+    s = imh.FixedIMH((d,), pot, imh.IMHKernel((d,), flow=f), imh.IMHParameters(n_iterations=T))
+    s.seed = 4242
+    run = Run(s, x0)
+    logq = torch.empty(n, dtype=torch.float32, device=dev)
+    masks = torch.zeros(T, n, dtype=torch.uint8, device=dev)
+    lr = torch.zeros(T, n, dtype=torch.float32, device=dev)
+    samples = torch.zeros(T, n, d, dtype=torch.float32, device=dev)
+    if not jump.imh_parallel_ok(run, f, pot, logq):
+        assert d >= 100 and nh == 8   # the spline weight image of the 128-coordinate layout at width 8 exceeds the LDS
+        return
+    jump.launch_imh_parallel(run, f, pot, logq, T, 0, False, run.stats.struct(), samples, masks, lr)
+    torch.cuda.synchronize()
+    p_m = masks.cpu().numpy().astype(bool)
+    both = np.logical_and.accumulate(np.vstack([np.ones((1, n), bool), (got_m == p_m)[:-1]]), axis=0)
+    assert both.mean() > 0.99 and ((got_m == p_m) | ~both).mean() > 0.99
+    assert (np.abs(lr.cpu().numpy() - got_lr)[both] <= 0.2 * tol[both]).all()
+    follows = both[-1] & (got_m[-1] == p_m[-1])
+    np.testing.assert_allclose(samples.cpu().numpy()[-1][follows], got_x[-1][follows], atol=2e-5 * max(1.0, d / 64))
 
 
 @pytest.mark.parametrize('d,ck,kind', [(200, {}, 'realnvp'), (24, {'n_hidden': 40}, 'realnvp'), (10, {}, 'c-rqnsf')])
