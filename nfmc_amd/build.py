@@ -9,6 +9,7 @@ import concurrent.futures
 import hashlib
 import os
 import subprocess
+import time
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -34,8 +35,15 @@ UNIT_FLAGS = {'neutra_mfma.hip': ['-mllvm', '-amdgpu-promote-alloca-to-vector-li
               'mfma_wide.hip': ['-mllvm', '-amdgpu-promote-alloca-to-vector-limit=16']}
 
 
+# units that take a minute or more to compile go first, so that the pool finishes with the short ones
+# (NFMC_BUILD_TIMES=1 prints the time of each)
+SLOW_FIRST = ['flow_b_kernels.hip', 'neutra_kernels_r64.hip', 'neutra_kernels_r32.hip', 'neutra_kernels_r16.hip',
+              'imh_parallel_rqs.hip', 'imh_parallel.hip', 'fit_kernels.hip', 'neutra_mfma.hip']
+
+
 def sources():
-    return sorted(f for f in os.listdir(CSRC) if f.endswith('.hip'))
+    names = sorted(f for f in os.listdir(CSRC) if f.endswith('.hip'))
+    return [f for f in SLOW_FIRST if f in names] + [f for f in names if f not in SLOW_FIRST]
 
 
 def _digest():
@@ -55,9 +63,12 @@ def _digest():
 def _compile(src):
     obj = os.path.join(OBJ, src[:-4] + '.o')
     cmd = [HIPCC] + FLAGS + UNIT_FLAGS.get(src, []) + ['-c', os.path.join(CSRC, src), '-o', obj]
+    t0 = time.time()
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError('hipcc failed for %s:\n%s' % (src, r.stderr[-4000:]))
+    if os.environ.get('NFMC_BUILD_TIMES'):
+        print('[nfmc_amd.build] %-28s %6.1f s' % (src, time.time() - t0), flush=True)
     return obj
 
 

@@ -1,0 +1,4 @@
+// VALU NeuTra kernels with 32 chains per wave (neutra_kernels.hpp), every conditioner width bucket
+#include "neutra_kernels.hpp"
+
+NFMC_NEUTRA_RPW_UNIT(32)
