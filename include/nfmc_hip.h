@@ -326,9 +326,10 @@ typedef struct {
     int64_t scratch_bytes;
 } NfmcNeutraHmcArgs;
 
-/* 0 for the VALU path (n_hidden <= 32).  Matrix-core path: 2 (n, d) tiles + 2 (n,) vectors, plus the activation
+/* 0 for the VALU path (n_hidden <= 32).  Matrix-core path at d = 64 / 128: 2 (n, d) tiles + 2 (n,) vectors, plus the activation
  * checkpoints of the resident workgroups (hidden activations, alpha, beta of every coupling layer: the reverse sweep
- * reads them back instead of recomputing them) -- at most 256 workgroups x 128 chains, whatever n. */
+ * reads them back instead of recomputing them) -- at most 256 workgroups x 128 chains, whatever n.  At the other multiples
+ * of 32 (trajectory composed from the streamed gradient kernel, csrc/mfma_wide.hip): 4 (n, d) arrays + 3 (n,) vectors. */
 int64_t nfmc_neutra_scratch_bytes(int64_t n, int32_t d, int32_t n_hidden, int32_t n_hidden_layers, int32_t n_coupling);
 
 int nfmc_neutra_hmc_steps_f32(const NfmcNeutraHmcArgs* args, nfmc_stream_t stream);

@@ -547,6 +547,189 @@ __global__ void __launch_bounds__(kMfmaBlock, 2) realnvp_inverse_wide_kernel(Nfm
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// NeuTra HMC (neutra.py:109-129 over hmc.py:61-77,96-126) at these shapes: no fused trajectory kernel; the transition is
+// composed HERE, on the stream, from the gradient kernel above and three elementwise kernels -- momentum draw + H0 + the
+// first half / full step; the steps between two gradients; the Hamiltonian test, masked update and statistics -- with
+// the arithmetic, the Philox streams and the one-gradient-per-position leapfrog of neutra_leapfrog_mfma_kernel.
+// A wave owns a chain: lane l holds the 16-byte blocks l, l + 64, ... of its row (one block = one Philox block).
+struct WideHmc {
+    float *p, *gz, *zq, *gq, *uz, *h0, *uq;   // caller scratch: momentum, grad at the state, proposal position and its grad, U~, H0, U~ at the proposal
+};
+constexpr int kEwBlock = 256, kEwChains = kEwBlock / kWave;
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, const f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ f32x4 mass4(const float* m, int b) {
+    f32x4 one;
+    one[0] = one[1] = one[2] = one[3] = 1.f;
+    return m ? ld4(m + 4 * b) : one;
+}
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
+    return v;
+}
+
+__global__ void __launch_bounds__(kEwBlock) wide_hmc_begin_kernel(NfmcNeutraHmcArgs a, WideHmc w, int s) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int d = a.flow.d;
+    const int64_t n = a.n;
+    const float h = a.step_size, hh = a.step_size / 2;
+    for (int64_t row = (int64_t)blockIdx.x * kEwChains + wave; row < n; row += (int64_t)gridDim.x * kEwChains) {
+        const uint32_t gchain = (uint32_t)(a.rng.chain_offset + (uint64_t)row);
+        float kin = 0.f;
+        for (int b = lane; b < d / 4; b += kWave) {
+            float zz[4];
+            if (a.rng.replay_normals) {
+                const f32x4 r = ld4(a.rng.replay_normals + ((int64_t)s * n + row) * d + 4 * b);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) zz[j] = r[j];
+            } else {
+                philox_normal4(gchain, a.rng.step0 + (uint32_t)s, (uint32_t)b, kTagNoise, (uint32_t)a.rng.seed, (uint32_t)(a.rng.seed >> 32), zz);
+            }
+            const f32x4 mass = mass4(a.inv_mass_diag, b), g = ld4(w.gz + row * d + 4 * b);
+            f32x4 z = ld4(a.z + row * d + 4 * b), p;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float mm = mass[j];
+                float v = zz[j] * (1.f / sqrtf(mm));   // hmc.py:100
+                kin = fmaf(v * v, mm, kin);
+                v = fmaf(-hh, g[j], v);                 // hmc.py:68-70
+                p[j] = v;
+                z[j] = fmaf(h, v * mm, z[j]);
+            }
+            st4(w.p + row * d + 4 * b, p);
+            st4(w.zq + row * d + 4 * b, z);
+        }
+        kin = wave_sum_f(kin);
+        if (lane == 0) w.h0[row] = w.uz[row] + 0.5f * kin;   // hmc.py:103-106
+    }
+}
+
+// after the gradient at the new position: the closing half step of this leapfrog step and, unless it was the last, the
+// opening half step of the next (the same gradient) and the next position
+__global__ void __launch_bounds__(kEwBlock) wide_hmc_step_kernel(NfmcNeutraHmcArgs a, WideHmc w, int last) {
+    const int d = a.flow.d;
+    const int64_t blocks4 = a.n * (int64_t)(d / 4);
+    const float h = a.step_size, hh = a.step_size / 2;
+    for (int64_t e = (int64_t)blockIdx.x * kEwBlock + threadIdx.x; e < blocks4; e += (int64_t)gridDim.x * kEwBlock) {
+        const int b = (int)(e % (d / 4));
+        const f32x4 g = ld4(w.gq + 4 * e);
+        f32x4 p = ld4(w.p + 4 * e);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) p[j] = fmaf(-hh, g[j], p[j]);   // hmc.py:71
+        if (!last) {
+            const f32x4 mass = mass4(a.inv_mass_diag, b);
+            f32x4 z = ld4(w.zq + 4 * e);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                p[j] = fmaf(-hh, g[j], p[j]);
+                z[j] = fmaf(h, p[j] * mass[j], z[j]);
+            }
+            st4(w.zq + 4 * e, z);
+        }
+        st4(w.p + 4 * e, p);
+    }
+}
+
+// Hamiltonian test, masked update (state, its gradient and potential), kept row, statistics slab of the workgroup
+__global__ void __launch_bounds__(kEwBlock) wide_hmc_end_kernel(NfmcNeutraHmcArgs a, WideHmc w, int s, float* sample_row, int dp) {
+    __shared__ double red[kEwChains][2 * 512 + 2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int d = a.flow.d;
+    const int64_t n = a.n;
+    constexpr int kOwn = 512 / 4 / kWave;   // 16-byte blocks of a row a lane owns at most
+    double sx[kOwn][4], sxx[kOwn][4];
+#pragma unroll
+    for (int o = 0; o < kOwn; ++o)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sx[o][j] = sxx[o][j] = 0.0;
+    uint32_t n_acc = 0, n_bad = 0;
+    for (int64_t row = (int64_t)blockIdx.x * kEwChains + wave; row < n; row += (int64_t)gridDim.x * kEwChains) {
+        bool accept = true;
+        float lr = 0.f;
+        if (a.adjust) {
+            float kin = 0.f;
+            for (int b = lane; b < d / 4; b += kWave) {
+                const f32x4 mass = mass4(a.inv_mass_diag, b), p = ld4(w.p + row * d + 4 * b);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) kin = fmaf(p[j] * p[j], mass[j], kin);
+            }
+            kin = wave_sum_f(kin);
+            lr = w.h0[row] - (w.uq[row] + 0.5f * kin);   // hmc.py:107-111
+            float uni;
+            if (a.rng.replay_uniforms) {
+                uni = a.rng.replay_uniforms[(int64_t)s * n + row];
+            } else {
+                const uint32_t step = a.rng.step0 + (uint32_t)s;
+                const uint4 r = philox4x32_10((uint32_t)(a.rng.chain_offset + (uint64_t)row), step >> 2, 0u, kTagAccept, (uint32_t)a.rng.seed,
+                                              (uint32_t)(a.rng.seed >> 32));
+                uni = u32_to_uniform(pick_word(r, step & 3u));
+            }
+            accept = fast_ln(uni) < lr;   // hmc.py:112-113
+            if (lane == 0 && !(fabsf(lr) <= 3.0e38f)) n_bad++;
+        }
+        if (lane == 0) {
+            if (accept) {
+                w.uz[row] = w.uq[row];
+                n_acc++;
+            }
+            if (a.masks_out) a.masks_out[(int64_t)s * n + row] = accept ? 1 : 0;
+            if (a.log_ratio_out) a.log_ratio_out[(int64_t)s * n + row] = lr;
+        }
+#pragma unroll
+        for (int o = 0; o < kOwn; ++o) {
+            const int b = lane + o * kWave;
+            if (b < d / 4) {
+                f32x4 zc;
+                if (accept) {
+                    zc = ld4(w.zq + row * d + 4 * b);
+                    st4(a.z + row * d + 4 * b, zc);
+                    st4(w.gz + row * d + 4 * b, ld4(w.gq + row * d + 4 * b));
+                } else {
+                    zc = ld4(a.z + row * d + 4 * b);
+                }
+                if (sample_row) st4(sample_row + row * d + 4 * b, zc);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    sx[o][j] += (double)zc[j];
+                    sxx[o][j] += (double)zc[j] * (double)zc[j];
+                }
+            }
+        }
+    }
+    if (!a.stats.sum_x) return;
+#pragma unroll
+    for (int o = 0; o < kOwn; ++o) {
+        const int b = lane + o * kWave;
+        if (b < d / 4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                red[wave][4 * b + j] = sx[o][j];
+                red[wave][d + 4 * b + j] = sxx[o][j];
+            }
+        }
+    }
+    if (lane == 0) {
+        red[wave][2 * d] = (double)n_acc;
+        red[wave][2 * d + 1] = (double)n_bad;
+    }
+    __syncthreads();
+    double* out = a.stats.scratch + (size_t)blockIdx.x * (2 * dp + kStatTail);
+    for (int i = threadIdx.x; i < 2 * dp + kStatTail; i += kEwBlock) {
+        int srci = -1;
+        if (i < dp) srci = i < d ? i : -1;
+        else if (i < 2 * dp) srci = (i - dp) < d ? d + (i - dp) : -1;
+        else if (i == 2 * dp) srci = 2 * d;
+        else if (i == 2 * dp + 1) srci = 2 * d + 1;
+        double v = 0.0;
+        if (srci >= 0)
+            for (int wv = 0; wv < kEwChains; ++wv) v += red[wv][srci];
+        out[i] = v;
+    }
+}
+
 }  // namespace nfmc
 
 using namespace nfmc;
@@ -591,7 +774,11 @@ static int wide_slab(float** slab, int64_t tiles, int d, int copies, hipStream_t
 #define NFMC_WIDE_LAUNCH(KERNEL, THV, NHLV, ...)                                                                       \
     {                                                                                                                   \
         auto kern = KERNEL<THV, NHLV>;                                                                                  \
-        e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWideLdsBytes);     \
+        static bool attr_set = false;   /* once per kernel (process-wide: one device per process) */                    \
+        if (!attr_set) {                                                                                                \
+            e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWideLdsBytes); \
+            attr_set = e == hipSuccess;                                                                                 \
+        }                                                                                                               \
         if (e == hipSuccess) hipLaunchKernelGGL(kern, dim3(grid), dim3(kMfmaBlock), kWideLdsBytes, st, __VA_ARGS__);    \
     }
 
@@ -627,19 +814,100 @@ int nfmc::nfmc_realnvp_inverse_wide_f32(const NfmcRealNVP* flow, const float* z,
     return rc == NFMC_OK && fe != hipSuccess ? (int)fe : rc;
 }
 
-int nfmc::nfmc_neutra_potential_grad_wide_f32(const NfmcRealNVP* flow, const NfmcPotential* pot, const float* z, int64_t n,
-                                                   float* u_out, float* grad_out, nfmc_stream_t stream) {
+// the gradient kernel on a slab the caller holds (2 x tiles x 128 x d floats)
+static int grad_wide_launch(const NfmcRealNVP* flow, const NfmcPotential* pot, const float* z, int64_t n, float* u_out, float* grad_out,
+                            float* slab, hipStream_t st) {
+    const int64_t tiles = (n + kMfmaChains - 1) / kMfmaChains;
+    const int grid = (int)(tiles < kCkMaxGrid ? tiles : kCkMaxGrid);
+    int rc = NFMC_OK;
+    NFMC_WIDE_DISPATCH(neutra_grad_wide_kernel, *flow, *pot, z, n, u_out, grad_out, slab, tiles)
+    return rc;
+}
+
+static int grad_wide_check(const NfmcRealNVP* flow, const NfmcPotential* pot, const float* z, int64_t n, const float* grad_out) {
     if (!flow || !pot || !z || n <= 0) return NFMC_EINVAL;
     if (!nfmc_mfma_wide_supported(flow->d, flow->n_hidden, flow->n_hidden_layers)) return NFMC_EUNSUPPORTED;
     if (pot->kind != NFMC_POT_QUADRATIC && pot->kind != NFMC_POT_FUNNEL) return NFMC_EUNSUPPORTED;
     if ((((uintptr_t)z) & 15u) || (((uintptr_t)grad_out) & 15u)) return NFMC_EUNSUPPORTED;   // 16-byte tile IO
+    return NFMC_OK;
+}
+
+int nfmc::nfmc_neutra_potential_grad_wide_f32(const NfmcRealNVP* flow, const NfmcPotential* pot, const float* z, int64_t n,
+                                                   float* u_out, float* grad_out, nfmc_stream_t stream) {
+    int rc = grad_wide_check(flow, pot, z, n, grad_out);
+    if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     const int64_t tiles = (n + kMfmaChains - 1) / kMfmaChains;
-    const int grid = (int)(tiles < kCkMaxGrid ? tiles : kCkMaxGrid);
     float* slab = nullptr;
-    int rc = wide_slab(&slab, tiles, flow->d, 2, st);   // state and gradient
+    rc = wide_slab(&slab, tiles, flow->d, 2, st);   // state and gradient
     if (rc) return rc;
-    NFMC_WIDE_DISPATCH(neutra_grad_wide_kernel, *flow, *pot, z, n, u_out, grad_out, slab, tiles)
+    rc = grad_wide_launch(flow, pot, z, n, u_out, grad_out, slab, st);
     const hipError_t fe = hipFreeAsync(slab, st);
     return rc == NFMC_OK && fe != hipSuccess ? (int)fe : rc;
+}
+
+// scratch of the composed trajectory: p, gz, zq, gq (n d floats each), then uz, h0, uq (n each)
+int64_t nfmc::nfmc_neutra_wide_scratch_floats(int64_t n, int32_t d) { return 4 * n * (int64_t)d + 3 * n; }
+
+int nfmc::nfmc_neutra_hmc_steps_wide_f32(const NfmcNeutraHmcArgs* args, float* scratch, int64_t scratch_bytes, nfmc_stream_t stream) {
+    if (!args || !scratch) return NFMC_EINVAL;
+    const NfmcNeutraHmcArgs& a = *args;
+    const int d = a.flow.d;
+    const int64_t n = a.n;
+    if (!nfmc_mfma_wide_supported(d, a.flow.n_hidden, a.flow.n_hidden_layers)) return NFMC_EUNSUPPORTED;
+    if (scratch_bytes < nfmc_neutra_wide_scratch_floats(n, d) * (int64_t)sizeof(float)) return NFMC_ESCRATCH;
+    if ((((uintptr_t)a.z) | ((uintptr_t)scratch) | ((uintptr_t)a.inv_mass_diag) | ((uintptr_t)a.samples.base) |
+         ((uintptr_t)a.rng.replay_normals)) & 15u)
+        return NFMC_EUNSUPPORTED;   // 16-byte row blocks
+    hipStream_t st = (hipStream_t)stream;
+    WideHmc w;
+    w.p = scratch;
+    w.gz = w.p + n * d;
+    w.zq = w.gz + n * d;
+    w.gq = w.zq + n * d;
+    w.uz = w.gq + n * d;
+    w.h0 = w.uz + n;
+    w.uq = w.h0 + n;
+    const int dp = padded_d(d);
+    const int64_t groups = (n + kEwChains - 1) / kEwChains;
+    const int grid_c = (int)(groups < kMaxGrid ? groups : kMaxGrid);                      // one wave per chain
+    const int64_t eblocks = (n * (int64_t)(d / 4) + kEwBlock - 1) / kEwBlock;
+    const int grid_e = (int)(eblocks < 4 * kMaxGrid ? eblocks : 4 * kMaxGrid);            // one thread per 16-byte block
+    if (a.stats.sum_x && a.stats.scratch_bytes < (int64_t)grid_c * (2 * dp + kStatTail) * (int64_t)sizeof(double)) return NFMC_ESCRATCH;
+    int rc = grad_wide_check(&a.flow, &a.pot, a.z, n, w.gz);
+    if (rc) return rc;
+    // ONE slab for the gradients of the whole call (allocating per gradient cost 0.65 ms of host time each: the stream ran dry)
+    float* slab = nullptr;
+    if ((rc = wide_slab(&slab, (n + kMfmaChains - 1) / kMfmaChains, d, 2, st))) return rc;
+    // U~ and its gradient at the state (also after the caller changed z)
+    rc = grad_wide_launch(&a.flow, &a.pot, a.z, n, w.uz, w.gz, slab, st);
+    int countdown = a.samples.countdown, srow = a.samples.row;   // one pass per transition: the store cursor runs here
+    for (int s = 0; s < a.n_steps && rc == NFMC_OK; ++s) {
+        float* sample_row = nullptr;
+        if (a.samples.base) {
+            if (countdown > 0) {
+                --countdown;
+            } else {
+                sample_row = a.samples.base + (int64_t)srow * n * d;
+                srow = srow + 1 == a.samples.ring_rows ? 0 : srow + 1;
+                countdown = a.samples.stride - 1;
+            }
+        }
+        hipLaunchKernelGGL(wide_hmc_begin_kernel, dim3(grid_c), dim3(kEwBlock), 0, st, a, w, s);
+        for (int l = 0; l < a.n_leapfrog; ++l) {
+            rc = grad_wide_launch(&a.flow, &a.pot, w.zq, n, w.uq, w.gq, slab, st);
+            if (rc) break;
+            hipLaunchKernelGGL(wide_hmc_step_kernel, dim3(grid_e), dim3(kEwBlock), 0, st, a, w, l + 1 == a.n_leapfrog ? 1 : 0);
+        }
+        if (rc) break;
+        hipLaunchKernelGGL(wide_hmc_end_kernel, dim3(grid_c), dim3(kEwBlock), 0, st, a, w, s, sample_row, dp);
+        if (a.stats.sum_x)
+            hipLaunchKernelGGL(stats_finish_kernel<true>, dim3(stats_finish_grid(dp)), dim3(kFinishBlock), 0, st, a.stats.scratch, grid_c, dp, d,
+                               a.stats, (unsigned long long)n);
+    }
+    const hipError_t fe = hipFreeAsync(slab, st);
+    const hipError_t le = hipGetLastError();
+    if (rc) return rc;
+    if (fe != hipSuccess) return (int)fe;
+    return le == hipSuccess ? NFMC_OK : (int)le;
 }

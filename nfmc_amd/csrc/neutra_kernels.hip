@@ -10,6 +10,8 @@ using namespace nfmc;
 extern "C" int64_t nfmc_neutra_scratch_bytes(int64_t n, int32_t d, int32_t n_hidden, int32_t n_hidden_layers,
                                              int32_t n_coupling) {
     if (n <= 0 || d <= 0 || n_hidden <= 32 || n_hidden_layers <= 0 || n_coupling < 0) return 0;
+    if (nfmc_mfma_wide_supported(d, n_hidden, n_hidden_layers))   // the composed trajectory of mfma_wide.hip: four (n, d) arrays, three (n,)
+        return nfmc_neutra_wide_scratch_floats(n, d) * (int64_t)sizeof(float);
     // momentum, gradient, U~ and H0 of every chain, then the activation checkpoints of every resident wave
     // (mfma_flow.hpp: CkLayout -- hidden activations, alpha, beta of every coupling layer, 1 KB tiles)
     const int64_t th = nfmc_realnvp_padded_hidden(n_hidden) / 16, td = d / 16;

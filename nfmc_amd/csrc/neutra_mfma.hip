@@ -632,7 +632,8 @@ int nfmc::nfmc_neutra_hmc_steps_mfma_f32(const NfmcNeutraHmcArgs* args, float* s
                                               nfmc_stream_t stream) {
     if (!args || !scratch) return NFMC_EINVAL;
     const NfmcNeutraHmcArgs& a = *args;
-    if (!nfmc_mfma_supported(a.flow.d, a.flow.n_hidden, a.flow.n_hidden_layers)) return NFMC_EUNSUPPORTED;
+    if (!nfmc_mfma_supported(a.flow.d, a.flow.n_hidden, a.flow.n_hidden_layers))   // the other multiples of 32: composed (mfma_wide.hip)
+        return nfmc_neutra_hmc_steps_wide_f32(args, scratch, scratch_bytes, stream);
     if (scratch_bytes < nfmc_neutra_scratch_bytes(a.n, a.flow.d, a.flow.n_hidden, a.flow.n_hidden_layers, a.flow.n_coupling))
         return NFMC_ESCRATCH;
     const int td = a.flow.d / 16, th = nfmc_realnvp_padded_hidden(a.flow.n_hidden) / 16, nhl = a.flow.n_hidden_layers;

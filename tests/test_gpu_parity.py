@@ -1781,38 +1781,45 @@ def test_neutra_hmc_shapes_without_a_fused_kernel_match_oracle(dev, d, ck, kind)
     assert abs(out.statistics.n_accepted_trajectories - tr.n_accepted) <= 4
 
 
-@pytest.mark.parametrize('d,nh,cl,nl', [(256, 128, 2, 2), (512, 64, 1, 3)])
-def test_neutra_hmc_wide_events_and_wide_conditioners_stay_off_torch_autograd(dev, d, nh, cl, nl, monkeypatch):
-    """NeuTra HMC at d = 256 / 512 with a conditioner wider than 32: no fused trajectory kernel, so the sampler composes the
-    transition from the inner HMC's split path -- but the adjusted potential and its gradient now come from the streamed
-    matrix-core kernel (csrc/mfma_wide.hip), not from torch autograd through the restatement (the test fails if the
-    restatement is touched), and the trajectory still follows the oracle on the Philox streams."""
+@pytest.mark.parametrize('d,nh,cl,nl,mass', [(256, 128, 2, 2, False), (512, 64, 1, 3, True), (96, 100, 2, 2, True)])
+def test_neutra_hmc_wide_events_and_wide_conditioners_stay_off_torch_autograd(dev, d, nh, cl, nl, mass, monkeypatch):
+    """NeuTra HMC at d = 256 / 512 (any multiple of 32) with a conditioner wider than 32: `nfmc_neutra_hmc_steps_f32` composes
+    the trajectory on the stream from the streamed matrix-core gradient kernel and three elementwise kernels
+    (csrc/mfma_wide.hip: no Python between the leapfrog steps, no torch autograd -- the test fails if the split path or the
+    torch restatement is touched), one gradient per position, and follows the oracle on the Philox streams: kept states,
+    acceptance count, moments; with and without a mass diagonal."""
     from nfmc_amd.samplers import neutra, mcmc
     from nfmc_amd import flow_training
     from nfmc_amd.flows import Flow, RealNVP
     from nfmc_amd.potentials import SumOfSquares
     from oracle import flow as oflow, potentials as opot, samplers as osamp
-    n, T, L, h = 150, 2, 10, 0.02
+    n, T, L, h = 150, 3, 10, 0.02
     ck = {'n_hidden': nh, 'n_layers': cl}
     torch.manual_seed(d + nh)
     of = oflow.perturb_(oflow.Flow(oflow.RealNVP((d,), n_layers=nl, conditioner_kwargs=ck)), 9, 0.05)
     f = Flow(RealNVP((d,), n_layers=nl, conditioner_kwargs=ck))
     f.load_state_dict(of.state_dict())
     z0 = 0.5 * torch.randn(n, d)
+    imd = torch.linspace(0.8, 1.3, d) if mass else None
 
     def boom(*a, **k):
-        raise AssertionError('the torch restatement of the flow was differentiated: no gradient kernel served this shape')
+        raise AssertionError('the split path / the torch restatement of the flow was used: no kernel served this shape')
     monkeypatch.setattr(flow_training, 'inverse_torch', boom)
-    s = neutra.NeuTraHMC((d,), SumOfSquares((d,)), mcmc.HMCKernel(event_size=d, n_leapfrog_steps=L, step_size=h),
-                         mcmc.HMCParameters(), neutra.NeuTraKernel((d,), flow=f), neutra.NeuTraParameters(n_iterations=T))
+    kern = mcmc.HMCKernel(event_size=d, n_leapfrog_steps=L, step_size=h, **({'inv_mass_diag': imd.clone()} if mass else {}))
+    s = neutra.NeuTraHMC((d,), SumOfSquares((d,)), kern, mcmc.HMCParameters(), neutra.NeuTraKernel((d,), flow=f),
+                         neutra.NeuTraParameters(n_iterations=T))
+    s.inner_sampler.sample = boom
     s.seed = 78
     out = s.sample(z0, show_progress=False)
-    tr = osamp.neutra_hmc_sample(z0, opot.sum_squares, of, T, h, None, L, noise=osamp.PhiloxNoise(78))
+    tr = osamp.neutra_hmc_sample(z0, opot.sum_squares, of, T, h, imd, L, noise=osamp.PhiloxNoise(78))
     got, want = out.samples.reshape(T, n, d), tr.stacked()
     same = (got - want).abs().amax(dim=(0, 2)) < 5e-4
     assert same.float().mean() > 0.9, float(same.float().mean())
+    np.testing.assert_allclose(got[:, same].numpy(), want[:, same].numpy(), atol=5e-4, rtol=0)
     assert out.statistics.n_attempted_trajectories == n * T
     assert abs(out.statistics.n_accepted_trajectories - tr.n_accepted) <= 4
+    np.testing.assert_allclose(out.mean.numpy(), tr.moments.first.numpy(), atol=3e-3)
+    np.testing.assert_allclose(out.second_moment.numpy(), tr.moments.second.numpy(), atol=5e-3)
 
 
 @pytest.mark.parametrize('d,nh', [(200, None), (256, None), (300, 8), (512, None), (511, 16)])
