@@ -329,6 +329,39 @@ def test_C4_neutra_hmc_65536x128_full_size_properties(dev):
     assert torch.equal(part.running_samples.last_sample, la[lo:hi])
 
 
+def test_wide_event_neutra_hmc_32768x256_full_size_properties(dev):
+    """C5's event size and per-GPU chain count with C4's conditioner (d = 256, 32768 chains, conditioner 128 x 2, funnel,
+    L = 10): no fused trajectory kernel exists for d > 128, `nfmc_neutra_hmc_steps_f32` composes the trajectory from the
+    streamed matrix-core gradient kernel (csrc/mfma_wide.hip; 256 chain tiles over 256 workgroup slots).  Finite states,
+    acceptance, run-twice bitwise identity and shard invariance (chain-id keyed noise, private slab rows)."""
+    from nfmc_amd.dist import Shard
+    d, n, T, L, h = 256, 32768, 2, 10, 0.02
+    torch.manual_seed(11)
+    _of, f = _pair_flows(d, 13, 0.05, ck={'n_hidden': 128, 'n_layers': 2})
+    z0 = 0.5 * torch.randn(n, d, generator=torch.Generator().manual_seed(5))
+
+    def run(shard=None):
+        s = _c4_sampler(f, T, L, h, d=d)
+        _no_split(s)
+        s.params.store_samples = False
+        s.seed = 9
+        s.shard = shard
+        return s.sample(z0, show_progress=False)
+
+    a, b = run(), run()
+    la = a.running_samples.last_sample
+    assert torch.isfinite(la).all()
+    assert a.statistics.n_attempted_trajectories == n * T
+    assert a.statistics.acceptance_rate > 0.6
+    assert torch.equal(la, b.running_samples.last_sample)
+    assert a.statistics.n_accepted_trajectories == b.statistics.n_accepted_trajectories
+    sh = Shard(rank=3, world=8)
+    sh.merge_statistics = lambda s_: s_
+    lo, hi = sh.bounds(n)
+    part = run(sh)
+    assert torch.equal(part.running_samples.last_sample, la[lo:hi])
+
+
 def test_C4_more_chain_tiles_than_workgroup_slots(dev):
     """The trajectory kernel runs at most 256 workgroups (one activation-checkpoint area per workgroup slot and wave,
     mfma_flow.hpp: CkLayout); with more than 256 x 128 chains a workgroup walks several chain tiles and reuses its
