@@ -420,7 +420,7 @@ __global__ void __launch_bounds__(kBlock, (CPL == 8 && HP == 4 && FAST && NB == 
             if (__ballot(have && !initial) != 0ull) {
                 float f_xp, u_xp;
                 imh_propose<CPL, LPC, HP>(xs, f_xp, u_xp, a, fl, pot, i, s, g, revl, base_c);
-                if (correct && imh_summed(u_xp, f_xp)) wgt -= 1.f;   // the proposal kernel counted it once
+                if (correct && !initial && imh_summed(u_xp, f_xp)) wgt -= 1.f;   // the proposal kernel counted it once (an initial state sharing the pass: never)
             }
             if (initial) load_row<CPL, LPC, FAST>(w.x0, i, d, g, true, xs);
             if (have) {

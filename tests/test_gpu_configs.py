@@ -362,6 +362,42 @@ def test_wide_event_neutra_hmc_32768x256_full_size_properties(dev):
     assert torch.equal(part.running_samples.last_sample, la[lo:hi])
 
 
+def test_wide_event_kernels_with_more_chain_tiles_than_workgroup_slots(dev):
+    """The streamed matrix-core kernels run at most 256 workgroups; with more than 256 x 128 chains a workgroup walks
+    several chain tiles (grid stride) and every lane group keeps its private slab row.  40000 chains = 313 tiles: gradient,
+    potential, forward and inverse of every chain must equal, bit for bit, what the same chain gets in a batch that holds
+    only the chains past the first 256 tiles (odd batch: the last tile is partly idle)."""
+    import ctypes as C
+    from nfmc_amd import hip
+    from nfmc_amd.potentials import Funnel
+    d, n, cut = 256, 40000, 256 * 128
+    torch.manual_seed(3)
+    _of, f = _pair_flows(d, 13, 0.05, ck={'n_hidden': 128, 'n_layers': 2})
+    z = (0.5 * torch.randn(n, d, generator=torch.Generator().manual_seed(6))).to(dev)
+    st, _keep = f.bijection.packed(dev)
+    pd = Funnel((d,), 3.0).descriptor(dev)
+
+    def grad(zz):
+        m = zz.shape[0]
+        u = torch.full((m,), float('nan'), device=dev)
+        g = torch.full((m, d), float('nan'), device=dev)
+        hip.check(hip.lib().nfmc_neutra_potential_grad_f32(C.byref(st), C.byref(pd), hip.ptr(zz), m, hip.ptr(u), hip.ptr(g), hip.stream()),
+                  'nfmc_neutra_potential_grad_f32')
+        return u, g
+
+    u, g = grad(z)
+    ut, gt = grad(z[cut:].contiguous())
+    assert torch.isfinite(u).all() and torch.isfinite(g).all()
+    assert torch.equal(u[cut:], ut) and torch.equal(g[cut:], gt)
+    x, ld = f.bijection.inverse(z)
+    xt, ldt = f.bijection.inverse(z[cut:].contiguous())
+    assert torch.equal(x[cut:], xt) and torch.equal(ld[cut:], ldt)
+    zz, ldf = f.bijection.forward(x)
+    zt, ldft = f.bijection.forward(x[cut:].contiguous())
+    assert torch.equal(zz[cut:], zt) and torch.equal(ldf[cut:], ldft)
+    np.testing.assert_allclose(zz.cpu().numpy(), z.cpu().numpy(), atol=2e-4)   # round trip
+
+
 def test_C4_more_chain_tiles_than_workgroup_slots(dev):
     """The trajectory kernel runs at most 256 workgroups (one activation-checkpoint area per workgroup slot and wave,
     mfma_flow.hpp: CkLayout); with more than 256 x 128 chains a workgroup walks several chain tiles and reuses its

@@ -1679,6 +1679,64 @@ def test_register_flow_metropolis_matches_oracle_in_every_layout(dev, d, nh, cl,
     assert want_m.any() or d >= 100   # small flows are close enough to the target for acceptances to happen
 
 
+@pytest.mark.parametrize('accepting', [True, False])
+@pytest.mark.parametrize('n,k', [(1, 1), (1, 57), (63, 27), (64, 28), (65, 29), (129, 55), (200, 56), (70, 113), (300, 1)])
+def test_data_parallel_imh_equals_sequential_kernel_at_block_and_tile_edges(dev, n, k, accepting, monkeypatch):
+    """The data-parallel independence sampler (imh_parallel.hpp) at the edges of its blocking: step counts around the scan's
+    28-step mask words and two-block iterations (1, 27, 28, 29, 55, 56, 57, 113), chain counts around the 64-lane scan
+    waves and the 64-row tiles of the proposal / replay kernels (1, 63, 64, 65, 129, ...).  With a flow close to the target
+    most proposals are accepted (the replay CORRECTS the proposal pass's sums), with a mismatched one few are (it SUMS the
+    accepted rows).  Final states, kept states, masks, log-ratios and counters equal the sequential kernel's bit for bit;
+    moments to summation order."""
+    from nfmc_amd.samplers import imh
+    from nfmc_amd.flows import Flow, RealNVP
+    from nfmc_amd.potentials import SumOfSquares
+    from oracle import flow as oflow
+    d = 16
+    torch.manual_seed(n * 1000 + k)
+    of = oflow.Flow(oflow.RealNVP((d,)))
+    if accepting:   # identity couplings + the target's scale, slightly perturbed: the proposals are almost draws of N(0, I/2)
+        with torch.no_grad():
+            for prm in of.parameters():
+                prm.zero_()
+        of = oflow.perturb_(of, 5, 0.05, 0.5 ** 0.5)
+    else:
+        of = oflow.perturb_(of, 5, 0.3, 1.5)
+    x0 = 0.7 * torch.randn(n, d)
+    outs = []
+    for par in ('1', '0'):
+        monkeypatch.setenv('NFMC_IMH_PARALLEL', par)
+        f = Flow(RealNVP((d,)))
+        f.load_state_dict(of.state_dict())
+        s = imh.FixedIMH((d,), SumOfSquares((d,)), imh.IMHKernel((d,), flow=f), imh.IMHParameters(n_iterations=k))
+        s.seed = 31
+        outs.append(s.sample(x0, show_progress=False))
+    a, b = outs
+    assert torch.equal(a.running_samples.last_sample, b.running_samples.last_sample)
+    assert torch.equal(a.samples, b.samples)
+    assert a.statistics.n_accepted_trajectories == b.statistics.n_accepted_trajectories
+    assert a.statistics.n_attempted_trajectories == b.statistics.n_attempted_trajectories == n * k
+    rate = a.statistics.n_accepted_trajectories / (n * k)
+    if n * k >= 1000:   # above 0.62 the replay corrects the proposal pass's sums, below it sums the accepted rows
+        assert (rate > 0.65) if accepting else (rate < 0.5), rate
+    np.testing.assert_allclose(a.mean.numpy(), b.mean.numpy(), atol=2e-5)
+    np.testing.assert_allclose(a.second_moment.numpy(), b.second_moment.numpy(), atol=2e-5)
+    # without the sample store (the path the bench takes: the correcting replay is allowed)
+    outs = []
+    for par in ('1', '0'):
+        monkeypatch.setenv('NFMC_IMH_PARALLEL', par)
+        f = Flow(RealNVP((d,)))
+        f.load_state_dict(of.state_dict())
+        s = imh.FixedIMH((d,), SumOfSquares((d,)), imh.IMHKernel((d,), flow=f), imh.IMHParameters(n_iterations=k, store_samples=False))
+        s.seed = 31
+        outs.append(s.sample(x0, show_progress=False))
+    a, b = outs
+    assert torch.equal(a.running_samples.last_sample, b.running_samples.last_sample)
+    assert a.statistics.n_accepted_trajectories == b.statistics.n_accepted_trajectories
+    np.testing.assert_allclose(a.mean.numpy(), b.mean.numpy(), atol=2e-5)
+    np.testing.assert_allclose(a.second_moment.numpy(), b.second_moment.numpy(), atol=2e-5)
+
+
 @pytest.mark.parametrize('d,nh,cl,nl', [(4, 3, 1, 2), (16, 4, 2, 2), (24, 3, 1, 2), (64, 4, 2, 2), (64, 8, 2, 3), (100, 8, 2, 2),
                                         (128, 4, 2, 2)])
 def test_spline_flow_metropolis_on_the_register_layout_matches_oracle(dev, d, nh, cl, nl, monkeypatch):
