@@ -513,18 +513,19 @@ def _reference_window(dense, thinning, max_samples):
 
 
 @pytest.mark.parametrize('strategy', ['mala', 'hmc', 'mh', 'imh', 'imh_seq', 'jump_mala', 'jump_hmc', 'jump_mala_tail',
-                                      'neutra_hmc', 'neutra_hmc_wide', 'jump_mala_wide', 'mala_callable'])
+                                      'neutra_hmc', 'neutra_hmc_wide', 'neutra_hmc_streamed', 'jump_mala_wide', 'mala_callable'])
 @pytest.mark.parametrize('thinning,max_samples', [(3, None), (1, 5), (4, 3), (7, 100)])
 def test_thinning_and_max_samples_are_applied_on_the_device(dev, strategy, thinning, max_samples, monkeypatch):
     """f3 (sampling/base.py:249-263): with `thinning` / `max_samples` the kernels write only the states that survive, into
     a device slab of at most max_samples rows; the result equals the dense run (same seed) cut by the reference's rule,
     bit for bit, on every kernel family: register samplers (+ fused jump tail), register / tile / matrix-core flow-MH,
-    data-parallel and sequential IMH, VALU and matrix-core NeuTra, and the split path of a plain callable."""
+    data-parallel and sequential IMH, VALU and matrix-core NeuTra (register-resident at d = 64, composed from the streamed
+    kernels at d = 96), and the split path of a plain callable."""
     from nfmc_amd import sample
     from nfmc_amd.containers import DeviceSampleStore
     from nfmc_amd.potentials import SumOfSquares
     from nfmc_amd.samplers import jump
-    d, n, T = 64, 70, 23
+    d, n, T = (96 if strategy == 'neutra_hmc_streamed' else 64), 70, 23
     kw = dict(show_progress=False, seed=5, n_chains=n)
     target = SumOfSquares((d,))
     base = strategy
@@ -543,8 +544,8 @@ def test_thinning_and_max_samples_are_applied_on_the_device(dev, strategy, thinn
     if strategy.startswith('neutra_hmc'):
         base, T = 'neutra_hmc', 9
         kw['inner_kernel_kwargs'] = {'n_leapfrog_steps': 2, 'step_size': 0.02}
-        kw['flow_kwargs'] = {'conditioner_kwargs': {'n_hidden': 64 if strategy.endswith('wide') else 8, 'n_layers': 1}}
-        if not strategy.endswith('wide'):
+        kw['flow_kwargs'] = {'conditioner_kwargs': {'n_hidden': 8 if strategy == 'neutra_hmc' else 64, 'n_layers': 1}}
+        if strategy == 'neutra_hmc':
             monkeypatch.setenv('NFMC_NEUTRA_VALU', '1')
     if strategy in ('hmc',):
         kw['kernel_kwargs'] = {'n_leapfrog_steps': 3, 'step_size': 0.05}
