@@ -318,7 +318,7 @@ FLOW_CASES = [(6, 2, None, 2), (7, 3, 5, 3), (25, 2, None, 2), (64, 2, None, 2),
               (32, 2, 64, 2), (96, 3, 128, 1), (160, 2, 100, 2), (320, 3, 64, 2), (448, 2, 128, 2)]
 
 
-@pytest.mark.parametrize('d,nl,nh,cl', [(6, 2, None, 2), (64, 3, 16, 2), (64, 2, 64, 2), (33, 4, 7, 1)])
+@pytest.mark.parametrize('d,nl,nh,cl', [(6, 2, None, 2), (64, 3, 16, 2), (64, 2, 64, 2), (33, 4, 7, 1), (96, 3, 64, 1), (256, 2, 128, 2)])
 def test_nice_flow_matches_oracle(dev, d, nl, nh, cl):
     """'nice' (nfmc/util.py:13): additive couplings through the same kernels (min_scale = 1): forward / inverse /
     log_prob vs the oracle, exact volume preservation of the couplings, round trip, sampling and NeuTra gradient."""
@@ -1680,19 +1680,19 @@ def test_register_flow_metropolis_matches_oracle_in_every_layout(dev, d, nh, cl,
 
 
 @pytest.mark.parametrize('accepting', [True, False])
-@pytest.mark.parametrize('n,k', [(1, 1), (1, 57), (63, 27), (64, 28), (65, 29), (129, 55), (200, 56), (70, 113), (300, 1)])
-def test_data_parallel_imh_equals_sequential_kernel_at_block_and_tile_edges(dev, n, k, accepting, monkeypatch):
+@pytest.mark.parametrize('n,k,d', [(1, 1, 16), (1, 57, 16), (63, 27, 16), (64, 28, 16), (65, 29, 16), (129, 55, 16), (200, 56, 16),
+                                   (70, 113, 16), (300, 1, 16), (70, 57, 25), (33, 85, 6)])
+def test_data_parallel_imh_equals_sequential_kernel_at_block_and_tile_edges(dev, n, k, d, accepting, monkeypatch):
     """The data-parallel independence sampler (imh_parallel.hpp) at the edges of its blocking: step counts around the scan's
     28-step mask words and two-block iterations (1, 27, 28, 29, 55, 56, 57, 113), chain counts around the 64-lane scan
     waves and the 64-row tiles of the proposal / replay kernels (1, 63, 64, 65, 129, ...).  With a flow close to the target
     most proposals are accepted (the replay CORRECTS the proposal pass's sums), with a mismatched one few are (it SUMS the
-    accepted rows).  Final states, kept states, masks, log-ratios and counters equal the sequential kernel's bit for bit;
+    accepted rows); exact-fit (d = 16) and ragged (d = 25, 6) register layouts.  Final states, kept states, masks, log-ratios and counters equal the sequential kernel's bit for bit;
     moments to summation order."""
     from nfmc_amd.samplers import imh
     from nfmc_amd.flows import Flow, RealNVP
     from nfmc_amd.potentials import SumOfSquares
     from oracle import flow as oflow
-    d = 16
     torch.manual_seed(n * 1000 + k)
     of = oflow.Flow(oflow.RealNVP((d,)))
     if accepting:   # identity couplings + the target's scale, slightly perturbed: the proposals are almost draws of N(0, I/2)
