@@ -672,3 +672,61 @@ def test_flow_fit_survives_non_finite_losses():
     with pytest.raises(ValueError):
         ft.variational_fit(f, lambda x: torch.full((x.shape[0],), float('nan')), n_epochs=2, n_samples=8,
                            check_for_divergences=True)
+
+
+# ------------------------------------------------------------------------------------------------ code-object metadata
+def _gfx950_kernels(path):
+    """Kernel metadata (AMDGPU msgpack note) of every gfx950 code object bundled in a shared library."""
+    import re
+    import struct
+    import msgpack
+    data = open(path, 'rb').read()
+    magic = b'__CLANG_OFFLOAD_BUNDLE__'
+    for m in re.finditer(magic, data):
+        b0 = m.start()
+        n, = struct.unpack_from('<Q', data, b0 + len(magic))
+        p = b0 + len(magic) + 8
+        for _ in range(n):
+            off, size, tl = struct.unpack_from('<QQQ', data, p)
+            triple = data[p + 24:p + 24 + tl].decode()
+            p += 24 + tl
+            if 'gfx950' not in triple or not size:
+                continue
+            elf = data[b0 + off:b0 + off + size]
+            assert elf[:4] == b'\x7fELF'
+            shoff, = struct.unpack_from('<Q', elf, 0x28)
+            shentsize, shnum = struct.unpack_from('<HH', elf, 0x3A)
+            for i in range(shnum):
+                sh = elf[shoff + i * shentsize: shoff + (i + 1) * shentsize]
+                if struct.unpack_from('<I', sh, 4)[0] != 7:   # SHT_NOTE
+                    continue
+                q, size_n = struct.unpack_from('<QQ', sh, 0x18)
+                end = q + size_n
+                while q < end:
+                    namesz, descsz, ntype = struct.unpack_from('<III', elf, q)
+                    q += 12
+                    name = elf[q:q + namesz]
+                    q += (namesz + 3) & ~3
+                    desc = elf[q:q + descsz]
+                    q += (descsz + 3) & ~3
+                    if ntype == 32 and name.startswith(b'AMDGPU'):
+                        for k in msgpack.unpackb(desc, raw=False, strict_map_key=False).get('amdhsa.kernels', []):
+                            yield k
+
+
+def test_hand_counted_memory_waits_see_no_compiler_inserted_memory_operations():
+    """`imh_scan_kernel` (csrc/imh_parallel.hpp) requests its records with inline `global_load_dwordx3` and waits with
+    `s_waitcnt vmcnt(N)`, N counted by hand from the memory operations between request and use.  A register spill would put
+    scratch stores / loads in between that the count does not know about.  The shipped code object must therefore show no
+    scratch and no spills for these kernels (a lane has up to 512 registers there: one wave per SIMD)."""
+    from nfmc_amd import build
+    lib = build.build(verbose=False)
+    seen = 0
+    for k in _gfx950_kernels(lib):
+        if 'imh_scan_kernel' not in k['.name']:
+            continue
+        seen += 1
+        assert k['.private_segment_fixed_size'] == 0, k['.name']
+        assert k.get('.vgpr_spill_count', 0) == 0 and k.get('.sgpr_spill_count', 0) == 0, k['.name']
+        assert k['.vgpr_count'] <= 512
+    assert seen >= 2   # with and without the per-step outputs, in the affine and the spline unit
