@@ -367,6 +367,21 @@ __device__ __forceinline__ float* store_row_of(const NfmcSampleStore& s, int t, 
     if (!s.base || k < 0 || k % s.stride != 0) return nullptr;
     return s.base + (int64_t)((s.row + k / s.stride) % s.ring_rows) * nd;
 }
+// f(row pointer) for every KEPT transition t of the call in [t0, t1), in order: one division for the run instead of three
+// per transition (the replay writes a state that lasted c steps into every kept row of those c: with thinning most of
+// the c lookups found nothing, 0.8 ms of a 1.1 ms replay at the C2 shape with every 250th state kept)
+template <class F>
+__device__ __forceinline__ void store_rows_in(const NfmcSampleStore& s, int t0, int t1, int64_t nd, F f) {
+    if (!s.base) return;
+    int k0 = t0 - s.countdown;
+    if (k0 < 0) k0 = 0;
+    const int j = (k0 + s.stride - 1) / s.stride;             // first kept index at or after t0
+    int row = (s.row + j) % s.ring_rows;
+    for (int t = s.countdown + j * s.stride; t < t1; t += s.stride) {
+        f(s.base + (int64_t)row * nd);
+        row = row + 1 == s.ring_rows ? 0 : row + 1;
+    }
+}
 // the store descriptor of the NEXT launch after one that offered k transitions (host side of StoreCursor)
 inline void store_advance(NfmcSampleStore& s, int k) {
     if (!s.base) return;

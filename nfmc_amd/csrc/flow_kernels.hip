@@ -326,7 +326,10 @@ extern "C" int nfmc_realnvp_forward_f32(const NfmcRealNVP* flow, const float* x,
     if (rc) return rc;
     if (!x || n <= 0) return NFMC_EINVAL;
     if (use_mfma_flow(flow) && al16(x) && al16(z)) return nfmc_realnvp_forward_mfma_f32(flow, x, n, z, logdet, log_prob, stream);
-    if (use_mfma_wide(flow) && al16(x) && al16(z)) return nfmc_realnvp_forward_wide_f32(flow, x, n, z, logdet, log_prob, stream);
+    if (use_mfma_wide(flow) && al16(x) && al16(z)) {   // "unsupported" from there = no stream-ordered allocator: the kernels below
+        rc = nfmc_realnvp_forward_wide_f32(flow, x, n, z, logdet, log_prob, stream);
+        if (rc != NFMC_EUNSUPPORTED) return rc;
+    }
     const int64_t tiles = (n + 63) / 64;
     const int grid = (int)(tiles < 4 * kMaxGrid ? tiles : 4 * kMaxGrid);
     const size_t lds = (size_t)64 * tile_stride(flow->d) * sizeof(float) + hbuf_bytes(flow->n_hidden);
@@ -350,7 +353,10 @@ extern "C" int nfmc_realnvp_inverse_f32(const NfmcRealNVP* flow, const float* z,
     if (int rr = rng_default_only(r)) return rr;
     r.replay_normals = nullptr;  // explicit latents come through `z`
     if (use_mfma_flow(flow) && al16(x) && al16(z)) return nfmc_realnvp_inverse_mfma_f32(flow, z, n, x, logdet, log_q, &r, stream);
-    if (use_mfma_wide(flow) && al16(x) && al16(z)) return nfmc_realnvp_inverse_wide_f32(flow, z, n, x, logdet, log_q, &r, stream);
+    if (use_mfma_wide(flow) && al16(x) && al16(z)) {
+        rc = nfmc_realnvp_inverse_wide_f32(flow, z, n, x, logdet, log_q, &r, stream);
+        if (rc != NFMC_EUNSUPPORTED) return rc;
+    }
     const int64_t tiles = (n + 63) / 64;
     const int grid = (int)(tiles < 4 * kMaxGrid ? tiles : 4 * kMaxGrid);
     const size_t lds = (size_t)64 * tile_stride(flow->d) * sizeof(float) + hbuf_bytes(flow->n_hidden);

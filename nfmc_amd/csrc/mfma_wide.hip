@@ -756,6 +756,10 @@ static int wide_slab(float** slab, int64_t tiles, int d, int copies, hipStream_t
         pooled = true;
     }
     hipError_t e = hipMallocAsync((void**)slab, (size_t)copies * tiles * kMfmaChains * d * sizeof(float), st);
+    if (e == hipErrorNotSupported) {   // no stream-ordered allocator on this device / driver: the caller takes its other route
+        (void)hipGetLastError();
+        return NFMC_EUNSUPPORTED;
+    }
     return e == hipSuccess ? NFMC_OK : (int)e;
 }
 
