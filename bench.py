@@ -422,7 +422,8 @@ def _pmc(cfg_name, kernel):
     summary's file name, and whether it is STALE: profiled on a library whose source digest (`nfmc_build_digest()`)
     differs from the one loaded now (None: the summary predates the digest)."""
     from nfmc_amd import hip
-    for name in ('r03_%s_pmc_summary.json' % cfg_name.lower(), 'r02_%s_pmc_summary.json' % cfg_name.lower(),
+    for name in ('r04_%s_pmc_summary.json' % cfg_name.lower(), 'r03_%s_pmc_summary.json' % cfg_name.lower(),
+                 'r02_%s_pmc_summary.json' % cfg_name.lower(),
                  'r02_bench_pmc_summary.json', 'r01_bench_pmc_summary.json'):
         p = os.path.join(ROOT, 'profiles', name)
         if os.path.exists(p):
@@ -504,8 +505,14 @@ def roofline(cfg_name, cfg, n_local, mean_ms, launches, transitions_per_launch):
         # one nfmc_imh_parallel_f32 call covers ALL steps of a run: the PMC passes (tools/profile_bench.sh: --steps 3)
         # counted 3 * 50 transitions per call, the live call has transitions_per_launch of them
         scale = transitions_per_launch / (PMC_STEPS * cfg['inner'])
-        pm = {k: (v * scale if isinstance(v, (int, float)) and k.startswith('SQ_INSTS') else v) for k, v in pm.items()}
+        # every per-launch EXTENSIVE counter scales with the transitions of the call (instructions, bytes, busy cycles);
+        # GRBM_GUI_ACTIVE too, so that the busy ratio stays the PMC run's
+        pm = {k: (v * scale if isinstance(v, (int, float)) and (k.startswith('SQ_') or k in ('FETCH_SIZE', 'WRITE_SIZE',
+                                                                                            'GRBM_GUI_ACTIVE')) else v)
+              for k, v in pm.items()}
         insts = pm.get('SQ_INSTS_VALU')
+        if 'FETCH_SIZE' in pm and 'WRITE_SIZE' in pm:
+            traffic = (2 * pm['FETCH_SIZE'] + pm['WRITE_SIZE']) * 1024
     issue = insts / secs / 1e9 if (insts and secs) else None
     r.update(bound='valu', achieved=ach, peak=FP32_PEAK_TFLOPS, unit='TFLOP/s',
              frac=(ach / FP32_PEAK_TFLOPS) if ach else None, traffic=traffic,
@@ -528,62 +535,19 @@ def roofline(cfg_name, cfg, n_local, mean_ms, launches, transitions_per_launch):
     return r
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=50,
-                    help='untimed steps before the timed repetitions; the default covers the ~30 ms the clocks take to ramp '
-                         'under load (with 2 the first two of five repetitions were 5-12 %% slower than the last)')
-    ap.add_argument('--reps', type=int, default=5, help='timed repetitions of K steps; value = median (SURVEY 8d)')
-    ap.add_argument('--config', choices=sorted(CONFIGS), default='C3')
-    ap.add_argument('--fit-nf', action='store_true', help='jump strategies: refit the flow every outer iteration, so the '
-                                                          'all-gather of the refit buffer (C1) is on the measured path')
-    ap.add_argument('--rng-rounds', type=int, choices=[10, 7], default=10,
-                    help='Philox4x32 rounds of the noise stream: 10 = the library default (what `value` is quoted on); 7 = the '
-                         'opt-in stream.  With the default, C3 / C5 also time the 7-round stream and report it as `philox7`')
-    ap.add_argument('--unfitted-flow', action='store_true',
-                    help='jump configs: keep the randomly initialised proposal flow (round 1-2 behaviour: ~0.2 %% of the jumps '
-                         'accepted) instead of fitting it once, before any timing, as `warmup=True` would')
-    ap.add_argument('--backend', choices=['nccl', 'gloo'], default='nccl')
-    ap.add_argument('--rehearse', action='store_true', help='launcher / rendezvous / reduction only, no GPU work')
-    ap.add_argument('--share-device', action='store_true',
-                    help='(rehearsal on a one-GPU box, with --backend gloo) every rank computes on cuda:0: the whole N-rank '
-                         'bench path -- launcher, sharding, collectives, reductions -- with real kernels; not a measurement')
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-kernel-events', action='store_true', help='(experiment) no HIP events in the timed region')
-    args = ap.parse_args()
-    args.reps = max(1, args.reps)
-
-    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
-        launch_ranks(args.gpus)   # does not return
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if args.rehearse:
-        return rehearse(args, rank, world)
-
+def measure(name, args, env, reps, min_busy_s, philox7=True, cpu_legs=True, unfitted=False):
+    """One config measured by the protocol of the module docstring; returns the JSON line's dict on rank 0 (None elsewhere).
+    `reps` timed repetitions of exactly K steps at least, more of the same until the repetitions add up to `min_busy_s`
+    seconds of back-to-back GPU work (so that an outside sampler of GPU utilisation sees the run); value = their median."""
     import torch
-    cfg = CONFIGS[args.config]
-    # NFMC_BENCH_FORCE_DIST=1: take the multi-rank code path (RCCL init, barriers, collectives) with one rank
-    distributed = world > 1 or os.environ.get('NFMC_BENCH_FORCE_DIST') == '1'
-    if args.share_device:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
-    dist = None
-    if distributed:
-        import torch.distributed as dist
-        _quiet_init(args.backend, rank, world, dev)
-    from nfmc_amd.dist import Shard
-    shard = Shard(rank=rank, world=world) if distributed else None
-
+    dev, world, rank, dist, shard = env['dev'], env['world'], env['rank'], env['dist'], env['shard']
+    distributed = dist is not None
+    cfg = dict(CONFIGS[name])
     n_local = cfg['n_per_gpu']
     n_total = n_local * world
-    cfg = dict(cfg)
     cfg['_flow_state'] = None
-    if not args.unfitted_flow:
-        cfg['_flow_state'] = fitted_flow_state(args.config, cfg, dev)   # deterministic: every rank fits the same flow
+    if not unfitted:
+        cfg['_flow_state'] = fitted_flow_state(name, cfg, dev)   # deterministic: every rank fits the same flow
     x_start = initial_state(cfg, n_total).to(dev)   # resident in HBM before any timed region
 
     def run(n_steps, x, time_kernels=False, rounds=None):
@@ -600,7 +564,7 @@ def main():
         torch.cuda.synchronize(dev)
         if distributed:
             dist.barrier()
-        return time.perf_counter() - t0, out
+        return time.perf_counter() - t0, out, s
 
     def carried(out, x_prev):
         """The state after a run as the next run's x0 (global shape: every rank writes back its own block)."""
@@ -626,31 +590,34 @@ def main():
     gc.collect()
     gc.disable()
     if args.warmup > 0:   # untimed; moves the state from x0 ~ N(0, I) to stationarity
-        _dt, wout = run(args.warmup, x_start)
+        _dt, wout, _s = run(args.warmup, x_start)
         x_start = carried(wout, x_start)
-    reps = []
     label = cfg['label']
-    # R repetitions WITHOUT events give `value` (an event pair per launch costs ~6 us of stream time: 3-4 % of a C3 step,
-    # measured); one more repetition of the same K steps, same brackets, WITH HIP events on the launch stream around
-    # every launch of the dominant kernel gives the roofline's launch duration (`events_rep_ms` is its wall time)
-    for i in range(args.reps + (0 if args.no_kernel_events else 1)):
-        timed_launches = (i == args.reps)
-        dt, out = run(args.steps, x_start, time_kernels=label if timed_launches else False)
+    # R (or more, see min_busy_s) repetitions WITHOUT events give `value` (an event pair per launch costs ~6 us of stream
+    # time: 3-4 % of a C3 step, measured); one more repetition of the same K steps, same brackets, WITH HIP events on the
+    # launch stream around every launch of the dominant kernel gives the roofline's launch duration (`events_rep_ms`)
+    reps_dt, reps_rank, out, sampler = [], [], None, None
+    busy = 0.0
+    while len(reps_dt) < reps or busy < min_busy_s:   # every rank sees the same max-reduced times: same decision everywhere
+        dt, out, sampler = run(args.steps, x_start)
         dt_max, per_rank = _reduce_times(dt, world, dist, dev)
-        ev = [a.elapsed_time(b) for (l, a, b) in (getattr(out, 'kernel_events', None) or []) if l == label]
-        if timed_launches:
-            events_rep = (dt_max, ev)
-        else:
-            reps.append((dt_max, per_rank, out, ev))
-    if args.no_kernel_events:
-        events_rep = (None, [])
+        reps_dt.append(dt_max)
+        reps_rank.append(per_rank)
+        busy += dt_max
+        if len(reps_dt) >= 100000:
+            break
+    events_rep = (None, [])
+    if not args.no_kernel_events:
+        dt, eout, _s = run(args.steps, x_start, time_kernels=label)
+        dt_max, _pr = _reduce_times(dt, world, dist, dev)
+        events_rep = (dt_max, [a.elapsed_time(b) for (l, a, b) in (getattr(eout, 'kernel_events', None) or []) if l == label])
     # the opt-in Philox4x32-7 stream next to the default (three repetitions, same protocol): a reported side figure
     alt = None
-    if args.rng_rounds == 10 and cfg['strategy'] in ('jump_mala', 'jump_hmc') and not args.fit_nf:
+    if philox7 and args.rng_rounds == 10 and cfg['strategy'] in ('jump_mala', 'jump_hmc') and not args.fit_nf:
         alt_reps, ev_all7 = [], []
         for i7 in range(3 if args.no_kernel_events else 4):
             timed_launches = (i7 == 3)
-            dt7, out7 = run(args.steps, x_start, time_kernels=label if timed_launches else False, rounds=7)
+            dt7, out7, _s = run(args.steps, x_start, time_kernels=label if timed_launches else False, rounds=7)
             dt7_max, _pr = _reduce_times(dt7, world, dist, dev)
             if timed_launches:
                 ev_all7 = [a.elapsed_time(b) for (l, a, b) in (getattr(out7, 'kernel_events', None) or []) if l == label]
@@ -666,64 +633,170 @@ def main():
                'note': 'Philox4x32-7 (sample(..., rng_rounds=7)): the fewest rounds Random123 reports as passing BigCrush; '
                        'opt-in, never what `value` is quoted on'}
     gc.enable()
+    if rank != 0:
+        return None
 
+    order = sorted(range(len(reps_dt)), key=lambda i: reps_dt[i])
+    med = order[len(order) // 2]
+    dt, per_rank = reps_dt[med], reps_rank[med]     # every repetition starts from the same state with the same seed:
+    all_ev = list(events_rep[1])                    # `out` (the last one) is the outcome of each of them
+    # what one HIP-event pair brackets: one launch of the inner kernel (C3: 100 MALA transitions, C5: 5
+    # trajectories); for C4 one nfmc_neutra_hmc_steps_f32 call = K trajectory launches; for C2 one
+    # nfmc_imh_parallel_f32 call = the three kernels of K*50 transitions (reported as ONE "launch")
+    launches_per_event = args.steps if cfg['strategy'] == 'neutra_hmc' else 1
+    mean_ms = (sum(all_ev) / len(all_ev) / launches_per_event) if all_ev else None
+    n_launches = len(all_ev) * launches_per_event
+    transitions_per_launch = cfg['inner'] * (args.steps if cfg['strategy'] == 'imh' else 1)
+    st = out.statistics
+    value = n_total * cfg['transitions_per_step'] * args.steps / dt
+    rep_ms = [1e3 * v for v in reps_dt]
+    line = {
+        'metric': cfg['metric'], 'value': value, 'unit': 'chain-steps/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': cfg['workload'], 'name': name, 'n_chains_total': n_total,
+                   'n_chains_per_gpu': n_local, 'n_dim': cfg['d'], 'inner_steps': cfg['inner'],
+                   'transitions_per_step': cfg['transitions_per_step'], 'store_samples': False,
+                   'x0': 'N(0, I), torch.manual_seed(0) on the CPU, uploaded before timing; W warm-up steps carry it '
+                         'to stationarity' + (' (x 0.5 for the unfitted funnel run)'
+                                              if cfg['strategy'] == 'neutra_hmc' and cfg['_flow_state'] is None else ''),
+                   'fit_nf': bool(args.fit_nf),
+                   'proposal_flow': ('default RealNVP, weights seed 1' + (
+                       ', fitted ONCE before timing (jump configs: Flow.fit, maximum likelihood, device path, on 4096 draws of the '
+                       'target; imh: Flow.variational_fit on the device, 300 epochs; neutra_hmc: Flow.variational_fit, 200 '
+                       'epochs, step size 0.3): the state warmup=True leaves'
+                       if cfg['_flow_state'] is not None else
+                       ' (unfitted)' if cfg['strategy'] != 'imh' else ' (unfitted, proposal scale matched: _match_scale_)')),
+                   'sharding': f'chains x{world}, no data-path collective; one statistics all-reduce per sample()'
+                               + ('; refit-buffer all-gather every outer iteration' if args.fit_nf else '')},
+        'repetitions': len(rep_ms), 'rep_ms': rep_ms[:reps], 'rep_ms_median': statistics.median(rep_ms),
+        'events_rep_ms': (1e3 * events_rep[0]) if events_rep[0] is not None else None,
+        'rep_ms_min': min(rep_ms), 'rep_ms_max': max(rep_ms),
+        'rep_ms_p10_p90': [sorted(rep_ms)[len(rep_ms) // 10], sorted(rep_ms)[(9 * len(rep_ms)) // 10]],
+        'timed_busy_s': busy,
+        'world_size_reported_by_backend': dist.get_world_size() if dist is not None else 1,
+        'backend': dist.get_backend() if dist is not None else None,
+        'per_rank_ms': [1e3 * v for v in per_rank],
+        'roofline': roofline(name, cfg, n_local, mean_ms, n_launches, transitions_per_launch),
+        'parity': {'mean_abs_max': float(out.mean.abs().max()), 'variance_mean': float(out.variance.mean()),
+                   'mcmc_acceptance': st.acceptance_rate},
+    }
+    if cfg['strategy'] != 'neutra_hmc':   # U = sum x^2: N(0, I/2)
+        line['parity']['variance_rel_err_max'] = float(((out.variance - 0.5).abs() / 0.5).max())
+        line['parity']['second_moment_rel_err_max'] = float(((out.second_moment - 0.5).abs() / 0.5).max())
+    else:
+        # NeuTra's statistics are moments of the LATENT z (the reference's quirk); the target's own
+        # marginal is checked on the chains' final states mapped to x = f^-1(z): funnel x_0 ~ N(0, 3^2)
+        with torch.no_grad():
+            z_last = out.running_samples.last_sample.reshape(-1, cfg['d']).to(dev)
+            x_last = sampler.kernel.flow.bijection.inverse(z_last)[0]
+            x0c = x_last[:, 0].double()
+        line['parity']['funnel_x0_marginal'] = {
+            'mean': float(x0c.mean()), 'var': float(x0c.var()), 'expected_mean': 0.0, 'expected_var': 9.0,
+            'chains': int(x0c.numel()), 'transitions_from_x0': args.warmup + args.steps,
+            'note': 'over the chains at the last state; the chains start at N(0, I), so the variance approaches 9 from below with W'}
+    if hasattr(st, 'jump_acceptance_rate'):
+        line['parity']['jump_acceptance'] = st.jump_acceptance_rate
+    line['config']['rng'] = 'Philox4x32-%d, chain-id keyed (oracle/philox.py)' % args.rng_rounds
+    if alt is not None:
+        line['philox7'] = alt
+    if world == 1 and cpu_legs:
+        line['parity']['vs_cpu_oracle_same_seeds'] = parity_vs_oracle(cfg, dev)
+    line['cpu_baseline'] = cpu_baseline(cfg) if (world == 1 and cpu_legs is True and not args.no_cpu_baseline) else None
+    return line
+
+
+def _brief(line):
+    """What `other_configs` keeps of a config's line."""
+    r = line['roofline']
+    return {'metric': line['metric'], 'value': line['value'], 'unit': line['unit'], 'ms_per_step': line['ms_per_step'],
+            'repetitions': line['repetitions'], 'rep_ms': line['rep_ms'], 'timed_busy_s': line['timed_busy_s'],
+            'workload': line['config']['workload'],
+            'roofline': {k: r.get(k) for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'mean_launch_ms',
+                                               'launches', 'pmc_source', 'pmc_stale', 'mfma_busy_frac', 'valu_busy_frac_pmc',
+                                               'hbm_real_frac')},
+            'parity': line['parity']}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=50,
+                    help='untimed steps before the timed repetitions; the default covers the ~30 ms the clocks take to ramp '
+                         'under load (with 2 the first two of five repetitions were 5-12 %% slower than the last)')
+    ap.add_argument('--reps', type=int, default=5, help='timed repetitions of K steps at least; value = median (SURVEY 8d)')
+    ap.add_argument('--min-busy-s', type=float, default=6.0,
+                    help='keep repeating the K-step repetition until the timed repetitions add up to this many seconds of '
+                         'back-to-back GPU work (the headline config; value stays the median of ALL repetitions): a 6 ms '
+                         'repetition x 5 is invisible to a utilisation sampler')
+    ap.add_argument('--config', choices=sorted(CONFIGS), default='C3')
+    ap.add_argument('--fit-nf', action='store_true', help='jump strategies: refit the flow every outer iteration, so the '
+                                                          'all-gather of the refit buffer (C1) is on the measured path')
+    ap.add_argument('--rng-rounds', type=int, choices=[10, 7], default=10,
+                    help='Philox4x32 rounds of the noise stream: 10 = the library default (what `value` is quoted on); 7 = the '
+                         'opt-in stream.  With the default, C3 / C5 also time the 7-round stream and report it as `philox7`')
+    ap.add_argument('--unfitted-flow', action='store_true',
+                    help='jump configs: keep the randomly initialised proposal flow (round 1-2 behaviour: ~0.2 %% of the jumps '
+                         'accepted) instead of fitting it once, before any timing, as `warmup=True` would')
+    ap.add_argument('--no-other-configs', action='store_true',
+                    help='the default single-GPU C3 run also measures C2, C4 and the C5 shard (3 repetitions each, >= 1 s of GPU '
+                         'work each, same protocol) and the unfitted-flow variants of C3 / C4, and attaches them to the ONE '
+                         'JSON line as `other_configs` / `unfitted_flow`; this switch keeps the line to the headline config')
+    ap.add_argument('--backend', choices=['nccl', 'gloo'], default='nccl')
+    ap.add_argument('--rehearse', action='store_true', help='launcher / rendezvous / reduction only, no GPU work')
+    ap.add_argument('--share-device', action='store_true',
+                    help='(rehearsal on a one-GPU box, with --backend gloo) every rank computes on cuda:0: the whole N-rank '
+                         'bench path -- launcher, sharding, collectives, reductions -- with real kernels; not a measurement')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-events', action='store_true', help='(experiment) no HIP events in the timed region')
+    args = ap.parse_args()
+    args.reps = max(1, args.reps)
+
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        launch_ranks(args.gpus)   # does not return
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.rehearse:
+        return rehearse(args, rank, world)
+
+    import torch
+    # NFMC_BENCH_FORCE_DIST=1: take the multi-rank code path (RCCL init, barriers, collectives) with one rank
+    distributed = world > 1 or os.environ.get('NFMC_BENCH_FORCE_DIST') == '1'
+    if args.share_device:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    dist = None
+    if distributed:
+        import torch.distributed as dist
+        _quiet_init(args.backend, rank, world, dev)
+    from nfmc_amd.dist import Shard
+    shard = Shard(rank=rank, world=world) if distributed else None
+    env = {'dev': dev, 'world': world, 'rank': rank, 'dist': dist, 'shard': shard}
+
+    line = measure(args.config, args, env, args.reps, args.min_busy_s, unfitted=args.unfitted_flow)
+    extras = (world == 1 and args.config == 'C3' and not args.fit_nf and not args.unfitted_flow and not args.no_other_configs
+              and args.rng_rounds == 10)
+    if extras:
+        # driver-visible evidence for every GPU config of BASELINE.json (VERDICT r03 #2): same protocol, 3+ repetitions and
+        # >= 1 s of GPU work each, roofline and the same-seed CPU-oracle leg; no CPU throughput baseline (the headline has it)
+        others = {}
+        for other in ('C2', 'C4', 'C5'):
+            sub = measure(other, args, env, 3, 1.0, philox7=False, cpu_legs='parity')
+            others[other] = _brief(sub)
+        line['other_configs'] = others
+        # the round 1-2 workload next to the fitted one (ADVICE r03: the default changed; keep the figures comparable)
+        unf = {}
+        for other in ('C3', 'C4'):
+            sub = measure(other, args, env, 3, 0.5, philox7=False, cpu_legs=False, unfitted=True)
+            unf[other] = {'value': sub['value'], 'ms_per_step': sub['ms_per_step'], 'rep_ms': sub['rep_ms'],
+                          'mcmc_acceptance': sub['parity']['mcmc_acceptance'],
+                          'jump_acceptance': sub['parity'].get('jump_acceptance'),
+                          'proposal_flow': sub['config']['proposal_flow']}
+        line['unfitted_flow'] = unf
     if rank == 0:
-        order = sorted(range(len(reps)), key=lambda i: reps[i][0])
-        med = order[len(order) // 2]
-        dt, per_rank, out, _ev = reps[med]
-        all_ev = list(events_rep[1])
-        # what one HIP-event pair brackets: one launch of the inner kernel (C3: 100 MALA transitions, C5: 5
-        # trajectories); for C4 one nfmc_neutra_hmc_steps_f32 call = K trajectory launches; for C2 one
-        # nfmc_imh_parallel_f32 call = the three kernels of K*50 transitions (reported as ONE "launch")
-        launches_per_event = args.steps if cfg['strategy'] == 'neutra_hmc' else 1
-        mean_ms = (sum(all_ev) / len(all_ev) / launches_per_event) if all_ev else None
-        n_launches = len(all_ev) * launches_per_event
-        transitions_per_launch = cfg['inner'] * (args.steps if cfg['strategy'] == 'imh' else 1)
-        st = out.statistics
-        value = n_total * cfg['transitions_per_step'] * args.steps / dt
-        rep_ms = [1e3 * r_[0] for r_ in reps]
-        line = {
-            'metric': cfg['metric'], 'value': value, 'unit': 'chain-steps/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': cfg['workload'], 'name': args.config, 'n_chains_total': n_total,
-                       'n_chains_per_gpu': n_local, 'n_dim': cfg['d'], 'inner_steps': cfg['inner'],
-                       'transitions_per_step': cfg['transitions_per_step'], 'store_samples': False,
-                       'x0': 'N(0, I), torch.manual_seed(0) on the CPU, uploaded before timing; W warm-up steps carry it '
-                             'to stationarity' + (' (x 0.5 for the unfitted funnel run)'
-                                                  if cfg['strategy'] == 'neutra_hmc' and cfg['_flow_state'] is None else ''),
-                       'fit_nf': bool(args.fit_nf),
-                       'proposal_flow': ('default RealNVP, weights seed 1' + (
-                           ', fitted ONCE before timing (jump configs: Flow.fit, maximum likelihood, device path, on 4096 draws of the '
-                           'target; imh: Flow.variational_fit on the device, 300 epochs; neutra_hmc: Flow.variational_fit, 200 '
-                           'epochs, step size 0.3): the state warmup=True leaves'
-                           if cfg['_flow_state'] is not None else
-                           ' (unfitted)' if cfg['strategy'] != 'imh' else ' (unfitted, proposal scale matched: _match_scale_)')),
-                       'sharding': f'chains x{world}, no data-path collective; one statistics all-reduce per sample()'
-                                   + ('; refit-buffer all-gather every outer iteration' if args.fit_nf else '')},
-            'repetitions': len(reps), 'rep_ms': rep_ms, 'rep_ms_median': statistics.median(rep_ms),
-            'events_rep_ms': (1e3 * events_rep[0]) if events_rep[0] is not None else None,
-            'rep_ms_min': min(rep_ms), 'rep_ms_max': max(rep_ms),
-            'world_size_reported_by_backend': dist.get_world_size() if dist is not None else 1,
-            'backend': dist.get_backend() if dist is not None else None,
-            'per_rank_ms': [1e3 * v for v in per_rank],
-            'roofline': roofline(args.config, cfg, n_local, mean_ms, n_launches, transitions_per_launch),
-            'parity': {'mean_abs_max': float(out.mean.abs().max()), 'variance_mean': float(out.variance.mean()),
-                       'mcmc_acceptance': st.acceptance_rate},
-        }
-        if cfg['strategy'] != 'neutra_hmc':   # U = sum x^2: N(0, I/2)
-            line['parity']['variance_rel_err_max'] = float(((out.variance - 0.5).abs() / 0.5).max())
-            line['parity']['second_moment_rel_err_max'] = float(((out.second_moment - 0.5).abs() / 0.5).max())
-        if hasattr(st, 'jump_acceptance_rate'):
-            line['parity']['jump_acceptance'] = st.jump_acceptance_rate
-        line['config']['rng'] = 'Philox4x32-%d, chain-id keyed (oracle/philox.py)' % args.rng_rounds
-        if alt is not None:
-            line['philox7'] = alt
-        if world == 1 and not args.no_cpu_baseline:
-            line['parity']['vs_cpu_oracle_same_seeds'] = parity_vs_oracle(cfg, dev)
-            line['cpu_baseline'] = cpu_baseline(cfg)
-        else:
-            line['cpu_baseline'] = None
         print(json.dumps(line), flush=True)
     if distributed:
         dist.destroy_process_group()

@@ -30,7 +30,7 @@ extern "C" {
 
 typedef void* nfmc_stream_t; /* hipStream_t */
 
-#define NFMC_ABI_VERSION 3
+#define NFMC_ABI_VERSION 4
 
 enum {
     NFMC_OK = 0,
@@ -390,7 +390,9 @@ int nfmc_philox_uniforms_f32(const NfmcRng* rng, int32_t tag, int64_t n, float* 
  * (ea0 log-scale, ea0 shift, ea1 log-scale, ea1 shift; d4 = d rounded up to 4 floats each) -- and `flow`'s pointers must be
  * views of it (weights = params, ea0_log_scale = params + ea_off, ...), so the sampling kernels see every step at once.
  * Shapes: affine / additive couplings (n_bins = 0), n_hidden <= 32, one or two hidden layers, d <= 256
- * (nfmc_flow_fit_supported_f32); other flows are trained by the host package's torch path. */
+ * (nfmc_flow_fit_supported_f32); other flows are trained by the host package's torch path.
+ * Conditioners of width <= 8 (every default flow) run on the row-per-wave kernel (csrc/fit_rows.hpp: up to 1024 waves per
+ * launch); it needs `params` 16-byte aligned and layer_stride, ea_off multiples of 4 floats (NFMC_EALIGN otherwise). */
 typedef struct {
     float lr, beta1, beta2, eps, weight_decay;
     int32_t step;             /* 1-based count of applied steps, for the bias corrections */
@@ -412,7 +414,38 @@ typedef struct {
     int64_t n_val;
     float* params_prev;       /* optional (n_params): receives the parameters as they were BEFORE the step -- what the
                                  validation loss of this call belongs to (best-weights bookkeeping without a second launch) */
+    float* best;              /* runs (nfmc_flow_fit_epochs_f32) with keep_best_weights: (n_params) the weights the best
+                                 monitored loss so far belongs to; call 0 initialises it with the starting weights */
+    float* run_state;         /* runs: device, 2 x NFMC_FIT_STATE_FLOATS floats (call c reads half c & 1, writes the other) */
 } NfmcFlowFit;
+
+/* The epoch loop of `Flow.fit` / `Flow.variational_fit` (torchflows, as nfmc drives it: jump.py:139-151 early stopping +
+ * keep_best_weights + ValueError on divergence; imh.py:67-72; neutra.py:84-91) with its bookkeeping ON THE DEVICE: call c of
+ * a run computes the batch loss (and the validation loss) at the weights w_c, decides -- in the fold kernel -- whether the
+ * monitored loss improved (best weights <- w_c with validation rows, w_{c+1} without), whether to stop early, whether the
+ * run diverged (non-finite loss), and applies the AdamW step unless the run has ended; calls after the end are no-ops.
+ * The host enqueues any number of calls and reads `run_state` when it wants to (at the end; every few epochs under a time
+ * limit).  With validation rows the run has n_epochs + 1 calls: the last one (index n_epochs) only evaluates. */
+typedef struct {
+    int32_t n_epochs;                 /* optimiser steps of the run at most */
+    int32_t early_stopping;           /* stop once the monitored loss has not improved for more than `threshold` epochs */
+    int32_t early_stopping_threshold;
+    int32_t keep_best_weights;        /* maintain NfmcFlowFit.best */
+    int32_t skip_nonfinite;           /* a non-finite batch loss skips the epoch (variational fits with
+                                         check_for_divergences = False) instead of ending the run as diverged */
+    int32_t reserved;
+} NfmcFitControl;
+enum {
+    NFMC_FIT_BEST_LOSS = 0,    /* best monitored loss so far (+inf before the first booked epoch) */
+    NFMC_FIT_SINCE_BEST = 1,   /* booked epochs since it improved */
+    NFMC_FIT_APPLIED = 2,      /* optimiser steps applied (AdamW's bias corrections use applied + 1) */
+    NFMC_FIT_STOPPED = 3,      /* 1: early stopping ended the run */
+    NFMC_FIT_DIVERGED = 4,     /* 1: a non-finite loss ended the run (the host package raises ValueError) */
+    NFMC_FIT_LAST_LOSS = 5,    /* batch loss of the latest live call */
+    NFMC_FIT_LAST_VAL = 6,     /* validation loss of the latest live call */
+    NFMC_FIT_BOOKED = 7,       /* epochs whose monitored loss has been booked */
+    NFMC_FIT_STATE_FLOATS = 8
+};
 
 int nfmc_flow_fit_supported_f32(const NfmcRealNVP* flow);
 int64_t nfmc_flow_fit_partial_floats(int64_t n, int64_t n_params);
@@ -422,6 +455,37 @@ int nfmc_flow_fit_step_f32(const NfmcFlowFit* fit, const float* x, int64_t n, co
  * with -log p = the closed-form potential `pot` (its gradient is evaluated in the kernel). */
 int nfmc_flow_variational_fit_step_f32(const NfmcFlowFit* fit, const NfmcPotential* pot, const float* z, int64_t n,
                                        const NfmcAdamW* opt, nfmc_stream_t stream);
+/* Calls first_call .. first_call + n_calls - 1 of a run (see NfmcFitControl), enqueued back to back: pot = NULL maximum
+ * likelihood on rows x (n, d), else the variational fit on latents; call c uses the rows at x + (c - first_call) *
+ * epoch_stride floats (0: the same rows every epoch; variational fits draw fresh latents per epoch).  AdamW's moments
+ * count as zero at call 0 and `opt->step` is ignored (the device counts applied steps). */
+int nfmc_flow_fit_epochs_f32(const NfmcFlowFit* fit, const NfmcPotential* pot, const float* x, int64_t n,
+                             int64_t epoch_stride, const NfmcAdamW* opt, const NfmcFitControl* ctl, int32_t first_call,
+                             int32_t n_calls, nfmc_stream_t stream);
+
+/* nn.Parameters <-> trainable vector in ONE launch.  A piece is one parameter tensor, contiguous (rows, cols) floats at
+ * `param`, whose element (r, c) lives at vec[vec_off + r * vec_row_stride + c * vec_col_stride] (the blob stores the first
+ * conditioner layer transposed and every hidden width padded).  to_vector = 1 gathers the parameters into the vector,
+ * 0 scatters the vector into them.  Replaces one slice copy per tensor of `Flow.fit`'s epilogue / prologue. */
+#define NFMC_BLOB_MAX_PIECES 16
+typedef struct {
+    float* param;
+    int64_t vec_off;
+    int32_t rows, cols;
+    int32_t vec_row_stride, vec_col_stride;
+} NfmcBlobPiece;
+int nfmc_flow_blob_copy_f32(float* vec, const NfmcBlobPiece* pieces, int32_t n_pieces, int32_t to_vector, nfmc_stream_t stream);
+
+/* The shuffled split of the refit buffer (`train_val_split`, tuning.py:44-65: pooled rows shuffled by torch.randperm, cut
+ * at train_pct, capped) without materialising a permutation of all N rows: out[i] = x[pi(first + i)], i < m, with pi a
+ * keyed pseudo-random PERMUTATION of [0, N) (6-round balanced Feistel network on ceil(log2 N) bits + cycle walking, keys
+ * from `seed` by splitmix64; nfmc_rows_sample_index evaluates pi on the host; oracle/shuffle.py restates it).  Rows
+ * [0, a) and [a, a + b) of one permutation are what the reference's (train, validation) pair is in distribution: distinct
+ * rows, uniformly placed.  `index_out` (optional, (m,) int64) receives the source rows. */
+#define NFMC_PRP_ROUNDS 6
+int nfmc_rows_sample_f32(const float* x, int64_t n, int32_t d, uint64_t seed, int64_t first, float* out, int64_t m,
+                         int64_t* index_out, nfmc_stream_t stream);
+int64_t nfmc_rows_sample_index(int64_t n, uint64_t seed, int64_t i);
 
 typedef struct {
     int32_t abi_version;

@@ -60,13 +60,44 @@ def _digest():
     return h.hexdigest()
 
 
+_INCLUDE = None
+
+
+def _unit_digest(src):
+    """sha256 of one translation unit with the local headers it includes (transitively) and its flags: an object whose
+    stamp matches is reused, so touching one unit does not recompile the other twenty."""
+    import re
+    seen, todo = [], [os.path.join(CSRC, src)]
+    while todo:
+        path = todo.pop()
+        if path in seen or not os.path.isfile(path):
+            continue
+        seen.append(path)
+        with open(path, 'r', errors='replace') as fh:
+            for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', fh.read(), re.M):
+                for root in (CSRC, INCLUDE):
+                    todo.append(os.path.join(root, inc))
+    h = hashlib.sha256()
+    for path in sorted(seen):
+        h.update(os.path.basename(path).encode())
+        with open(path, 'rb') as fh:
+            h.update(fh.read())
+    h.update(' '.join(FLAGS + UNIT_FLAGS.get(src, [])).encode())
+    return h.hexdigest()
+
+
 def _compile(src):
     obj = os.path.join(OBJ, src[:-4] + '.o')
+    stamp, dig = obj + '.digest', _unit_digest(src)
+    if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dig and not os.environ.get('NFMC_BUILD_ALL'):
+        return obj
     cmd = [HIPCC] + FLAGS + UNIT_FLAGS.get(src, []) + ['-c', os.path.join(CSRC, src), '-o', obj]
     t0 = time.time()
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError('hipcc failed for %s:\n%s' % (src, r.stderr[-4000:]))
+    with open(stamp, 'w') as fh:
+        fh.write(dig)
     if os.environ.get('NFMC_BUILD_TIMES'):
         print('[nfmc_amd.build] %-28s %6.1f s' % (src, time.time() - t0), flush=True)
     return obj
@@ -74,6 +105,8 @@ def _compile(src):
 
 def build(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
+    if force:
+        os.environ['NFMC_BUILD_ALL'] = '1'   # --force recompiles every unit
     stamp = os.path.join(OBJ, 'digest.txt')
     dig = _digest()
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == dig:

@@ -19,12 +19,19 @@
 // atomics, every partial sum in a fixed order.
 // The trainable vector has the layout of the flow's weight blob (flows.py: packed): coupling layers, then the four
 // ElementwiseAffine vectors; gradients and AdamW moments use the same indices.
-#include "flow_device.hpp"
+// Round 4: conditioners of width <= 8 (every default flow) take the row-per-WAVE kernel of fit_rows.hpp (lanes = coordinates,
+// up to 1024 waves per launch); the row-per-lane kernel below stays for widths 16 / 32.  The epoch loop's bookkeeping (best
+// validation loss, best weights, early stopping, divergence) moved into the fold kernel, so a run of epochs is enqueued
+// without a host round trip per epoch (nfmc_flow_fit_epochs_f32).
+#include "fit_rows.hpp"
 
 namespace nfmc {
 
+int fit_rows_launch_h4(bool rkl, int ch, int s, const FitRowsArgs& a, int grid, size_t lds, hipStream_t st);
+int fit_rows_launch_h8(bool rkl, int ch, int s, const FitRowsArgs& a, int grid, size_t lds, hipStream_t st);
+
 constexpr int kFitBlock = 64;
-constexpr int kFitTail = 4;   // per-workgroup partial: [n_params] gradient sums, then loss sum, rows, validation loss sum, validation rows
+constexpr int kFitTail = kFitTailFloats;   // per-workgroup partial: [n_params] gradient sums, then loss sum, rows, validation loss sum, validation rows
 
 __host__ __device__ inline int fit_hb_stride(int hp) { return 4 * hp + 1; }   // odd: lanes = rows write conflict-free
 __host__ __device__ inline size_t fit_lds_bytes(int d, int hp, int rpw = 64) {
@@ -78,8 +85,9 @@ __global__ void __launch_bounds__(kFitBlock) fit_grad_kernel(NfmcRealNVP f, Nfmc
                                                              int64_t n, const float* __restrict__ xv, int64_t nv,
                                                              float* __restrict__ partial, int64_t pstride,
                                                              int64_t ea_off, int d4, int64_t n_params, int64_t tiles,
-                                                             int64_t vtiles) {
+                                                             int64_t vtiles, const float* __restrict__ run_state) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    if (run_state && (run_state[3] != 0.f || run_state[4] != 0.f)) return;   // the run has ended
     const FlowGeom g = make_geom(f);
     const int d = g.d, stride = tile_stride(d), hs = fit_hb_stride(HP);
     const int lane = threadIdx.x;
@@ -422,64 +430,212 @@ __global__ void __launch_bounds__(kFitBlock) fit_grad_kernel(NfmcRealNVP f, Nfmc
     }
 }
 
-// Fold of the partial gradients (fixed order: workgroup 0, 1, ...) + AdamW, one thread per parameter.
-// torch.optim.AdamW semantics: p <- p (1 - lr wd);  m <- b1 m + (1 - b1) g;  v <- b2 v + (1 - b2) g^2;
-// p <- p - lr (m / bc1) / (sqrt(v / bc2) + eps),  bc = 1 - beta^step.  A non-finite batch loss applies NO step
-// (flow_training._loop: `continue` before backward) and reports it: status[1] = 0.
-__global__ void __launch_bounds__(256) adamw_fold_kernel(float* __restrict__ params, float* __restrict__ am,
-                                                         float* __restrict__ av, float* __restrict__ prev,
-                                                         const float* __restrict__ partial, int64_t pstride, int nparts,
-                                                         int64_t n_params, NfmcAdamW opt, float* __restrict__ status) {
-    __shared__ float sh[4];
-    if (threadIdx.x < 4) {
-        float a = 0.f;
-        for (int w = 0; w < nparts; ++w) a += partial[w * pstride + n_params + threadIdx.x];
-        sh[threadIdx.x] = a;
+// ---------------------------------------------------------------------------------------------------------------------
+// Fold of the partial gradients + AdamW + the epoch loop's bookkeeping, one launch.
+//   sums      per parameter: 16 threads add up to 16 slabs each (all loads in flight at once, added in slab order), one
+//             thread adds the 16 sub-sums in order; the four tail values by a fixed butterfly -- every sum has a fixed
+//             association, so a run repeats bit for bit.  Only the slabs of workgroups that produced gradients are summed
+//             (a workgroup that only saw validation rows never writes its gradient entries).
+//   AdamW     torch.optim.AdamW: p <- p (1 - lr wd);  m <- b1 m + (1 - b1) g;  v <- b2 v + (1 - b2) g^2;
+//             p <- p - lr (m / bc1) / (sqrt(v / bc2) + eps),  bc = 1 - beta^step.
+//   run       (ctl given) flow_training._loop / torchflows' fit loop as nfmc drives it (jump.py:139-151: early stopping,
+//             keep_best_weights, ValueError on divergence), decided here so that the host enqueues epochs without reading
+//             anything back.  Call c works on the weights w_c:
+//               validation rows:  their loss at w_c closes epoch c - 1 (best-so-far / early stopping; best weights <- w_c),
+//                                 then -- unless the run stopped or this is the closing call -- the step w_c -> w_{c+1};
+//               no validation:    the batch loss at w_c stands in, paired with w_{c+1} (the reference's `_loop`).
+//             A non-finite batch loss ends the run (state[4] = 1: the host raises ValueError) or, for variational fits
+//             with check_for_divergences = False, skips the epoch.  Once stopped / diverged every later call of the run is
+//             a no-op (the gradient kernel returns at once, this kernel copies the state through).
+struct FitFoldArgs {
+    float* params;
+    float* am;
+    float* av;
+    float* prev;
+    float* best;
+    const float* partial;
+    int64_t pstride;
+    int nparts_tail, nparts_grad;
+    int64_t n_params;
+    NfmcAdamW opt;
+    float* status;
+    int has_ctl, call, has_val;
+    NfmcFitControl ctl;
+    const float* state_in;
+    float* state_out;
+};
+
+__global__ void __launch_bounds__(256) fit_fold_kernel(FitFoldArgs a) {
+    __shared__ float red[4][4];
+    __shared__ float sub[16][17];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // ---- run state
+    float best = INFINITY, since = 0.f, applied = 0.f, stopped = 0.f, diverged = 0.f, booked = 0.f;
+    if (a.has_ctl && a.call > 0) {
+        best = a.state_in[NFMC_FIT_BEST_LOSS];
+        since = a.state_in[NFMC_FIT_SINCE_BEST];
+        applied = a.state_in[NFMC_FIT_APPLIED];
+        stopped = a.state_in[NFMC_FIT_STOPPED];
+        diverged = a.state_in[NFMC_FIT_DIVERGED];
+        booked = a.state_in[NFMC_FIT_BOOKED];
+    }
+    const bool frozen = stopped != 0.f || diverged != 0.f;
+    if (frozen) {   // uniform: the run ended in an earlier call
+        if (blockIdx.x == 0 && tid < NFMC_FIT_STATE_FLOATS) a.state_out[tid] = a.state_in[tid];
+        return;
+    }
+    // ---- loss sum, rows, validation loss sum, validation rows over all slabs (at most 256 of them)
+    float t4[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int w = tid; w < a.nparts_tail; w += 256) {
+        const float* t = a.partial + (int64_t)w * a.pstride + a.n_params;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t4[k] += t[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) t4[k] = group_allreduce<64>(t4[k]);
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) red[wave][k] = t4[k];
     }
     __syncthreads();
-    const float rows = sh[1], loss = sh[0] / rows;
+    float sums[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sums[k] = ((red[0][k] + red[1][k]) + red[2][k]) + red[3][k];
+    const float rows = sums[1], loss = sums[0] / rows;
     const bool ok = fabsf(loss) <= 3.0e38f;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        status[0] = loss;
-        status[1] = ok ? 1.f : 0.f;
-        status[2] = sh[3] > 0.f ? sh[2] / sh[3] : loss;   // validation loss at the parameters BEFORE the step
-    }
-    const float bc1 = 1.f - powf(opt.beta1, (float)opt.step), bc2 = 1.f - powf(opt.beta2, (float)opt.step);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_params; i += (int64_t)gridDim.x * blockDim.x) {
-        float p = params[i];
-        if (prev) prev[i] = p;
-        if (!ok) continue;
-        float gsum = 0.f;
-        int w = 0;
-        for (; w + 8 <= nparts; w += 8) {   // eight loads in flight; the sum keeps the workgroup order
-            float t[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) t[k] = partial[(w + k) * pstride + i];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) gsum += t[k];
+    const float val = sums[3] > 0.f ? sums[2] / sums[3] : loss;
+    // ---- decisions (every thread of every workgroup takes the same ones)
+    bool do_step = ok, prev_to_best = false, new_to_best = false;
+    int step = a.opt.step;
+    if (a.has_ctl) {
+        const bool closing = a.has_val && a.call >= a.ctl.n_epochs;
+        if (a.call == 0 && a.ctl.keep_best_weights) prev_to_best = true;   // the weights the run started from are the fallback
+        if (a.has_val && a.call > 0) {   // the validation loss at w_c closes epoch c - 1
+            if (!(fabsf(val) <= 3.0e38f)) {
+                diverged = 1.f;
+            } else if (val < best) {
+                best = val;
+                since = 0.f;
+                prev_to_best = a.ctl.keep_best_weights != 0;
+            } else {
+                since += 1.f;
+                if (a.ctl.early_stopping && since > (float)a.ctl.early_stopping_threshold) stopped = 1.f;
+            }
+            booked += 1.f;
         }
-        for (; w < nparts; ++w) gsum += partial[w * pstride + i];
+        do_step = false;
+        if (!closing && stopped == 0.f && diverged == 0.f) {
+            if (ok) {
+                do_step = true;
+                step = (int)applied + 1;
+                applied += 1.f;
+                if (!a.has_val) {   // the batch loss before the step stands in for the validation loss
+                    if (loss < best) {
+                        best = loss;
+                        since = 0.f;
+                        new_to_best = a.ctl.keep_best_weights != 0;
+                    } else {
+                        since += 1.f;
+                        if (a.ctl.early_stopping && since > (float)a.ctl.early_stopping_threshold) stopped = 1.f;
+                    }
+                    booked += 1.f;
+                }
+            } else if (!a.ctl.skip_nonfinite) {
+                diverged = 1.f;
+            }
+        }
+        if (blockIdx.x == 0 && tid == 0) {
+            a.state_out[NFMC_FIT_BEST_LOSS] = best;
+            a.state_out[NFMC_FIT_SINCE_BEST] = since;
+            a.state_out[NFMC_FIT_APPLIED] = applied;
+            a.state_out[NFMC_FIT_STOPPED] = stopped;
+            a.state_out[NFMC_FIT_DIVERGED] = diverged;
+            a.state_out[NFMC_FIT_LAST_LOSS] = loss;
+            a.state_out[NFMC_FIT_LAST_VAL] = val;
+            a.state_out[NFMC_FIT_BOOKED] = booked;
+        }
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        a.status[0] = loss;
+        a.status[1] = ok ? 1.f : 0.f;
+        a.status[2] = val;   // validation loss at the parameters BEFORE the step
+    }
+    // ---- gradient of parameter i = 16 blockIdx + c: 16 sub-sums of up to 16 slabs each
+    const int c = tid & 15, part = tid >> 4;
+    const int64_t i = (int64_t)blockIdx.x * 16 + c;
+    if (do_step) {
+        const int chunk = (a.nparts_grad + 15) / 16;
+        const int w0 = part * chunk, w1 = min(a.nparts_grad, w0 + chunk);
+        float g = 0.f;
+        if (i < a.n_params) {
+            for (int w = w0; w < w1; w += 16) {
+                float t[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) t[k] = w + k < w1 ? a.partial[(int64_t)(w + k) * a.pstride + i] : 0.f;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) g += t[k];
+            }
+        }
+        sub[part][c] = g;
+    }
+    __syncthreads();
+    if (part != 0 || i >= a.n_params) return;
+    float p = a.params[i];
+    if (a.prev) a.prev[i] = p;
+    const bool reset = a.has_ctl && a.call == 0;
+    float pn = p;
+    if (do_step) {
+        float gsum = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) gsum += sub[k][c];
         const float gr = gsum / rows;
-        p *= 1.f - opt.lr * opt.weight_decay;
-        const float m = opt.beta1 * am[i] + (1.f - opt.beta1) * gr;
-        const float v = opt.beta2 * av[i] + (1.f - opt.beta2) * gr * gr;
-        am[i] = m;
-        av[i] = v;
-        params[i] = p - opt.lr * (m / bc1) / (sqrtf(v / bc2) + opt.eps);
+        const float bc1 = 1.f - powf(a.opt.beta1, (float)step), bc2 = 1.f - powf(a.opt.beta2, (float)step);
+        pn = p * (1.f - a.opt.lr * a.opt.weight_decay);
+        const float m = a.opt.beta1 * (reset ? 0.f : a.am[i]) + (1.f - a.opt.beta1) * gr;
+        const float v = a.opt.beta2 * (reset ? 0.f : a.av[i]) + (1.f - a.opt.beta2) * gr * gr;
+        a.am[i] = m;
+        a.av[i] = v;
+        pn = pn - a.opt.lr * (m / bc1) / (sqrtf(v / bc2) + a.opt.eps);
+        a.params[i] = pn;
+    } else if (reset) {
+        a.am[i] = 0.f;
+        a.av[i] = 0.f;
+    }
+    if (a.best) {
+        if (new_to_best) a.best[i] = pn;
+        else if (prev_to_best) a.best[i] = p;
     }
 }
 
-static int fit_grid(int64_t n, int64_t nv) {
-    const int rpw = fit_rows_per_wave(n);
-    const int64_t tiles = (n + rpw - 1) / rpw + (nv > 0 ? (nv + rpw - 1) / rpw : 0);
-    return (int)(tiles < 256 ? tiles : 256);
+static bool fit_rows_shape(const NfmcRealNVP* f, int64_t n_params, int* hp_out, int* ch_out) {
+    const int hp = nfmc_realnvp_padded_hidden(f->n_hidden);
+    if (hp != 4 && hp != 8) return false;
+    const int d_b = f->d - f->d / 2;
+    const int ch = d_b <= 64 ? 1 : 2;
+    if (d_b > 128) return false;
+    if (fit_rows_lds_bytes(n_params, hp, ch) > 160 * 1024) return false;
+    *hp_out = hp;
+    *ch_out = ch;
+    return true;
+}
+
+// trainable floats of a flow in the fit's layout with the tightest packing (what nfmc_flow_fit_supported_f32 assumes)
+static int64_t fit_min_params(const NfmcRealNVP* f) {
+    const int64_t stride = (nfmc_coupling_layer_floats(f->d, f->n_hidden, f->n_hidden_layers, 0) + 3) / 4 * 4;
+    const int64_t d4 = (f->d + 3) / 4 * 4;
+    return (int64_t)(f->n_coupling > 0 ? f->n_coupling : 1) * stride + 4 * d4;
 }
 
 static bool fit_supported(const NfmcRealNVP* f) {
     if (!f || f->n_bins != 0 || f->d <= 0 || f->d > 256 || f->n_coupling < 0) return false;
     if (f->n_hidden <= 0 || f->n_hidden > 32 || f->n_hidden_layers < 1 || f->n_hidden_layers > 2) return false;
     const int hp = nfmc_realnvp_padded_hidden(f->n_hidden);
-    return hp > 0 && fit_lds_bytes(f->d, hp) <= 160 * 1024;
+    if (hp <= 0) return false;
+    if (hp <= 8) {
+        int h, c;
+        return fit_rows_shape(f, fit_min_params(f), &h, &c);
+    }
+    return fit_lds_bytes(f->d, hp) <= 160 * 1024;
 }
 
 }  // namespace nfmc
@@ -493,8 +649,111 @@ extern "C" int64_t nfmc_flow_fit_partial_floats(int64_t n, int64_t n_params) {
     return (int64_t)256 * (n_params + kFitTail);   // one slab per workgroup; never more than 256 workgroups
 }
 
-static int fit_step(const NfmcFlowFit* fit, const NfmcPotential* pot, const float* x, int64_t n, const NfmcAdamW* opt,
-                    nfmc_stream_t stream) {
+// One call of a run (or one stand-alone step when ctl == NULL): gradient launch + fold launch.
+static int fit_call(const NfmcFlowFit* fit, const NfmcPotential* pot, const float* x, int64_t n, const NfmcAdamW* opt,
+                    const NfmcFitControl* ctl, int call, hipStream_t st) {
+    const NfmcRealNVP& f = fit->flow;
+    const int d4 = (f.d + 3) / 4 * 4;
+    const bool has_val = !pot && fit->x_val && fit->n_val > 0;
+    const int64_t nv = has_val ? fit->n_val : 0;
+    const bool closing = ctl && has_val && call >= ctl->n_epochs;
+    const int64_t n_train = closing ? 0 : n;   // the closing call only needs the validation loss
+    const int64_t pstride = fit->n_params + kFitTail;
+    const int hp = nfmc_realnvp_padded_hidden(f.n_hidden);
+    const float* state_in = ctl && call > 0 ? fit->run_state + NFMC_FIT_STATE_FLOATS * (call & 1) : nullptr;
+    float* state_out = ctl ? fit->run_state + NFMC_FIT_STATE_FLOATS * ((call + 1) & 1) : nullptr;
+    NfmcPotential p0 = {};
+    if (pot) p0 = *pot;
+    int grid = 0, grad_slabs = 0;
+    int rhp = 0, rch = 0;
+    if (fit_rows_shape(&f, fit->n_params, &rhp, &rch)) {
+        if ((f.layer_stride & 3) != 0 || (fit->ea_off & 3) != 0 || (reinterpret_cast<uintptr_t>(fit->params) & 15) != 0)
+            return NFMC_EALIGN;
+        // rows per wave tile: 4 when that still gives every SIMD of the machine a tile, else 1
+        const int S = (n_train + nv) >= 4096 ? 4 : 1;
+        const int64_t tiles = (n_train + S - 1) / S, tiles4 = (tiles + kFrWaves - 1) / kFrWaves * kFrWaves;
+        const int64_t vtiles = (nv + S - 1) / S;
+        const int64_t wgs = (tiles4 + vtiles + kFrWaves - 1) / kFrWaves;
+        grid = (int)(wgs < 256 ? (wgs < 1 ? 1 : wgs) : 256);
+        grad_slabs = (int)(tiles4 / kFrWaves < grid ? tiles4 / kFrWaves : grid);
+        if (fit->partial_floats < (int64_t)grid * pstride) return NFMC_ESCRATCH;
+        FitRowsArgs a;
+        a.f = f;
+        a.pot = p0;
+        a.x = x;
+        a.n = n_train;
+        a.xv = fit->x_val;
+        a.nv = nv;
+        a.partial = fit->partial;
+        a.pstride = pstride;
+        a.ea_off = fit->ea_off;
+        a.d4 = d4;
+        a.n_params = fit->n_params;
+        a.tiles4 = tiles4;
+        a.vtiles = vtiles;
+        a.params = fit->params;
+        a.run_state = state_in;
+        const size_t lds = fit_rows_lds_bytes(fit->n_params, rhp, rch);
+        const int rc = rhp == 4 ? fit_rows_launch_h4(pot != nullptr, rch, S, a, grid, lds, st)
+                                : fit_rows_launch_h8(pot != nullptr, rch, S, a, grid, lds, st);
+        if (rc != 0) return rc;
+    } else {
+        const int rpw = fit_rows_per_wave(n_train);
+        const int64_t tiles = (n_train + rpw - 1) / rpw, vtiles = nv > 0 ? (nv + rpw - 1) / rpw : 0;
+        const int64_t all = tiles + vtiles;
+        grid = (int)(all < 256 ? (all < 1 ? 1 : all) : 256);
+        grad_slabs = (int)(tiles < grid ? tiles : grid);   // workgroups beyond the batch tiles never write gradient entries
+        if (fit->partial_floats < (int64_t)grid * pstride) return NFMC_ESCRATCH;
+        const size_t lds = fit_lds_bytes(f.d, hp, rpw);
+#define NFMC_FIT_LAUNCH3(HPV, RKLV, RPWV)                                                                                 \
+    {                                                                                                                     \
+        auto kern = fit_grad_kernel<HPV, RKLV, RPWV>;                                                                     \
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
+        if (e != hipSuccess) return (int)e;                                                                               \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kFitBlock), lds, st, f, p0, x, n_train, fit->x_val, nv, fit->partial,   \
+                           pstride, fit->ea_off, d4, fit->n_params, tiles, vtiles, state_in);                             \
+    }
+#define NFMC_FIT_LAUNCH2(HPV, RKLV)              \
+    if (rpw == 16) NFMC_FIT_LAUNCH3(HPV, RKLV, 16) \
+    else NFMC_FIT_LAUNCH3(HPV, RKLV, 64)
+#define NFMC_FIT_LAUNCH(HPV)            \
+    if (pot) NFMC_FIT_LAUNCH2(HPV, true) \
+    else NFMC_FIT_LAUNCH2(HPV, false)
+        switch (hp) {
+            case 16: NFMC_FIT_LAUNCH(16) break;
+            case 32: NFMC_FIT_LAUNCH(32) break;
+            default: return NFMC_EUNSUPPORTED;
+        }
+#undef NFMC_FIT_LAUNCH
+#undef NFMC_FIT_LAUNCH2
+#undef NFMC_FIT_LAUNCH3
+    }
+    FitFoldArgs fa;
+    fa.params = fit->params;
+    fa.am = fit->adam_m;
+    fa.av = fit->adam_v;
+    fa.prev = fit->params_prev;
+    fa.best = ctl ? fit->best : nullptr;
+    fa.partial = fit->partial;
+    fa.pstride = pstride;
+    fa.nparts_tail = grid;
+    fa.nparts_grad = grad_slabs;
+    fa.n_params = fit->n_params;
+    fa.opt = *opt;
+    fa.status = fit->status;
+    fa.has_ctl = ctl ? 1 : 0;
+    fa.call = call;
+    fa.has_val = has_val ? 1 : 0;
+    fa.ctl = ctl ? *ctl : NfmcFitControl{};
+    fa.state_in = state_in;
+    fa.state_out = state_out;
+    const int blocks = (int)((fit->n_params + 15) / 16);
+    hipLaunchKernelGGL(fit_fold_kernel, dim3(blocks), dim3(256), 0, st, fa);
+    NFMC_HIP_CHECK_LAUNCH();
+    return NFMC_OK;
+}
+
+static int fit_check(const NfmcFlowFit* fit, const NfmcPotential* pot, const float* x, int64_t n, const NfmcAdamW* opt) {
     if (!fit || !x || !opt || n <= 0) return NFMC_EINVAL;
     const NfmcRealNVP& f = fit->flow;
     if (!fit->params || !fit->adam_m || !fit->adam_v || !fit->partial || !fit->status) return NFMC_EINVAL;
@@ -506,57 +765,36 @@ static int fit_step(const NfmcFlowFit* fit, const NfmcPotential* pot, const floa
     if (f.weights != fit->params || f.ea0_log_scale != fit->params + fit->ea_off || f.ea0_shift != fit->params + fit->ea_off + d4 ||
         f.ea1_log_scale != fit->params + fit->ea_off + 2 * d4 || f.ea1_shift != fit->params + fit->ea_off + 3 * d4)
         return NFMC_EINVAL;
-    const bool has_val = !pot && fit->x_val && fit->n_val > 0;
-    const int64_t nv = has_val ? fit->n_val : 0;
-    const int grid = fit_grid(n, nv);
-    const int64_t pstride = fit->n_params + kFitTail;
-    if (fit->partial_floats < (int64_t)grid * pstride) return NFMC_ESCRATCH;
-    if (opt->step < 1) return NFMC_EINVAL;
-    hipStream_t st = (hipStream_t)stream;
-    const int hp = nfmc_realnvp_padded_hidden(f.n_hidden);
-    const int rpw = fit_rows_per_wave(n);
-    const size_t lds = fit_lds_bytes(f.d, hp, rpw);
-    const int64_t tiles = (n + rpw - 1) / rpw, vtiles = nv > 0 ? (nv + rpw - 1) / rpw : 0;
-    NfmcPotential p0 = {};
-    if (pot) p0 = *pot;
-#define NFMC_FIT_LAUNCH3(HPV, RKLV, RPWV)                                                                                 \
-    {                                                                                                                     \
-        auto kern = fit_grad_kernel<HPV, RKLV, RPWV>;                                                                     \
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
-        if (e != hipSuccess) return (int)e;                                                                               \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kFitBlock), lds, st, f, p0, x, n, fit->x_val, nv, fit->partial, pstride, \
-                           fit->ea_off, d4, fit->n_params, tiles, vtiles);                                                \
-    }
-#define NFMC_FIT_LAUNCH2(HPV, RKLV)              \
-    if (rpw == 16) NFMC_FIT_LAUNCH3(HPV, RKLV, 16) \
-    else NFMC_FIT_LAUNCH3(HPV, RKLV, 64)
-#define NFMC_FIT_LAUNCH(HPV)            \
-    if (pot) NFMC_FIT_LAUNCH2(HPV, true) \
-    else NFMC_FIT_LAUNCH2(HPV, false)
-    switch (hp) {
-        case 4: NFMC_FIT_LAUNCH(4) break;
-        case 8: NFMC_FIT_LAUNCH(8) break;
-        case 16: NFMC_FIT_LAUNCH(16) break;
-        case 32: NFMC_FIT_LAUNCH(32) break;
-        default: return NFMC_EUNSUPPORTED;
-    }
-#undef NFMC_FIT_LAUNCH
-#undef NFMC_FIT_LAUNCH2
-#undef NFMC_FIT_LAUNCH3
-    const int ablocks = (int)((fit->n_params + 255) / 256);
-    hipLaunchKernelGGL(adamw_fold_kernel, dim3(ablocks < 1024 ? ablocks : 1024), dim3(256), 0, st, fit->params, fit->adam_m,
-                       fit->adam_v, fit->params_prev, fit->partial, pstride, grid, fit->n_params, *opt, fit->status);
-    NFMC_HIP_CHECK_LAUNCH();
     return NFMC_OK;
 }
 
 extern "C" int nfmc_flow_fit_step_f32(const NfmcFlowFit* fit, const float* x, int64_t n, const NfmcAdamW* opt,
                                       nfmc_stream_t stream) {
-    return fit_step(fit, nullptr, x, n, opt, stream);
+    const int rc = fit_check(fit, nullptr, x, n, opt);
+    if (rc != NFMC_OK) return rc;
+    if (opt->step < 1) return NFMC_EINVAL;
+    return fit_call(fit, nullptr, x, n, opt, nullptr, 0, (hipStream_t)stream);
 }
 
 extern "C" int nfmc_flow_variational_fit_step_f32(const NfmcFlowFit* fit, const NfmcPotential* pot, const float* z, int64_t n,
                                                   const NfmcAdamW* opt, nfmc_stream_t stream) {
     if (!pot) return NFMC_EINVAL;
-    return fit_step(fit, pot, z, n, opt, stream);
+    const int rc = fit_check(fit, pot, z, n, opt);
+    if (rc != NFMC_OK) return rc;
+    if (opt->step < 1) return NFMC_EINVAL;
+    return fit_call(fit, pot, z, n, opt, nullptr, 0, (hipStream_t)stream);
+}
+
+extern "C" int nfmc_flow_fit_epochs_f32(const NfmcFlowFit* fit, const NfmcPotential* pot, const float* x, int64_t n,
+                                        int64_t epoch_stride, const NfmcAdamW* opt, const NfmcFitControl* ctl,
+                                        int32_t first_call, int32_t n_calls, nfmc_stream_t stream) {
+    if (!ctl || first_call < 0 || n_calls < 0 || epoch_stride < 0) return NFMC_EINVAL;
+    const int rc = fit_check(fit, pot, x, n, opt);
+    if (rc != NFMC_OK) return rc;
+    if (!fit->run_state || (ctl->keep_best_weights && !fit->best)) return NFMC_EINVAL;
+    for (int c = first_call; c < first_call + n_calls; ++c) {
+        const int r = fit_call(fit, pot, x + (int64_t)(c - first_call) * epoch_stride, n, opt, ctl, c, (hipStream_t)stream);
+        if (r != NFMC_OK) return r;
+    }
+    return NFMC_OK;
 }

@@ -159,11 +159,32 @@ def _loop(flow, loss_fn, val_fn, n_epochs, lr, early_stopping, early_stopping_th
     return best_loss
 
 
+def _bump_versions(params):
+    """A raw kernel wrote into these tensors' memory: advance their autograd version counters, as an in-place torch op
+    would have, so that everything keyed on `_version` (RealNVP._version_key: the weight-blob caches) sees the change.
+    False when this torch build has no way to do it without one launch per tensor."""
+    setter = getattr(torch._C._autograd, '_unsafe_set_version_counter', None)
+    if setter is None:
+        return False
+    try:
+        setter(tuple(params), tuple(int(p._version) + 1 for p in params))
+        return True
+    except Exception:
+        return False
+
+
 class DeviceFit:
-    """State of a maximum-likelihood fit on the device (include/nfmc_hip.h: NfmcFlowFit, csrc/fit_kernels.hip): the flow's
-    parameters as ONE trainable vector in the layout of its weight blob, AdamW moments, per-workgroup partial gradients.
-    `step(x)` enqueues one optimiser step (gradient kernel + fold / AdamW kernel) and returns nothing; `status` holds the
-    batch loss before the step and whether it was applied.  `write_back()` copies the vector into the nn.Parameters."""
+    """State of a flow fit on the device (include/nfmc_hip.h: NfmcFlowFit, csrc/fit_kernels.hip, csrc/fit_rows.hpp): the
+    flow's parameters as ONE trainable vector in the layout of its weight blob, AdamW moments, per-workgroup partial
+    gradients, the run's bookkeeping state and best weights.
+      `step(x)` / `step_variational(z, pot)`   one optimiser step (gradient kernel + fold / AdamW kernel); `status` holds the
+                                               batch loss before the step and whether it was applied;
+      `run_calls(...)`                         calls of a whole epoch loop enqueued without reading anything back per epoch:
+                                               best loss, best weights, early stopping and divergence are decided in the
+                                               fold kernel (nfmc_flow_fit_epochs_f32);
+      `write_back()`                           the vector into the nn.Parameters (one launch) and the flow's pack cache.
+    `DeviceFit.of(bijection, ...)` keeps one instance per flow alive across fits (the refit of jump.py:193-201 runs every
+    outer iteration): no allocation, and no gather of the parameters when the vector is still what the flow's kernels use."""
 
     def __init__(self, bijection, device, n_rows, lr):
         import ctypes as C
@@ -173,25 +194,55 @@ class DeviceFit:
         self.d = d = bijection.d
         self.H, self.nhl = bijection.n_hidden, bijection.n_hidden_layers
         self.hp = int(lib.nfmc_realnvp_padded_hidden(self.H))
-        self.layer_stride = int(lib.nfmc_coupling_layer_floats(d, self.H, self.nhl, 0))
+        # layer stride rounded to 16 bytes: the row-per-wave kernel reads the staged blob with 16-byte LDS loads
+        self.layer_stride = (int(lib.nfmc_coupling_layer_floats(d, self.H, self.nhl, 0)) + 3) // 4 * 4
         self.d4 = (d + 3) // 4 * 4
         self.ea_off = (max(1, bijection.n_coupling * self.layer_stride) + 3) // 4 * 4
         self.n_params = self.ea_off + 4 * self.d4
-        # the trainable vector, gathered from the nn.Parameters ON THE DEVICE (RealNVP.packed goes through the host: a
-        # device-to-host copy per parameter tensor, ~0.6 ms of synchronisation per refit at the C5 shape)
         self.params = torch.zeros(self.n_params, dtype=torch.float32, device=device)
-        self._scatter(self.params, to_vector=True)
         self.m = torch.zeros_like(self.params)
         self.v = torch.zeros_like(self.params)
-        nfl = int(lib.nfmc_flow_fit_partial_floats(int(n_rows), self.n_params))
+        nfl = int(lib.nfmc_flow_fit_partial_floats(max(int(n_rows), 1), self.n_params))
         self.partial = torch.zeros(nfl, dtype=torch.float32, device=device)
         self.status = torch.zeros(3, dtype=torch.float32, device=device)
         self.prev = torch.zeros_like(self.params)     # the parameters before the latest step (what its validation loss is of)
+        self.best = torch.zeros_like(self.params)     # runs: the weights of the best monitored loss
+        self.run_state = torch.zeros(2 * hip.FIT_STATE_FLOATS, dtype=torch.float32, device=device)
         self.flow_struct = self._struct(self.params)
         self.fit = hip.NfmcFlowFit(self.flow_struct, hip.ptr(self.params), hip.ptr(self.m), hip.ptr(self.v), self.n_params,
-                                   self.ea_off, hip.ptr(self.partial), nfl, hip.ptr(self.status), None, 0, hip.ptr(self.prev))
+                                   self.ea_off, hip.ptr(self.partial), nfl, hip.ptr(self.status), None, 0, hip.ptr(self.prev),
+                                   hip.ptr(self.best), hip.ptr(self.run_state))
         self.opt = hip.NfmcAdamW(float(lr), 0.9, 0.999, 1e-8, 0.01, 0)   # torch.optim.AdamW defaults
         self.n_rows = int(n_rows)
+        self._pieces = None
+        self._xv = None
+        # the trainable vector, gathered from the nn.Parameters ON THE DEVICE (RealNVP.packed goes through the host)
+        self._scatter(self.params, to_vector=True)
+
+    @classmethod
+    def of(cls, bijection, device, n_rows, lr):
+        """The flow's resident fitter (created on first use), ready for a new fit: learning rate set, validation rows
+        cleared, the vector equal to the flow's current parameters."""
+        fitter = bijection.__dict__.get('_device_fit')
+        if (fitter is None or fitter.dev != device or fitter.bij is not bijection or fitter.H != bijection.n_hidden
+                or fitter.nhl != bijection.n_hidden_layers or fitter.d != bijection.d
+                or fitter.ea_off < bijection.n_coupling * fitter.layer_stride):
+            fitter = cls(bijection, device, n_rows, lr)
+            bijection.__dict__['_device_fit'] = fitter
+            return fitter
+        fitter.opt.lr, fitter.opt.weight_decay, fitter.opt.step = float(lr), 0.01, 0
+        fitter.fit.x_val, fitter.fit.n_val, fitter._xv = None, 0, None
+        if not fitter._vector_is_current():
+            fitter._scatter(fitter.params, to_vector=True)
+        return fitter
+
+    def _vector_is_current(self):
+        """True when the flow's pack cache still holds THIS vector for the parameters as they are now: nothing touched the
+        nn.Parameters since the last write_back, so there is nothing to gather."""
+        cache = self.bij._pack_cache if isinstance(self.bij._pack_cache, dict) else {}
+        hit = cache.get(0)
+        return bool(hit is not None and hit[0] == self.bij._version_key(self.dev) + (0,) and hit[1][1]
+                    and hit[1][1][0] is self.params)
 
     def _struct(self, vec):
         hip, o, d4, bij = self.hip, self.ea_off, self.d4, self.bij
@@ -199,39 +250,66 @@ class DeviceFit:
         return hip.NfmcRealNVP(self.d, bij.n_coupling, self.H, self.nhl, float(bij.min_scale), 0, view(0), view(1), view(2),
                                view(3), hip.ptr(vec), self.layer_stride, float(bij.spline_bound), 0)
 
-    def _scatter(self, vec, to_vector, bijection=None):
-        """nn.Parameters <-> trainable vector, by device-side slice copies in the VALU blob layout (include/nfmc_hip.h:
-        W1T (d_a, HP) | b1 | [WhT (HP, HP) | bh] | W3 (2 d_b, HP) | b3 per coupling layer, then the four ElementwiseAffine
-        vectors at ea_off)."""
-        bij = self.bij if bijection is None else bijection
+    def _layout(self, bijection):
+        """[(parameter tensor, offset in the vector, rows, cols, vector stride of a row, of a column)] in the VALU blob
+        layout (include/nfmc_hip.h: W1T (d_a, HP) | b1 | [WhT (HP, HP) | bh] | W3 (2 d_b, HP) | b3 per coupling layer, then
+        the four ElementwiseAffine vectors at ea_off)."""
         H, hp, d = self.H, self.hp, self.d
         d_a, d_b = d // 2, d - d // 2
-
-        def move(param, view):
-            if to_vector:
-                view.copy_(param.detach().to(view))
-            else:
-                param.copy_(view)
-
-        with torch.no_grad():
-            for li, cpl in enumerate(bij.couplings):
-                lin = list(cpl.conditioner)
-                cur = li * self.layer_stride
-                move(lin[0].weight.t(), vec[cur:cur + d_a * hp].view(d_a, hp)[:, :H])
-                cur += d_a * hp
-                move(lin[0].bias, vec[cur:cur + H])
+        out = []
+        for li, cpl in enumerate(bijection.couplings):
+            lin = list(cpl.conditioner)
+            cur = li * self.layer_stride
+            out.append((lin[0].weight, cur, H, d_a, 1, hp))             # Linear weight (H, d_a) <-> W1T (d_a, HP)
+            cur += d_a * hp
+            out.append((lin[0].bias, cur, 1, H, 0, 1))
+            cur += hp
+            for l in lin[1:-1]:
+                out.append((l.weight, cur, H, H, 1, hp))                # (out, in) <-> WhT (in, out)
+                cur += hp * hp
+                out.append((l.bias, cur, 1, H, 0, 1))
                 cur += hp
-                for l in lin[1:-1]:
-                    move(l.weight.t(), vec[cur:cur + hp * hp].view(hp, hp)[:H, :H])
-                    cur += hp * hp
-                    move(l.bias, vec[cur:cur + H])
-                    cur += hp
-                move(lin[-1].weight, vec[cur:cur + 2 * d_b * hp].view(2 * d_b, hp)[:, :H])
-                cur += 2 * d_b * hp
-                move(lin[-1].bias, vec[cur:cur + 2 * d_b])
-            ea0, ea1 = bij.layers[0], bij.layers[-1]
-            for k, t in enumerate((ea0.log_scale, ea0.shift, ea1.log_scale, ea1.shift)):
-                move(t, vec[self.ea_off + k * self.d4:self.ea_off + k * self.d4 + d])
+            out.append((lin[-1].weight, cur, 2 * d_b, H, hp, 1))        # W3 keeps (out, in)
+            cur += 2 * d_b * hp
+            out.append((lin[-1].bias, cur, 1, 2 * d_b, 0, 1))
+        ea0, ea1 = bijection.layers[0], bijection.layers[-1]
+        for k, t in enumerate((ea0.log_scale, ea0.shift, ea1.log_scale, ea1.shift)):
+            out.append((t, self.ea_off + k * self.d4, 1, d, 0, 1))
+        return out
+
+    def _scatter(self, vec, to_vector, bijection=None):
+        """nn.Parameters <-> trainable vector in one launch (nfmc_flow_blob_copy_f32); parameters that are not plain
+        contiguous float32 tensors on the vector's device take slice copies."""
+        bij = self.bij if bijection is None else bijection
+        hip = self.hip
+        layout = [t for t in self._layout(bij) if t[0].numel() > 0]   # d = 1: the source half is empty, W1 has no entries
+        plain = (vec.dtype == torch.float32 and vec.is_contiguous()
+                 and all(p.dtype == torch.float32 and p.device == vec.device and p.is_contiguous() for p, *_ in layout))
+        with torch.no_grad():
+            if plain:
+                key = tuple(p.data_ptr() for p, *_ in layout)
+                if bijection is None and self._pieces is not None and self._pieces[0] == key:
+                    arr = self._pieces[1]
+                else:
+                    arr = (hip.NfmcBlobPiece * len(layout))(*[
+                        hip.NfmcBlobPiece(hip.ptr(p), off, rows, cols, rs, cs) for p, off, rows, cols, rs, cs in layout])
+                    if bijection is None:
+                        self._pieces = (key, arr)
+                if to_vector or _bump_versions([p for p, *_ in layout]):
+                    hip.check(hip.lib().nfmc_flow_blob_copy_f32(hip.ptr(vec), arr, len(layout), 1 if to_vector else 0,
+                                                                hip.stream()), 'nfmc_flow_blob_copy_f32')
+                    return
+            for p, off, rows, cols, rs, cs in layout:
+                if rows == 1:
+                    view = vec[off:off + cols]
+                elif rs == 1:      # stored transposed
+                    view = vec[off:off + cols * cs].view(cols, cs)[:, :rows].t()
+                else:
+                    view = vec[off:off + rows * rs].view(rows, rs)[:, :cols]
+                if to_vector:
+                    view.copy_(p.detach().to(view))
+                else:
+                    p.copy_(view)
 
     @staticmethod
     def supported(bijection, device) -> bool:
@@ -270,6 +348,22 @@ class DeviceFit:
             self.C.byref(self.fit), self.C.byref(pot_struct), self.hip.ptr(z), int(z.shape[0]), self.C.byref(self.opt),
             self.hip.stream()), 'nfmc_flow_variational_fit_step_f32')
 
+    def control(self, n_epochs, early_stopping, early_stopping_threshold, keep_best_weights, skip_nonfinite=False):
+        return self.hip.NfmcFitControl(int(n_epochs), int(bool(early_stopping)), int(early_stopping_threshold),
+                                       int(bool(keep_best_weights)), int(bool(skip_nonfinite)), 0)
+
+    def run_calls(self, ctl, x, first_call, n_calls, pot_struct=None, epoch_stride=0):
+        """Enqueue calls first_call .. first_call + n_calls - 1 of a run on rows x (n, d) (nothing is read back)."""
+        self.hip.check(self.hip.lib().nfmc_flow_fit_epochs_f32(
+            self.C.byref(self.fit), self.C.byref(pot_struct) if pot_struct is not None else None, self.hip.ptr(x),
+            int(x.shape[-2]), int(epoch_stride), self.C.byref(self.opt), self.C.byref(ctl), int(first_call), int(n_calls),
+            self.hip.stream()), 'nfmc_flow_fit_epochs_f32')
+
+    def state_after(self, n_calls_done):
+        """The run's bookkeeping state after `n_calls_done` calls, as a list of floats (ONE device-to-host copy)."""
+        half = (n_calls_done & 1) * self.hip.FIT_STATE_FLOATS
+        return self.run_state[half:half + self.hip.FIT_STATE_FLOATS].tolist()
+
     def nll(self, x):
         """Mean NLL of rows x under the CURRENT trainable vector (forward kernel), as a device scalar."""
         n = int(x.shape[0])
@@ -283,70 +377,66 @@ class DeviceFit:
         own flow -- straight into that flow's pack cache: the sampling kernels' next launch takes the trained vector as its
         weight blob without a trip through the host (RealNVP.packed would rebuild it from the parameters)."""
         vec = self.params if vec is None else vec
+        if bijection is None and vec is not self.params and vec.dtype == torch.float32:
+            self.params.copy_(vec)       # the resident vector stays the one the kernels (and the next fit) use
+            vec = self.params
         self._scatter(vec, to_vector=False, bijection=bijection)
         if bijection is None and vec.dtype == torch.float32:
             bij, o, d4 = self.bij, self.ea_off, self.d4
             keep = [vec] + [vec[o + k * d4:o + k * d4 + self.d] for k in range(4)]
-            cache = bij._pack_cache if isinstance(bij._pack_cache, dict) else {}
-            cache[0] = (bij._version_key(self.dev) + (0,), (self._struct(vec), keep))
-            bij._pack_cache = cache
+            # every other presentation of the weights (e.g. zero-padded to the matrix-core width) is stale now
+            bij._pack_cache = {0: (bij._version_key(self.dev) + (0,), (self._struct(vec), keep))}
+
+
+def _run_chunk(time_limit_seconds, early_stopping):
+    """Calls enqueued between two looks at the run's state (one 32-byte read each): everything at once when nothing can
+    end the run early, 64 epochs when early stopping can (calls after the end are no-ops, but they are still launches), 16
+    under a time limit (an epoch is tens of microseconds)."""
+    if time_limit_seconds is not None:
+        return 16
+    return 64 if early_stopping else 1 << 30
 
 
 def _fit_device(flow, xt, xv, n_epochs, lr, early_stopping, early_stopping_threshold, keep_best_weights, time_limit_seconds):
-    """`_loop` for the full-batch maximum-likelihood fit with the step on the device.  Same order of events per epoch e --
-    loss at the weights w_e, step unless it is not finite, validation at the new weights w_{e+1}, best-so-far bookkeeping --
-    with ONE ABI call (two launches) and ONE 12-byte read per epoch: call c reports the batch loss AND the validation loss
-    at w_c (the validation rows ride in the gradient launch), so the bookkeeping of epoch c - 1 happens at call c, on the
-    copy of w_c that the update kernel leaves in `prev`; one extra evaluate-only call closes the last epoch."""
-    fitter = DeviceFit(flow.bijection, xt.device, xt.shape[0], lr)
+    """`_loop` for the full-batch maximum-likelihood fit, on the device end to end.  Same order of events per epoch e --
+    loss at the weights w_e, step unless it is not finite, validation at the new weights w_{e+1}, best-so-far / early
+    stopping bookkeeping -- but decided in the fold kernel (csrc/fit_kernels.hip: fit_fold_kernel): call c reports the batch
+    loss AND the validation loss at w_c (the validation rows ride in the gradient launch), so the bookkeeping of epoch
+    c - 1 happens inside call c, and one extra evaluate-only call closes the last epoch.  The host enqueues the calls and
+    reads 32 bytes at the end (every 64 epochs with early stopping, every 16 under a time limit)."""
+    fitter = DeviceFit.of(flow.bijection, xt.device, xt.shape[0] + (xv.shape[0] if xv is not None else 0), lr)
+    hip = fitter.hip
     if xv is not None:
         fitter.set_validation(xv)
-    best_loss, best_vec, since_best, applied = math.inf, (fitter.params.clone() if keep_best_weights else None), 0, 0
-    last_vec = None    # without best-weights bookkeeping: the weights after the last epoch that counted
-    t0 = time.time()
     n_epochs = int(n_epochs)
-
-    def book(v, vec):
-        """best-so-far bookkeeping for one finished epoch: validation value v, weights `vec` after its step"""
-        nonlocal best_loss, since_best
-        if not math.isfinite(v):
-            raise ValueError('flow training diverged (non-finite validation loss)')
-        if v < best_loss:
-            best_loss, since_best = v, 0
-            if keep_best_weights:
-                best_vec.copy_(vec)
-            return False
-        since_best += 1
-        return early_stopping and since_best > early_stopping_threshold
-
+    ctl = fitter.control(n_epochs, early_stopping, early_stopping_threshold, keep_best_weights)
+    total = n_epochs + (1 if xv is not None else 0)
+    t0 = time.time()
+    done, st = 0, None
     try:
-        stop = False
-        for c in range(n_epochs + (1 if xv is not None else 0)):
-            closing = c == n_epochs                      # evaluate-only call: the validation loss of the last epoch
-            if not closing and time_limit_seconds is not None and time.time() - t0 >= time_limit_seconds:
-                n_epochs = c
-                closing = xv is not None and c > 0
-                if not closing:
-                    break
-            fitter.step(xt, applied, lr=0.0 if closing else lr)
-            loss, ok, val = (float(t) for t in fitter.status.cpu())
-            if xv is not None and c > 0:                 # epoch c - 1 ended at the weights this call started from
-                last_vec = fitter.prev
-                stop = book(val, fitter.prev)
-            if closing or stop:
+        while done < total:
+            if time_limit_seconds is not None and done > 0 and time.time() - t0 >= time_limit_seconds:
+                if xv is not None and ctl.n_epochs > done:       # close the last applied epoch: one evaluate-only call
+                    ctl.n_epochs = done
+                    fitter.run_calls(ctl, xt, done, 1)
+                    done += 1
                 break
-            if not math.isfinite(loss) or ok == 0.0:
-                raise ValueError('flow training diverged (non-finite loss)')
-            applied += 1
-            if xv is None:                               # no validation set: the batch loss before the step stands in
-                last_vec = fitter.params
-                if book(loss, fitter.params):
+            k = min(_run_chunk(time_limit_seconds, early_stopping), total - done)
+            fitter.run_calls(ctl, xt, done, k)
+            done += k
+            if done < total:
+                st = fitter.state_after(done)
+                if st[hip.FIT_STOPPED] or st[hip.FIT_DIVERGED]:
                     break
+        st = fitter.state_after(done) if done else None
+        if st is not None and st[hip.FIT_DIVERGED]:
+            raise ValueError('flow training diverged (non-finite loss)')
     finally:
         # whatever happened, the nn.Parameters end up as the best weights seen (or the last ones): callers that catch the
-        # ValueError restore their own saved state_dict on top (jump.py:150-151)
-        fitter.write_back(best_vec if keep_best_weights else (last_vec.clone() if last_vec is not None else None))
-    return best_loss
+        # ValueError restore their own saved state_dict on top (jump.py:150-151).  Without best-weights bookkeeping the
+        # weights after the last epoch that counted are the current vector (an early stop applies no further step).
+        fitter.write_back(fitter.best if (keep_best_weights and done) else None)
+    return st[hip.FIT_BEST_LOSS] if st is not None else math.inf
 
 
 def fit(flow, x_train, x_val=None, n_epochs: int = 500, lr: float = 0.05, batch_size='adaptive',
@@ -386,37 +476,37 @@ def fit(flow, x_train, x_val=None, n_epochs: int = 500, lr: float = 0.05, batch_
 
 def _variational_fit_device(flow, potential, dev, n_epochs, lr, n_samples, early_stopping, early_stopping_threshold,
                             keep_best_weights, check_for_divergences, time_limit_seconds):
-    """`_loop` for the reverse-KL fit with the step on the device: each epoch draws its latents with torch.randn on the
-    device (the global CUDA generator, as the torch path does), then ONE ABI call; the host reads the 8-byte status.
-    A non-finite epoch is skipped (the kernel applies no step) or raises, as `check_for_divergences` says."""
+    """`_loop` for the reverse-KL fit, on the device end to end: each epoch draws its latents with torch.randn on the
+    device (the global CUDA generator, as the torch path does) and enqueues ONE call of the run; best loss, best weights,
+    early stopping and the handling of a non-finite epoch (skipped, or the end of the run when `check_for_divergences`)
+    are decided in the fold kernel.  The host looks at the run's state every 64 epochs (16 under a time limit)."""
     d = flow.bijection.d
-    fitter = DeviceFit(flow.bijection, dev, n_samples, lr)
+    fitter = DeviceFit.of(flow.bijection, dev, n_samples, lr)
+    hip = fitter.hip
     pot = potential.descriptor(dev)
-    best_loss, best_vec, since_best, applied = math.inf, (fitter.params.clone() if keep_best_weights else None), 0, 0
+    n_epochs = int(n_epochs)
+    ctl = fitter.control(n_epochs, early_stopping, early_stopping_threshold, keep_best_weights,
+                         skip_nonfinite=not check_for_divergences)
+    look = 16 if time_limit_seconds is not None else 64
     t0 = time.time()
+    done, st = 0, None
     try:
-        for _epoch in range(int(n_epochs)):
+        while done < n_epochs:
             if time_limit_seconds is not None and time.time() - t0 >= time_limit_seconds:
                 break
             z = torch.randn(n_samples, d, device=dev)
-            fitter.step_variational(z, pot, applied)
-            loss, ok, _val = (float(t) for t in fitter.status.cpu())
-            if not math.isfinite(loss) or ok == 0.0:
-                if check_for_divergences:
-                    raise ValueError('flow training diverged (non-finite loss)')
-                continue
-            applied += 1
-            if loss < best_loss:
-                best_loss, since_best = loss, 0
-                if keep_best_weights:
-                    best_vec.copy_(fitter.params)
-            else:
-                since_best += 1
-                if early_stopping and since_best > early_stopping_threshold:
+            fitter.run_calls(ctl, z, done, 1, pot_struct=pot)
+            done += 1
+            if done % look == 0 and done < n_epochs:
+                st = fitter.state_after(done)
+                if st[hip.FIT_STOPPED] or st[hip.FIT_DIVERGED]:
                     break
+        st = fitter.state_after(done) if done else None
+        if st is not None and st[hip.FIT_DIVERGED]:
+            raise ValueError('flow training diverged (non-finite loss)')
     finally:
-        fitter.write_back(best_vec if keep_best_weights else None)
-    return best_loss
+        fitter.write_back(fitter.best if (keep_best_weights and done) else None)
+    return st[hip.FIT_BEST_LOSS] if st is not None else math.inf
 
 
 def variational_fit(flow, log_prob_fn, n_epochs: int = 500, lr: float = 0.05, n_samples: int = 1000,

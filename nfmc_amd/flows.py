@@ -109,6 +109,7 @@ class RealNVP(nn.Module):
         state = self.__dict__.copy()
         state['_pack_cache'] = None
         state.pop('_mods_cache', None)
+        state.pop('_device_fit', None)      # flow_training.DeviceFit: device buffers + ctypes structs of THIS object
         return state
 
     # ------------------------------------------------------------------ packing for the kernels

@@ -21,7 +21,7 @@ MAX_STEPS_PER_CALL = 512
 IMH_PARALLEL_MAX_STEPS = 65536
 
 c_fp = C.c_void_p  # all device pointers travel as void*
-NFMC_ABI_VERSION = 3   # include/nfmc_hip.h
+NFMC_ABI_VERSION = 4   # include/nfmc_hip.h
 
 
 class NfmcPotential(C.Structure):
@@ -110,7 +110,22 @@ class NfmcAdamW(C.Structure):
 class NfmcFlowFit(C.Structure):
     _fields_ = [('flow', NfmcRealNVP), ('params', c_fp), ('adam_m', c_fp), ('adam_v', c_fp), ('n_params', C.c_int64),
                 ('ea_off', C.c_int64), ('partial', c_fp), ('partial_floats', C.c_int64), ('status', c_fp),
-                ('x_val', c_fp), ('n_val', C.c_int64), ('params_prev', c_fp)]
+                ('x_val', c_fp), ('n_val', C.c_int64), ('params_prev', c_fp), ('best', c_fp), ('run_state', c_fp)]
+
+
+class NfmcBlobPiece(C.Structure):
+    _fields_ = [('param', c_fp), ('vec_off', C.c_int64), ('rows', C.c_int32), ('cols', C.c_int32),
+                ('vec_row_stride', C.c_int32), ('vec_col_stride', C.c_int32)]
+
+
+class NfmcFitControl(C.Structure):
+    _fields_ = [('n_epochs', C.c_int32), ('early_stopping', C.c_int32), ('early_stopping_threshold', C.c_int32),
+                ('keep_best_weights', C.c_int32), ('skip_nonfinite', C.c_int32), ('reserved', C.c_int32)]
+
+
+# indices into NfmcFlowFit.run_state (include/nfmc_hip.h: NFMC_FIT_*)
+FIT_BEST_LOSS, FIT_SINCE_BEST, FIT_APPLIED, FIT_STOPPED, FIT_DIVERGED, FIT_LAST_LOSS, FIT_LAST_VAL, FIT_BOOKED = range(8)
+FIT_STATE_FLOATS = 8
 
 
 class NfmcLimits(C.Structure):
@@ -153,6 +168,11 @@ SYMBOLS = [
     ('nfmc_flow_fit_step_f32', C.c_int, [C.POINTER(NfmcFlowFit), c_fp, C.c_int64, C.POINTER(NfmcAdamW), c_fp]),
     ('nfmc_flow_variational_fit_step_f32', C.c_int, [C.POINTER(NfmcFlowFit), C.POINTER(NfmcPotential), c_fp, C.c_int64,
                                                     C.POINTER(NfmcAdamW), c_fp]),
+    ('nfmc_flow_fit_epochs_f32', C.c_int, [C.POINTER(NfmcFlowFit), C.POINTER(NfmcPotential), c_fp, C.c_int64, C.c_int64,
+                                          C.POINTER(NfmcAdamW), C.POINTER(NfmcFitControl), C.c_int32, C.c_int32, c_fp]),
+    ('nfmc_flow_blob_copy_f32', C.c_int, [c_fp, C.POINTER(NfmcBlobPiece), C.c_int32, C.c_int32, c_fp]),
+    ('nfmc_rows_sample_f32', C.c_int, [c_fp, C.c_int64, C.c_int32, C.c_uint64, C.c_int64, c_fp, C.c_int64, c_fp, c_fp]),
+    ('nfmc_rows_sample_index', C.c_int64, [C.c_int64, C.c_uint64, C.c_int64]),
     ('nfmc_limits', C.c_int, [C.POINTER(NfmcLimits)]),
     ('nfmc_error_string', C.c_char_p, [C.c_int]),
     ('nfmc_build_digest', C.c_char_p, []),

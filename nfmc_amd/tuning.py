@@ -78,9 +78,24 @@ def train_val_split(x: torch.Tensor, train_pct: float, max_train_size: int, max_
             rows = rows[perm.to(rows.device)]
     elif shuffle:
         # the rows of the shuffled buffer that survive the cut and the caps, without materialising the shuffled buffer (at
-        # the C5 shape it is 160 MiB per refit for 8192 kept rows): same permutation, same rows, same order
-        perm = torch.randperm(rows.shape[0], device=rows.device)
-        cut = int(train_pct * rows.shape[0])
+        # the C5 shape it is 160 MiB per refit for 8192 kept rows)
+        total = rows.shape[0]
+        cut = int(train_pct * total)
+        n_train, n_val = min(cut, int(max_train_size)), min(total - cut, int(max_val_size))
+        if rows.is_cuda and rows.dtype == torch.float32 and rows.is_contiguous() and total > 0:
+            # ONE launch (csrc/fit_support.hip: nfmc_rows_sample_f32): rows pi(0 .. n_train + n_val - 1) of a keyed
+            # pseudo-random permutation pi of the pooled rows -- positions [0, n_train) and [cut, cut + n_val) of a uniform
+            # shuffle are, in distribution, any n_train + n_val distinct positions of it.  The key comes from torch's CPU
+            # generator, like the reference's randperm (tuning.py:58-59); no sort of all rows, no index tensors.
+            from . import hip
+            flat = rows.reshape(total, -1)
+            out = torch.empty(n_train + n_val, flat.shape[1], dtype=torch.float32, device=rows.device)
+            seed = int(torch.randint(0, 2 ** 62, ()).item())
+            hip.check(hip.lib().nfmc_rows_sample_f32(hip.ptr(flat), total, flat.shape[1], seed, 0, hip.ptr(out),
+                                                     n_train + n_val, None, hip.stream()), 'nfmc_rows_sample_f32')
+            out = out.reshape(n_train + n_val, *rows.shape[1:])
+            return out[:n_train], out[n_train:]
+        perm = torch.randperm(total, device=rows.device)
         return rows[perm[:cut][:max_train_size]], rows[perm[cut:][:max_val_size]]
     cut = int(train_pct * rows.shape[0])
     return rows[:cut][:max_train_size], rows[cut:][:max_val_size]

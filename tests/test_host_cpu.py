@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(handle, name), f'{name} declared in include/nfmc_hip.h but not exported'
     assert declared == {s[0] for s in hip.SYMBOLS}, 'hip.SYMBOLS and the header disagree'
     lim = hip.limits()
-    assert lim.abi_version == hip.NFMC_ABI_VERSION == 3 and lim.max_d_sampler >= 256 and lim.max_steps_per_call == hip.MAX_STEPS_PER_CALL
+    assert lim.abi_version == hip.NFMC_ABI_VERSION == 4 and lim.max_d_sampler >= 256 and lim.max_steps_per_call == hip.MAX_STEPS_PER_CALL
     assert hip.lib().nfmc_error_string(-5).decode().startswith('statistics scratch')
     assert hip.lib().nfmc_stats_scratch_bytes(64) > 0 and hip.lib().nfmc_stats_scratch_bytes(5000) == 0
     assert hip.lib().nfmc_realnvp_padded_hidden(5) == 8 and hip.lib().nfmc_realnvp_padded_hidden(100) == 128
@@ -42,7 +42,7 @@ def test_struct_sizes_match_the_header():
     """Compile a tiny C program against include/nfmc_hip.h and compare sizeof() with the ctypes mirrors."""
     from nfmc_amd import hip
     names = ['NfmcPotential', 'NfmcRng', 'NfmcStats', 'NfmcSampleStore', 'NfmcTune', 'NfmcJumpTail', 'NfmcMalaArgs', 'NfmcHmcArgs', 'NfmcRealNVP', 'NfmcFlowMhArgs',
-             'NfmcNeutraHmcArgs', 'NfmcSelectArgs', 'NfmcLimits', 'NfmcAdamW', 'NfmcFlowFit']
+             'NfmcNeutraHmcArgs', 'NfmcSelectArgs', 'NfmcLimits', 'NfmcAdamW', 'NfmcFlowFit', 'NfmcFitControl']
     src = '#include <stdio.h>\n#include "nfmc_hip.h"\nint main(){' + ''.join(
         f'printf("%zu\\n", sizeof({n}));' for n in names) + 'return 0;}'
     import tempfile
@@ -730,3 +730,26 @@ def test_hand_counted_memory_waits_see_no_compiler_inserted_memory_operations():
         assert k.get('.vgpr_spill_count', 0) == 0 and k.get('.sgpr_spill_count', 0) == 0, k['.name']
         assert k['.vgpr_count'] <= 512
     assert seen >= 2   # with and without the per-step outputs, in the affine and the spline unit
+
+
+def test_refit_split_permutation_matches_the_oracle_and_is_a_permutation():
+    """The refit buffer's shuffled split (tuning.py:44-65) on the device gathers rows pi(0), pi(1), ... of a keyed
+    pseudo-random permutation (csrc/fit_support.hip).  The library's HOST evaluation of pi (`nfmc_rows_sample_index`: the
+    same inline function the kernel calls, integer arithmetic only) against oracle/shuffle.py index for index, pi a
+    bijection of [0, N) at sizes around the powers of two (cycle walking), different seeds give different orders, and the
+    first rows are spread over the whole buffer (a shuffle, not a rotation)."""
+    from nfmc_amd import hip
+    from oracle import shuffle
+    lib = hip.lib()
+    for n, seed in ((1, 5), (2, 9), (3, 1), (7, 2), (64, 3), (65, 4), (1000, 2 ** 61 + 12345), (4097, 77)):
+        got = [int(lib.nfmc_rows_sample_index(n, seed, i)) for i in range(n)]
+        assert got == shuffle.permutation_prefix(n, seed, n).tolist(), (n, seed)
+        assert sorted(got) == list(range(n)), (n, seed)
+    n = 163840   # the C5 refit buffer: 5 x 32768 pooled rows
+    a = [int(lib.nfmc_rows_sample_index(n, 11, i)) for i in range(2048)]
+    b = [int(lib.nfmc_rows_sample_index(n, 12, i)) for i in range(2048)]
+    assert a == shuffle.permutation_prefix(n, 11, 2048).tolist()
+    assert len(set(a)) == 2048 and a != b
+    counts = np.bincount(np.asarray(a) * 16 // n, minlength=16)          # 128 expected per sixteenth
+    assert counts.min() > 80 and counts.max() < 180, counts.tolist()
+    assert lib.nfmc_rows_sample_index(n, 11, n) == -1 and lib.nfmc_rows_sample_index(0, 1, 0) == -1
