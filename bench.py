@@ -132,14 +132,14 @@ def fitted_flow_state(cfg_name, cfg, dev):
     from nfmc_amd.flows import Flow, RealNVP
     if cfg_name not in FLOW_STATE and cfg['strategy'] == 'neutra_hmc':
         # C4: the state NeuTra's warmup leaves (neutra.py:70-107): a variational (reverse-KL) fit of the flow to the funnel,
-        # 200 epochs of 1024 latents -- the conditioner is 128 wide, so this fit runs on the torch path (fit kernels: <= 32)
+        # 200 epochs of 1024 latents, on the device (the conditioner is 128 wide: the matrix-core fit kernel, csrc/fit_mfma.hip)
         from nfmc_amd.potentials import Funnel
         d = cfg['d']
         pot = Funnel((d,), 3.0)
         torch.manual_seed(1)
         f = Flow(RealNVP((d,), conditioner_kwargs={'n_hidden': 128, 'n_layers': 2})).to(dev)
         f.variational_fit(lambda v: -pot(v), n_epochs=200, lr=0.01, n_samples=1024, early_stopping=False,
-                          keep_best_weights=True, show_progress=False)
+                          keep_best_weights=True, show_progress=False, potential=pot)
         FLOW_STATE[cfg_name] = {k: v.detach().cpu().clone() for k, v in f.state_dict().items()}
     if cfg_name not in FLOW_STATE and cfg['strategy'] == 'imh':
         # C2: the independence sampler's own warmup (imh.py:60-75): a variational fit of the default RealNVP to the target,

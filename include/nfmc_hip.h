@@ -126,7 +126,18 @@ typedef struct {
     int64_t layer_stride;     /* floats between consecutive coupling layers */
     float spline_bound;       /* B (n_bins > 0) */
     int32_t reserved;
+    float* scratch;           /* workspace of the streamed matrix-core kernels (n_hidden 33..128 at d = 32 .. 512 a multiple of
+                                 32 other than 64 / 128): >= nfmc_flow_scratch_bytes(flow, n, ...) bytes, 16-byte aligned, private
+                                 to one stream at a time; NULL / 0 elsewhere.  The library never allocates: a call that needs it
+                                 and does not find it returns NFMC_ESCRATCH */
+    int64_t scratch_bytes;
 } NfmcRealNVP;
+
+/* Bytes of NfmcRealNVP.scratch that nfmc_realnvp_forward_f32 / nfmc_realnvp_inverse_f32 (with_gradient = 0) or
+ * nfmc_neutra_potential_grad_f32 (with_gradient = 1) need for n rows: the state (and gradient) of the resident workgroups'
+ * chains stream through it, one private row per lane group of a workgroup SLOT -- at most 256 x 128 rows of d floats (x 2
+ * with the gradient) whatever n.  0 for every shape that runs register- or LDS-resident. */
+int64_t nfmc_flow_scratch_bytes(const NfmcRealNVP* flow, int64_t n, int32_t with_gradient);
 
 /* HP: n_hidden padded to the kernels' width (4, 8, 16, 32 on the VALU path; 64 or 128 on the matrix-core path,
  * whose blob also carries every matrix in both orientations: csrc/mfma_device.hpp); 0 = unsupported. */
@@ -329,16 +340,16 @@ typedef struct {
 /* 0 for the VALU path (n_hidden <= 32).  Matrix-core path at d = 64 / 128: 2 (n, d) tiles + 2 (n,) vectors, plus the activation
  * checkpoints of the resident workgroups (hidden activations, alpha, beta of every coupling layer: the reverse sweep
  * reads them back instead of recomputing them) -- at most 256 workgroups x 128 chains, whatever n.  At the other multiples
- * of 32 (trajectory composed from the streamed gradient kernel, csrc/mfma_wide.hip): 4 (n, d) arrays + 3 (n,) vectors. */
+ * of 32 (trajectory composed from the streamed gradient kernel, csrc/mfma_wide.hip): 4 (n, d) arrays + 3 (n,) vectors + the
+ * gradient kernel's own workspace (nfmc_flow_scratch_bytes with the gradient; NfmcRealNVP.scratch is not used by this call). */
 int64_t nfmc_neutra_scratch_bytes(int64_t n, int32_t d, int32_t n_hidden, int32_t n_hidden_layers, int32_t n_coupling);
 
 int nfmc_neutra_hmc_steps_f32(const NfmcNeutraHmcArgs* args, nfmc_stream_t stream);
 
 /* Adjusted potential and its gradient alone (tests; split path).  n_hidden <= 32: every d <= 512.  n_hidden 33..128
  * (matrix cores): d = 64 / 128 register-resident, every other multiple of 32 up to 512 with the state and the gradient
- * streamed through a scratch slab the entry point allocates and frees in stream order (hipMallocAsync;
- * csrc/mfma_wide.hip); other d: NFMC_EUNSUPPORTED.  nfmc_realnvp_forward_f32 / nfmc_realnvp_inverse_f32 use the same
- * streamed kernels at those d. */
+ * streamed through the caller's workspace NfmcRealNVP.scratch (nfmc_flow_scratch_bytes; csrc/mfma_wide.hip); other d:
+ * NFMC_EUNSUPPORTED.  nfmc_realnvp_forward_f32 / nfmc_realnvp_inverse_f32 use the same streamed kernels at those d. */
 int nfmc_neutra_potential_grad_f32(const NfmcRealNVP* flow, const NfmcPotential* pot, const float* z, int64_t n,
                                    float* u_out, float* grad_out, nfmc_stream_t stream);
 
@@ -389,8 +400,8 @@ int nfmc_philox_uniforms_f32(const NfmcRng* rng, int32_t tag, int64_t n, float* 
  * layers (n_coupling * layer_stride floats, VALU layout above), then at `ea_off` the four ElementwiseAffine vectors
  * (ea0 log-scale, ea0 shift, ea1 log-scale, ea1 shift; d4 = d rounded up to 4 floats each) -- and `flow`'s pointers must be
  * views of it (weights = params, ea0_log_scale = params + ea_off, ...), so the sampling kernels see every step at once.
- * Shapes: affine / additive couplings (n_bins = 0), n_hidden <= 32, one or two hidden layers, d <= 256
- * (nfmc_flow_fit_supported_f32); other flows are trained by the host package's torch path.
+ * Shapes: affine / additive couplings (n_bins = 0), one or two hidden layers; n_hidden <= 32 at d <= 256, n_hidden 33..128
+ * at d = 64 / 128 (nfmc_flow_fit_supported_f32); other flows are trained by the host package's torch path.
  * Conditioners of width <= 8 (every default flow) run on the row-per-wave kernel (csrc/fit_rows.hpp: up to 1024 waves per
  * launch); it needs `params` 16-byte aligned and layer_stride, ea_off multiples of 4 floats (NFMC_EALIGN otherwise). */
 typedef struct {
@@ -417,6 +428,9 @@ typedef struct {
     float* best;              /* runs (nfmc_flow_fit_epochs_f32) with keep_best_weights: (n_params) the weights the best
                                  monitored loss so far belongs to; call 0 initialises it with the starting weights */
     float* run_state;         /* runs: device, 2 x NFMC_FIT_STATE_FLOATS floats (call c reads half c & 1, writes the other) */
+    float* scratch;           /* conditioners of width 33..128 (matrix-core kernel, csrc/fit_mfma.hip): the resident waves'
+                                 activation checkpoints, >= nfmc_flow_fit_workspace(...) bytes, 16-byte aligned; NULL elsewhere */
+    int64_t scratch_bytes;
 } NfmcFlowFit;
 
 /* The epoch loop of `Flow.fit` / `Flow.variational_fit` (torchflows, as nfmc drives it: jump.py:139-151 early stopping +
@@ -449,6 +463,13 @@ enum {
 
 int nfmc_flow_fit_supported_f32(const NfmcRealNVP* flow);
 int64_t nfmc_flow_fit_partial_floats(int64_t n, int64_t n_params);
+/* Workspace of a fit of `flow` on n batch rows (+ n_val validation rows) with a trainable vector of n_params floats:
+ * returns the bytes of NfmcFlowFit.scratch (0 for conditioners of width <= 32) and stores the floats `partial` must hold
+ * (one slab of n_params + 4 floats per workgroup of the gradient launch).  Conditioners of width 33..128 are trained at
+ * d = 64 / 128 (the shapes of the register-resident matrix-core kernels) with the trainable vector in the matrix-core blob
+ * layout (csrc/mfma_device.hpp: every matrix in both orientations; the gradient kernel writes both slots, AdamW keeps them
+ * equal), layer_stride >= nfmc_realnvp_layer_floats(d, n_hidden, n_hidden_layers) and a multiple of 4. */
+int64_t nfmc_flow_fit_workspace(const NfmcRealNVP* flow, int64_t n, int64_t n_val, int64_t n_params, int64_t* partial_floats);
 int nfmc_flow_fit_step_f32(const NfmcFlowFit* fit, const float* x, int64_t n, const NfmcAdamW* opt, nfmc_stream_t stream);
 /* The same step for the variational fit of imh.py:67-72 / neutra.py:84-91 (`Flow.variational_fit`): rows z (n, d) are
  * latents drawn from N(0, I) by the caller, the loss is the reverse KL estimate mean[log q(x) - log p(x)], x = f^-1(z),

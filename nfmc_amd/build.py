@@ -32,13 +32,14 @@ FLAGS = ['-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC', '-fno-gpu-rdc', 
 # into independent 128-bit values instead.
 UNIT_FLAGS = {'neutra_mfma.hip': ['-mllvm', '-amdgpu-promote-alloca-to-vector-limit=16'],
               'flow_mfma.hip': ['-mllvm', '-amdgpu-promote-alloca-to-vector-limit=16'],
-              'mfma_wide.hip': ['-mllvm', '-amdgpu-promote-alloca-to-vector-limit=16']}
+              'mfma_wide.hip': ['-mllvm', '-amdgpu-promote-alloca-to-vector-limit=16'],
+              'fit_mfma.hip': ['-mllvm', '-amdgpu-promote-alloca-to-vector-limit=16']}
 
 
 # units that take a minute or more to compile go first, so that the pool finishes with the short ones
 # (NFMC_BUILD_TIMES=1 prints the time of each)
 SLOW_FIRST = ['flow_b_kernels.hip', 'neutra_kernels_r64.hip', 'neutra_kernels_r32.hip', 'neutra_kernels_r16.hip',
-              'imh_parallel_rqs.hip', 'imh_parallel.hip', 'fit_kernels.hip', 'neutra_mfma.hip']
+              'imh_parallel_rqs.hip', 'imh_parallel.hip', 'fit_kernels.hip', 'neutra_mfma.hip', 'fit_mfma.hip']
 
 
 def sources():

@@ -24,6 +24,7 @@
 // validation loss, best weights, early stopping, divergence) moved into the fold kernel, so a run of epochs is enqueued
 // without a host round trip per epoch (nfmc_flow_fit_epochs_f32).
 #include "fit_rows.hpp"
+#include "fit_mfma.hpp"
 
 namespace nfmc {
 
@@ -31,6 +32,7 @@ int fit_rows_launch_h4(bool rkl, int ch, int s, const FitRowsArgs& a, int grid, 
 int fit_rows_launch_h8(bool rkl, int ch, int s, const FitRowsArgs& a, int grid, size_t lds, hipStream_t st);
 
 constexpr int kFitBlock = 64;
+constexpr int kMfmaChainsFit = 128;   // rows per workgroup tile of the matrix-core kernel (mfma_device.hpp: kMfmaChains)
 constexpr int kFitTail = kFitTailFloats;   // per-workgroup partial: [n_params] gradient sums, then loss sum, rows, validation loss sum, validation rows
 
 __host__ __device__ inline int fit_hb_stride(int hp) { return 4 * hp + 1; }   // odd: lanes = rows write conflict-free
@@ -626,7 +628,10 @@ static int64_t fit_min_params(const NfmcRealNVP* f) {
     return (int64_t)(f->n_coupling > 0 ? f->n_coupling : 1) * stride + 4 * d4;
 }
 
+static bool fit_wide(const NfmcRealNVP* f);
+static int64_t mfma_layer_floats_of(const NfmcRealNVP& f) { return nfmc_realnvp_layer_floats(f.d, f.n_hidden, f.n_hidden_layers); }
 static bool fit_supported(const NfmcRealNVP* f) {
+    if (fit_wide(f)) return true;
     if (!f || f->n_bins != 0 || f->d <= 0 || f->d > 256 || f->n_coupling < 0) return false;
     if (f->n_hidden <= 0 || f->n_hidden > 32 || f->n_hidden_layers < 1 || f->n_hidden_layers > 2) return false;
     const int hp = nfmc_realnvp_padded_hidden(f->n_hidden);
@@ -638,6 +643,11 @@ static bool fit_supported(const NfmcRealNVP* f) {
     return fit_lds_bytes(f->d, hp) <= 160 * 1024;
 }
 
+// conditioners of width 33..128 at d = 64 / 128: the matrix-core kernel (fit_mfma.hip), blob in the matrix-core layout
+static bool fit_wide(const NfmcRealNVP* f) {
+    return f && f->n_bins == 0 && f->n_coupling > 0 && f->n_hidden > 32 && nfmc_mfma_supported(f->d, f->n_hidden, f->n_hidden_layers);
+}
+
 }  // namespace nfmc
 
 using namespace nfmc;
@@ -647,6 +657,20 @@ extern "C" int nfmc_flow_fit_supported_f32(const NfmcRealNVP* flow) { return fit
 extern "C" int64_t nfmc_flow_fit_partial_floats(int64_t n, int64_t n_params) {
     if (n <= 0 || n_params <= 0) return 0;
     return (int64_t)256 * (n_params + kFitTail);   // one slab per workgroup; never more than 256 workgroups
+}
+
+extern "C" int64_t nfmc_flow_fit_workspace(const NfmcRealNVP* flow, int64_t n, int64_t n_val, int64_t n_params,
+                                           int64_t* partial_floats) {
+    if (partial_floats) *partial_floats = 0;
+    if (!flow || n <= 0 || n_val < 0 || n_params <= 0 || !fit_supported(flow)) return 0;
+    if (!fit_wide(flow)) {
+        if (partial_floats) *partial_floats = nfmc_flow_fit_partial_floats(n, n_params);
+        return 0;
+    }
+    const int grid = fit_mfma_grid(n, n_val);
+    if (partial_floats) *partial_floats = (int64_t)grid * (n_params + kFitTail);
+    return fit_mfma_ck_floats(flow->d, nfmc_realnvp_padded_hidden(flow->n_hidden), flow->n_hidden_layers, flow->n_coupling, grid) *
+           (int64_t)sizeof(float);
 }
 
 // One call of a run (or one stand-alone step when ctl == NULL): gradient launch + fold launch.
@@ -666,7 +690,36 @@ static int fit_call(const NfmcFlowFit* fit, const NfmcPotential* pot, const floa
     if (pot) p0 = *pot;
     int grid = 0, grad_slabs = 0;
     int rhp = 0, rch = 0;
-    if (fit_rows_shape(&f, fit->n_params, &rhp, &rch)) {
+    if (fit_wide(&f)) {
+        const int64_t tiles = (n_train + kMfmaChainsFit - 1) / kMfmaChainsFit, vtiles = (nv + kMfmaChainsFit - 1) / kMfmaChainsFit;
+        grid = fit_mfma_grid(n_train, nv);
+        grad_slabs = (int)(tiles < grid ? tiles : grid);
+        if (fit->partial_floats < (int64_t)grid * pstride) return NFMC_ESCRATCH;
+        const int64_t ckf = fit_mfma_ck_floats(f.d, hp, f.n_hidden_layers, f.n_coupling, grid);
+        if (!fit->scratch || fit->scratch_bytes < ckf * (int64_t)sizeof(float)) return NFMC_ESCRATCH;
+        if ((reinterpret_cast<uintptr_t>(fit->params) & 15) != 0 || (reinterpret_cast<uintptr_t>(fit->scratch) & 15) != 0 ||
+            (reinterpret_cast<uintptr_t>(x) & 15) != 0 || (nv > 0 && (reinterpret_cast<uintptr_t>(fit->x_val) & 15) != 0) ||
+            (f.layer_stride & 3) != 0 || (fit->ea_off & 3) != 0)
+            return NFMC_EALIGN;
+        FitMfmaArgs a;
+        a.f = f;
+        a.pot = p0;
+        a.x = x;
+        a.n = n_train;
+        a.xv = fit->x_val;
+        a.nv = nv;
+        a.partial = fit->partial;
+        a.pstride = pstride;
+        a.ea_off = fit->ea_off;
+        a.d4 = d4;
+        a.n_params = fit->n_params;
+        a.tiles = tiles;
+        a.vtiles = vtiles;
+        a.ck = fit->scratch;
+        a.run_state = state_in;
+        const int rc = fit_mfma_launch(pot != nullptr, a, grid, st);
+        if (rc != 0) return rc;
+    } else if (fit_rows_shape(&f, fit->n_params, &rhp, &rch)) {
         if ((f.layer_stride & 3) != 0 || (fit->ea_off & 3) != 0 || (reinterpret_cast<uintptr_t>(fit->params) & 15) != 0)
             return NFMC_EALIGN;
         // rows per wave tile: 4 when that still gives every SIMD of the machine a tile, else 1
@@ -758,6 +811,7 @@ static int fit_check(const NfmcFlowFit* fit, const NfmcPotential* pot, const flo
     const NfmcRealNVP& f = fit->flow;
     if (!fit->params || !fit->adam_m || !fit->adam_v || !fit->partial || !fit->status) return NFMC_EINVAL;
     if (!fit_supported(&f)) return NFMC_EUNSUPPORTED;
+    if (fit_wide(&f) && f.layer_stride < mfma_layer_floats_of(f)) return NFMC_EINVAL;
     if (pot && pot->kind != NFMC_POT_QUADRATIC && pot->kind != NFMC_POT_FUNNEL) return NFMC_EUNSUPPORTED;
     const int d4 = (f.d + 3) / 4 * 4;
     if (fit->ea_off < (int64_t)f.n_coupling * f.layer_stride || fit->n_params < fit->ea_off + 4 * d4) return NFMC_EINVAL;

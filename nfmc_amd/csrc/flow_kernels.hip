@@ -290,6 +290,12 @@ extern "C" int32_t nfmc_realnvp_padded_hidden(int32_t n_hidden) {
     return n_hidden <= 64 ? 64 : (n_hidden <= 128 ? 128 : 0);
 }
 
+extern "C" int64_t nfmc_flow_scratch_bytes(const NfmcRealNVP* flow, int64_t n, int32_t with_gradient) {
+    if (!flow || n <= 0 || flow->n_bins != 0 || flow->n_coupling <= 0) return 0;
+    if (!nfmc_mfma_wide_supported(flow->d, flow->n_hidden, flow->n_hidden_layers)) return 0;
+    return nfmc_wide_slab_floats(n, flow->d, with_gradient ? 2 : 1) * (int64_t)sizeof(float);
+}
+
 extern "C" int64_t nfmc_realnvp_layer_floats(int32_t d, int32_t n_hidden, int32_t n_hidden_layers) {
     if (d <= 0 || n_hidden <= 0 || n_hidden_layers <= 0) return 0;
     const int64_t hp = nfmc_realnvp_padded_hidden(n_hidden);

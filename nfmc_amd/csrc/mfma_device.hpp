@@ -308,6 +308,7 @@ int nfmc_mfma_wide_supported(int32_t d, int32_t n_hidden, int32_t n_hidden_layer
 int nfmc_neutra_potential_grad_wide_f32(const NfmcRealNVP* flow, const NfmcPotential* pot, const float* z, int64_t n,
                                         float* u_out, float* grad_out, nfmc_stream_t stream);
 int64_t nfmc_neutra_wide_scratch_floats(int64_t n, int32_t d);
+int64_t nfmc_wide_slab_floats(int64_t n, int32_t d, int32_t copies);
 int nfmc_neutra_hmc_steps_wide_f32(const NfmcNeutraHmcArgs* args, float* scratch, int64_t scratch_bytes, nfmc_stream_t stream);
 int nfmc_realnvp_forward_wide_f32(const NfmcRealNVP* flow, const float* x, int64_t n, float* z, float* logdet, float* log_prob,
                                   nfmc_stream_t stream);

@@ -252,4 +252,48 @@ __device__ __forceinline__ float potential_value_c(const f32x4 (&x)[TD], const N
     return chain_sum(u);
 }
 
+// ---- closed-form potential and gradient in C layout (tile position = coordinate of x)
+template <int TD>
+__device__ __forceinline__ float potential_value_grad_c(const f32x4 (&x)[TD], f32x4 (&g)[TD], const NfmcPotential& p,
+                                                        int half, int lane) {
+    constexpr int d = 16 * TD;
+    if (p.kind == NFMC_POT_FUNNEL) {
+        const float x0 = __shfl(x[0][0], lane & 15, kWave);  // coordinate 0 = tile 0, reg 0, lane group 0
+        float s = 0.f;
+#pragma unroll
+        for (int m = 0; m < TD; ++m)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) s = fmaf(x[m][t], (m == 0 && t == 0 && half == 0) ? 0.f : x[m][t], s);
+        s = chain_sum(s);
+        const float inv_s2 = 1.f / (p.a_scalar * p.a_scalar);
+        const float e = fast_exp(-x0);
+        const float hd = 0.5f * (float)(d - 1);
+#pragma unroll
+        for (int m = 0; m < TD; ++m)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) g[m][t] = x[m][t] * e;
+        if (half == 0) g[0][0] = x0 * inv_s2 - 0.5f * e * s + hd;
+        return 0.5f * x0 * x0 * inv_s2 + 0.5f * e * s + hd * x0;
+    }
+    float u = 0.f;
+#pragma unroll
+    for (int m = 0; m < TD; ++m) {
+        f32x4 a, b;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            a[t] = p.a_scalar;
+            b[t] = p.b_scalar;
+        }
+        if (p.a) a = vec_tile(p.a, m, half);
+        if (p.b) b = vec_tile(p.b, m, half);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float dlt = x[m][t] - b[t];
+            u = fmaf(a[t] * dlt, dlt, u);
+            g[m][t] = 2.f * a[t] * dlt;
+        }
+    }
+    return chain_sum(u);
+}
+
 }  // namespace nfmc

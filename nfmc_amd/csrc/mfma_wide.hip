@@ -421,8 +421,8 @@ __device__ __forceinline__ float wide_potential_grad(const WideCtx& c, const Nfm
     return chain_sum(u);
 }
 
-// slab: (tiles * 128) private rows of d floats for the state, then as many for the gradient (rows past n belong to the
-// idle lanes of the last tile: they run on a copy of row n - 1 and are never read)
+// slab: (grid * 128) private rows of d floats for the state, then as many for the gradient, one row per lane group of a
+// workgroup slot (lanes past n in the last tile run on a copy of row n - 1 and are never read)
 template <int TH, int NHL>
 __global__ void __launch_bounds__(kMfmaBlock, 2) neutra_grad_wide_kernel(NfmcRealNVP f, NfmcPotential pot, const float* __restrict__ z,
                                                                       int64_t n, float* __restrict__ u_out, float* __restrict__ grad_out,
@@ -435,12 +435,15 @@ __global__ void __launch_bounds__(kMfmaBlock, 2) neutra_grad_wide_kernel(NfmcRea
     const bool rev_last = (f.n_coupling & 1) != 0;
     WideCtx c;
     wide_ctx_init(c, lds, f, lane);
+    // the lane group's private slab row belongs to the workgroup SLOT, not to the chain: the next chain tile of the grid-stride
+    // loop reuses it (a tile's results have left for the output arrays by then), so the slab is bounded by the grid
+    const int64_t srow = (int64_t)blockIdx.x * kMfmaChains + wave * 16 + c.col;
     for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         const int64_t row = tile * kMfmaChains + wave * 16 + c.col;
         const bool active = row < n;
         const float* zr = z + (active ? row : n - 1) * d;
-        c.xs = slab + row * d + 4 * c.q;
-        c.gs = slab + (tiles * kMfmaChains + row) * d + 4 * c.q;
+        c.xs = slab + srow * d + 4 * c.q;
+        c.gs = slab + ((int64_t)gridDim.x * kMfmaChains + srow) * d + 4 * c.q;
         // z at tile positions in latent order (flows with an odd number of reversals: position p holds logical d - 1 - p)
         wide_tiles(d / 16, [&](int m) { return rev_last ? vec_tile_rev(zr, m, c.q, d) : vec_tile(zr, m, c.q); },
                    [&](int m, const f32x4& v) { tile_st(c.xs, m, v); });
@@ -461,7 +464,7 @@ __global__ void __launch_bounds__(kMfmaBlock, 2) neutra_grad_wide_kernel(NfmcRea
     }
 }
 
-// x -> z, logdet_forward, log_prob (realnvp_forward_mfma_kernel's contract); slab: tiles * 128 private rows of d floats
+// x -> z, logdet_forward, log_prob (realnvp_forward_mfma_kernel's contract); slab: grid * 128 private rows of d floats
 template <int TH, int NHL>
 __global__ void __launch_bounds__(kMfmaBlock, 2) realnvp_forward_wide_kernel(NfmcRealNVP f, const float* __restrict__ x, int64_t n,
                                                                           float* __restrict__ z, float* __restrict__ logdet,
@@ -474,11 +477,14 @@ __global__ void __launch_bounds__(kMfmaBlock, 2) realnvp_forward_wide_kernel(Nfm
     const bool rev_last = (f.n_coupling & 1) != 0;
     WideCtx c;
     wide_ctx_init(c, lds, f, lane);
+    // the lane group's private slab row belongs to the workgroup SLOT, not to the chain: the next chain tile of the grid-stride
+    // loop reuses it (a tile's results have left for the output arrays by then), so the slab is bounded by the grid
+    const int64_t srow = (int64_t)blockIdx.x * kMfmaChains + wave * 16 + c.col;
     for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         const int64_t row = tile * kMfmaChains + wave * 16 + c.col;
         const bool active = row < n;
         const float* xr = x + (active ? row : n - 1) * d;
-        c.xs = slab + row * d + 4 * c.q;
+        c.xs = slab + srow * d + 4 * c.q;
         wide_tiles(d / 16, [&](int m) { return vec_tile(xr, m, c.q); }, [&](int m, const f32x4& v) { tile_st(c.xs, m, v); });
         float ldp = wide_ea<kEaForward>(c, f.ea0_log_scale, f.ea0_shift, false);
         for (int l = 0; l < f.n_coupling; ++l)
@@ -509,11 +515,14 @@ __global__ void __launch_bounds__(kMfmaBlock, 2) realnvp_inverse_wide_kernel(Nfm
     const bool rev_last = (f.n_coupling & 1) != 0;
     WideCtx c;
     wide_ctx_init(c, lds, f, lane);
+    // the lane group's private slab row belongs to the workgroup SLOT, not to the chain: the next chain tile of the grid-stride
+    // loop reuses it (a tile's results have left for the output arrays by then), so the slab is bounded by the grid
+    const int64_t srow = (int64_t)blockIdx.x * kMfmaChains + wave * 16 + c.col;
     for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         const int64_t row = tile * kMfmaChains + wave * 16 + c.col;
         const bool active = row < n;
         const int64_t rrow = active ? row : n - 1;
-        c.xs = slab + row * d + 4 * c.q;
+        c.xs = slab + srow * d + 4 * c.q;
         if (z) {
             const float* zr = z + rrow * d;
             wide_tiles(d / 16, [&](int m) { return rev_last ? vec_tile_rev(zr, m, c.q, d) : vec_tile(zr, m, c.q); },
@@ -740,27 +749,21 @@ int nfmc::nfmc_mfma_wide_supported(int32_t d, int32_t n_hidden, int32_t n_hidden
            n_hidden_layers <= 2;
 }
 
-// the scratch slab of one launch: stream-ordered allocation (the C entry points of these passes have no scratch argument)
-static int wide_slab(float** slab, int64_t tiles, int d, int copies, hipStream_t st) {
-    // keep freed slabs in the device's default pool across synchronisations (its default threshold of 0 hands the memory
-    // back at every sync: a real allocation of tens of MB per call)
-    static bool pooled = false;
-    if (!pooled) {
-        int dev = 0;
-        hipMemPool_t pool = nullptr;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
-            uint64_t keep = ~0ull;
-            (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
-        }
-        (void)hipGetLastError();
-        pooled = true;
-    }
-    hipError_t e = hipMallocAsync((void**)slab, (size_t)copies * tiles * kMfmaChains * d * sizeof(float), st);
-    if (e == hipErrorNotSupported) {   // no stream-ordered allocator on this device / driver: the caller takes its other route
-        (void)hipGetLastError();
-        return NFMC_EUNSUPPORTED;
-    }
-    return e == hipSuccess ? NFMC_OK : (int)e;
+// The scratch slab of a launch comes from the caller (NfmcRealNVP.scratch; SURVEY 8b: the library never allocates): one
+// private row of d floats per lane group of a workgroup SLOT -- at most kCkMaxGrid slots whatever n -- times `copies`
+// (1: state; 2: state and gradient).
+static int wide_grid(int64_t n) {
+    const int64_t tiles = (n + kMfmaChains - 1) / kMfmaChains;
+    return (int)(tiles < kCkMaxGrid ? tiles : kCkMaxGrid);
+}
+int64_t nfmc::nfmc_wide_slab_floats(int64_t n, int32_t d, int32_t copies) {
+    return n > 0 ? (int64_t)copies * wide_grid(n) * kMfmaChains * d : 0;
+}
+static int wide_slab(float** slab, const NfmcRealNVP* flow, int64_t n, int copies) {
+    const int64_t need = nfmc_wide_slab_floats(n, flow->d, copies) * (int64_t)sizeof(float);
+    if (!flow->scratch || flow->scratch_bytes < need || (((uintptr_t)flow->scratch) & 15u)) return NFMC_ESCRATCH;
+    *slab = flow->scratch;
+    return NFMC_OK;
 }
 
 #define NFMC_WIDE_DISPATCH(KERNEL, ...)                                                                                        \
@@ -778,11 +781,8 @@ static int wide_slab(float** slab, int64_t tiles, int d, int copies, hipStream_t
 #define NFMC_WIDE_LAUNCH(KERNEL, THV, NHLV, ...)                                                                       \
     {                                                                                                                   \
         auto kern = KERNEL<THV, NHLV>;                                                                                  \
-        static bool attr_set = false;   /* once per kernel (process-wide: one device per process) */                    \
-        if (!attr_set) {                                                                                                \
-            e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWideLdsBytes); \
-            attr_set = e == hipSuccess;                                                                                 \
-        }                                                                                                               \
+        /* per call: the attribute belongs to the (kernel, device) pair, and a process may drive several devices */     \
+        e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWideLdsBytes);     \
         if (e == hipSuccess) hipLaunchKernelGGL(kern, dim3(grid), dim3(kMfmaBlock), kWideLdsBytes, st, __VA_ARGS__);    \
     }
 
@@ -792,13 +792,12 @@ int nfmc::nfmc_realnvp_forward_wide_f32(const NfmcRealNVP* flow, const float* x,
     if (!nfmc_mfma_wide_supported(flow->d, flow->n_hidden, flow->n_hidden_layers)) return NFMC_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const int64_t tiles = (n + kMfmaChains - 1) / kMfmaChains;
-    const int grid = (int)(tiles < kCkMaxGrid ? tiles : kCkMaxGrid);
+    const int grid = wide_grid(n);
     float* slab = nullptr;
-    int rc = wide_slab(&slab, tiles, flow->d, 1, st);
+    int rc = wide_slab(&slab, flow, n, 1);
     if (rc) return rc;
     NFMC_WIDE_DISPATCH(realnvp_forward_wide_kernel, *flow, x, n, z, logdet, log_prob, slab, tiles)
-    const hipError_t fe = hipFreeAsync(slab, st);
-    return rc == NFMC_OK && fe != hipSuccess ? (int)fe : rc;
+    return rc;
 }
 
 int nfmc::nfmc_realnvp_inverse_wide_f32(const NfmcRealNVP* flow, const float* z, int64_t n, float* x, float* logdet, float* log_q,
@@ -809,20 +808,19 @@ int nfmc::nfmc_realnvp_inverse_wide_f32(const NfmcRealNVP* flow, const float* z,
     if (rng) r = *rng;
     hipStream_t st = (hipStream_t)stream;
     const int64_t tiles = (n + kMfmaChains - 1) / kMfmaChains;
-    const int grid = (int)(tiles < kCkMaxGrid ? tiles : kCkMaxGrid);
+    const int grid = wide_grid(n);
     float* slab = nullptr;
-    int rc = wide_slab(&slab, tiles, flow->d, 1, st);
+    int rc = wide_slab(&slab, flow, n, 1);
     if (rc) return rc;
     NFMC_WIDE_DISPATCH(realnvp_inverse_wide_kernel, *flow, z, n, x, logdet, log_q, r, slab, tiles)
-    const hipError_t fe = hipFreeAsync(slab, st);
-    return rc == NFMC_OK && fe != hipSuccess ? (int)fe : rc;
+    return rc;
 }
 
-// the gradient kernel on a slab the caller holds (2 x tiles x 128 x d floats)
+// the gradient kernel on a slab the caller holds (2 x grid x 128 x d floats)
 static int grad_wide_launch(const NfmcRealNVP* flow, const NfmcPotential* pot, const float* z, int64_t n, float* u_out, float* grad_out,
                             float* slab, hipStream_t st) {
     const int64_t tiles = (n + kMfmaChains - 1) / kMfmaChains;
-    const int grid = (int)(tiles < kCkMaxGrid ? tiles : kCkMaxGrid);
+    const int grid = wide_grid(n);
     int rc = NFMC_OK;
     NFMC_WIDE_DISPATCH(neutra_grad_wide_kernel, *flow, *pot, z, n, u_out, grad_out, slab, tiles)
     return rc;
@@ -841,17 +839,17 @@ int nfmc::nfmc_neutra_potential_grad_wide_f32(const NfmcRealNVP* flow, const Nfm
     int rc = grad_wide_check(flow, pot, z, n, grad_out);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    const int64_t tiles = (n + kMfmaChains - 1) / kMfmaChains;
     float* slab = nullptr;
-    rc = wide_slab(&slab, tiles, flow->d, 2, st);   // state and gradient
+    rc = wide_slab(&slab, flow, n, 2);   // state and gradient
     if (rc) return rc;
-    rc = grad_wide_launch(flow, pot, z, n, u_out, grad_out, slab, st);
-    const hipError_t fe = hipFreeAsync(slab, st);
-    return rc == NFMC_OK && fe != hipSuccess ? (int)fe : rc;
+    return grad_wide_launch(flow, pot, z, n, u_out, grad_out, slab, st);
 }
 
-// scratch of the composed trajectory: p, gz, zq, gq (n d floats each), then uz, h0, uq (n each)
-int64_t nfmc::nfmc_neutra_wide_scratch_floats(int64_t n, int32_t d) { return 4 * n * (int64_t)d + 3 * n; }
+// scratch of the composed trajectory: p, gz, zq, gq (n d floats each), then uz, h0, uq (n each, the three rounded up to a
+// multiple of 4 floats), then the gradient kernel's slab (state and gradient rows of the workgroup slots)
+int64_t nfmc::nfmc_neutra_wide_scratch_floats(int64_t n, int32_t d) {
+    return 4 * n * (int64_t)d + (3 * n + 3) / 4 * 4 + nfmc_wide_slab_floats(n, d, 2);
+}
 
 int nfmc::nfmc_neutra_hmc_steps_wide_f32(const NfmcNeutraHmcArgs* args, float* scratch, int64_t scratch_bytes, nfmc_stream_t stream) {
     if (!args || !scratch) return NFMC_EINVAL;
@@ -880,9 +878,8 @@ int nfmc::nfmc_neutra_hmc_steps_wide_f32(const NfmcNeutraHmcArgs* args, float* s
     if (a.stats.sum_x && a.stats.scratch_bytes < (int64_t)grid_c * (2 * dp + kStatTail) * (int64_t)sizeof(double)) return NFMC_ESCRATCH;
     int rc = grad_wide_check(&a.flow, &a.pot, a.z, n, w.gz);
     if (rc) return rc;
-    // ONE slab for the gradients of the whole call (allocating per gradient cost 0.65 ms of host time each: the stream ran dry)
-    float* slab = nullptr;
-    if ((rc = wide_slab(&slab, (n + kMfmaChains - 1) / kMfmaChains, d, 2, st))) return rc;
+    // ONE slab for the gradients of the whole call, behind the trajectory's arrays in the caller's scratch
+    float* slab = scratch + 4 * n * (int64_t)d + (3 * n + 3) / 4 * 4;
     // U~ and its gradient at the state (also after the caller changed z)
     rc = grad_wide_launch(&a.flow, &a.pot, a.z, n, w.uz, w.gz, slab, st);
     int countdown = a.samples.countdown, srow = a.samples.row;   // one pass per transition: the store cursor runs here
@@ -909,9 +906,7 @@ int nfmc::nfmc_neutra_hmc_steps_wide_f32(const NfmcNeutraHmcArgs* args, float* s
             hipLaunchKernelGGL(stats_finish_kernel<true>, dim3(stats_finish_grid(dp)), dim3(kFinishBlock), 0, st, a.stats.scratch, grid_c, dp, d,
                                a.stats, (unsigned long long)n);
     }
-    const hipError_t fe = hipFreeAsync(slab, st);
     const hipError_t le = hipGetLastError();
     if (rc) return rc;
-    if (fe != hipSuccess) return (int)fe;
     return le == hipSuccess ? NFMC_OK : (int)le;
 }

@@ -202,22 +202,41 @@ class DeviceFit:
         self.params = torch.zeros(self.n_params, dtype=torch.float32, device=device)
         self.m = torch.zeros_like(self.params)
         self.v = torch.zeros_like(self.params)
-        nfl = int(lib.nfmc_flow_fit_partial_floats(max(int(n_rows), 1), self.n_params))
-        self.partial = torch.zeros(nfl, dtype=torch.float32, device=device)
+        self.wide = self.hp > 32      # matrix-core layout: every matrix in both orientations (csrc/mfma_device.hpp, fit_mfma.hip)
+        self.partial, self.scratch = None, None
         self.status = torch.zeros(3, dtype=torch.float32, device=device)
         self.prev = torch.zeros_like(self.params)     # the parameters before the latest step (what its validation loss is of)
         self.best = torch.zeros_like(self.params)     # runs: the weights of the best monitored loss
         self.run_state = torch.zeros(2 * hip.FIT_STATE_FLOATS, dtype=torch.float32, device=device)
         self.flow_struct = self._struct(self.params)
         self.fit = hip.NfmcFlowFit(self.flow_struct, hip.ptr(self.params), hip.ptr(self.m), hip.ptr(self.v), self.n_params,
-                                   self.ea_off, hip.ptr(self.partial), nfl, hip.ptr(self.status), None, 0, hip.ptr(self.prev),
-                                   hip.ptr(self.best), hip.ptr(self.run_state))
+                                   self.ea_off, None, 0, hip.ptr(self.status), None, 0, hip.ptr(self.prev),
+                                   hip.ptr(self.best), hip.ptr(self.run_state), None, 0)
         self.opt = hip.NfmcAdamW(float(lr), 0.9, 0.999, 1e-8, 0.01, 0)   # torch.optim.AdamW defaults
-        self.n_rows = int(n_rows)
+        self.n_rows = 0
+        self.ensure_rows(n_rows)
         self._pieces = None
         self._xv = None
         # the trainable vector, gathered from the nn.Parameters ON THE DEVICE (RealNVP.packed goes through the host)
         self._scatter(self.params, to_vector=True)
+
+    def ensure_rows(self, n_rows):
+        """Workspace for fits of up to `n_rows` rows (batch + validation): the per-workgroup partial-gradient slabs and, for
+        wide conditioners, the resident waves' activation checkpoints (nfmc_flow_fit_workspace).  Grows, never shrinks."""
+        n_rows = max(int(n_rows), 1)
+        if n_rows <= self.n_rows:
+            return
+        C, hip = self.C, self.hip
+        nfl = C.c_int64(0)
+        sbytes = int(hip.lib().nfmc_flow_fit_workspace(C.byref(self.flow_struct), n_rows, n_rows, self.n_params, C.byref(nfl)))
+        nfl = int(nfl.value)
+        if self.partial is None or self.partial.numel() < nfl:
+            self.partial = torch.zeros(nfl, dtype=torch.float32, device=self.dev)
+            self.fit.partial, self.fit.partial_floats = hip.ptr(self.partial), nfl
+        if sbytes and (self.scratch is None or self.scratch.numel() * 4 < sbytes):
+            self.scratch = torch.empty(sbytes // 4, dtype=torch.float32, device=self.dev)
+            self.fit.scratch, self.fit.scratch_bytes = hip.ptr(self.scratch), sbytes
+        self.n_rows = n_rows
 
     @classmethod
     def of(cls, bijection, device, n_rows, lr):
@@ -232,6 +251,7 @@ class DeviceFit:
             return fitter
         fitter.opt.lr, fitter.opt.weight_decay, fitter.opt.step = float(lr), 0.01, 0
         fitter.fit.x_val, fitter.fit.n_val, fitter._xv = None, 0, None
+        fitter.ensure_rows(n_rows)
         if not fitter._vector_is_current():
             fitter._scatter(fitter.params, to_vector=True)
         return fitter
@@ -257,7 +277,22 @@ class DeviceFit:
         H, hp, d = self.H, self.hp, self.d
         d_a, d_b = d // 2, d - d // 2
         out = []
-        for li, cpl in enumerate(bijection.couplings):
+        if self.wide:
+            # W1 (HP, d_a) | W1T (d_a, HP) | b1 | [Wh (HP, HP) | WhT | bh] | W3 (2 d_b, HP) | W3T (HP, 2 d_b) | b3: every Linear
+            # weight (out, in) appears as itself and transposed; gathering fills both, scattering reads both (they are equal)
+            for li, cpl in enumerate(bijection.couplings):
+                lin = list(cpl.conditioner)
+                cur = li * self.layer_stride
+                mats = [(lin[0], hp, d_a)] + [(l, hp, hp) for l in lin[1:-1]] + [(lin[-1], 2 * d_b, hp)]
+                for l, rows_p, cols_p in mats:
+                    r, c = l.weight.shape
+                    out.append((l.weight, cur, r, c, cols_p, 1))
+                    cur += rows_p * cols_p
+                    out.append((l.weight, cur, r, c, 1, rows_p))
+                    cur += rows_p * cols_p
+                    out.append((l.bias, cur, 1, r, 0, 1))
+                    cur += rows_p
+        for li, cpl in enumerate(bijection.couplings if not self.wide else []):
             lin = list(cpl.conditioner)
             cur = li * self.layer_stride
             out.append((lin[0].weight, cur, H, d_a, 1, hp))             # Linear weight (H, d_a) <-> W1T (d_a, HP)

@@ -110,6 +110,7 @@ class RealNVP(nn.Module):
         state['_pack_cache'] = None
         state.pop('_mods_cache', None)
         state.pop('_device_fit', None)      # flow_training.DeviceFit: device buffers + ctypes structs of THIS object
+        state.pop('_wide_scratch', None)    # workspace of the streamed matrix-core kernels
         return state
 
     # ------------------------------------------------------------------ packing for the kernels
@@ -224,6 +225,16 @@ class RealNVP(nn.Module):
         st = hip.NfmcRealNVP(d, self.n_coupling, H, nhl, float(self.min_scale), int(self.n_bins), hip.ptr(keep[1]),
                              hip.ptr(keep[2]), hip.ptr(keep[3]), hip.ptr(keep[4]), hip.ptr(keep[0]), stride,
                              float(self.spline_bound), 0)
+        # the streamed matrix-core kernels (wide conditioner at d = 32 .. 512 other than 64 / 128) work in a slab the CALLER
+        # holds: sized here once per flow object at its bound -- 2 x 256 workgroup slots x 128 rows of d floats (67 MB at
+        # d = 256), whatever the number of rows of a call -- and kept across re-packs
+        need = int(lib.nfmc_flow_scratch_bytes(C.byref(st), 1 << 40, 1))
+        if need:
+            ws = self.__dict__.get('_wide_scratch')
+            if ws is None or ws.device != torch.device(device) or ws.numel() * 4 < need:
+                ws = self.__dict__['_wide_scratch'] = torch.empty(need // 4, dtype=torch.float32, device=device)
+            st.scratch, st.scratch_bytes = hip.ptr(ws), need
+            keep.append(ws)
         cache[int(min_hidden)] = (key, (st, keep))
         self._pack_cache = cache
         return st, keep

@@ -43,7 +43,8 @@ class NfmcRealNVP(C.Structure):
     _fields_ = [('d', C.c_int32), ('n_coupling', C.c_int32), ('n_hidden', C.c_int32), ('n_hidden_layers', C.c_int32),
                 ('min_scale', C.c_float), ('n_bins', C.c_int32),
                 ('ea0_log_scale', c_fp), ('ea0_shift', c_fp), ('ea1_log_scale', c_fp), ('ea1_shift', c_fp),
-                ('weights', c_fp), ('layer_stride', C.c_int64), ('spline_bound', C.c_float), ('reserved', C.c_int32)]
+                ('weights', c_fp), ('layer_stride', C.c_int64), ('spline_bound', C.c_float), ('reserved', C.c_int32),
+                ('scratch', c_fp), ('scratch_bytes', C.c_int64)]
 
 
 class NfmcSampleStore(C.Structure):
@@ -110,7 +111,8 @@ class NfmcAdamW(C.Structure):
 class NfmcFlowFit(C.Structure):
     _fields_ = [('flow', NfmcRealNVP), ('params', c_fp), ('adam_m', c_fp), ('adam_v', c_fp), ('n_params', C.c_int64),
                 ('ea_off', C.c_int64), ('partial', c_fp), ('partial_floats', C.c_int64), ('status', c_fp),
-                ('x_val', c_fp), ('n_val', C.c_int64), ('params_prev', c_fp), ('best', c_fp), ('run_state', c_fp)]
+                ('x_val', c_fp), ('n_val', C.c_int64), ('params_prev', c_fp), ('best', c_fp), ('run_state', c_fp),
+                ('scratch', c_fp), ('scratch_bytes', C.c_int64)]
 
 
 class NfmcBlobPiece(C.Structure):
@@ -142,6 +144,7 @@ SYMBOLS = [
     ('nfmc_realnvp_padded_hidden', C.c_int32, [C.c_int32]),
     ('nfmc_realnvp_layer_floats', C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     ('nfmc_coupling_layer_floats', C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    ('nfmc_flow_scratch_bytes', C.c_int64, [C.POINTER(NfmcRealNVP), C.c_int64, C.c_int32]),
     ('nfmc_realnvp_forward_f32', C.c_int, [C.POINTER(NfmcRealNVP), c_fp, C.c_int64, c_fp, c_fp, c_fp, c_fp]),
     ('nfmc_realnvp_inverse_f32', C.c_int, [C.POINTER(NfmcRealNVP), c_fp, C.c_int64, c_fp, c_fp, c_fp,
                                            C.POINTER(NfmcRng), c_fp]),
@@ -165,6 +168,7 @@ SYMBOLS = [
     ('nfmc_philox_uniforms_f32', C.c_int, [C.POINTER(NfmcRng), C.c_int32, C.c_int64, c_fp, c_fp]),
     ('nfmc_flow_fit_supported_f32', C.c_int, [C.POINTER(NfmcRealNVP)]),
     ('nfmc_flow_fit_partial_floats', C.c_int64, [C.c_int64, C.c_int64]),
+    ('nfmc_flow_fit_workspace', C.c_int64, [C.POINTER(NfmcRealNVP), C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_int64)]),
     ('nfmc_flow_fit_step_f32', C.c_int, [C.POINTER(NfmcFlowFit), c_fp, C.c_int64, C.POINTER(NfmcAdamW), c_fp]),
     ('nfmc_flow_variational_fit_step_f32', C.c_int, [C.POINTER(NfmcFlowFit), C.POINTER(NfmcPotential), c_fp, C.c_int64,
                                                     C.POINTER(NfmcAdamW), c_fp]),

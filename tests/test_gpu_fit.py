@@ -478,3 +478,92 @@ def test_refit_split_on_the_device_matches_the_oracle_rows(dev):
     # 2-D events keep their shape
     xt, xv = train_val_split(torch.randn(3, 40, 4, 2).to(dev), 0.5, 4096, 4096)
     assert xt.shape == (60, 4, 2) and xv.shape == (60, 4, 2)
+
+
+WIDE_CASES = [  # d, n_hidden, hidden layers, coupling layers, rows, potential / 'ml', NICE
+    (128, 128, 2, 2, 300, 'funnel', False), (128, 128, 2, 2, 200, 'ml', False), (64, 40, 1, 3, 130, 'sum', False),
+    (64, 64, 2, 2, 129, 'ml', False), (128, 100, 1, 2, 128, 'diag', False), (64, 128, 2, 1, 77, 'ml', True),
+]
+
+
+@pytest.mark.parametrize('d,H,nhl,nl,n,kind,nice', WIDE_CASES)
+def test_wide_conditioner_gradients_on_the_matrix_cores_match_autograd(dev, d, H, nhl, nl, n, kind, nice):
+    """Conditioners of width 33..128 at d = 64 / 128 (C4's flow: 128 x 2 at d = 128) are fitted on the device too
+    (csrc/fit_mfma.hip: weight gradients as batch-axis GEMMs on the matrix cores).  One step with lr = 0, beta1 = 0 leaves the
+    first moment equal to the gradient: every entry of every parameter against autograd of the CPU restatement (oracle/flow.py),
+    for the reverse-KL loss (neutra.py:84-91, imh.py:67-72) and the maximum-likelihood loss (jump.py:139-151); the two
+    orientations of every matrix in the blob carry the same gradient bit for bit."""
+    from nfmc_amd.flow_training import DeviceFit
+    from nfmc_amd.potentials import DiagonalGaussian, Funnel, SumOfSquares
+    of, f = _flow(d, H, nhl, nl, 70 + d + H, nice)
+    f.to(dev)
+    assert DeviceFit.supported(f.bijection, dev)
+    g0 = torch.Generator().manual_seed(300 + d)
+    rows = torch.randn(n, d, generator=g0) * (0.8 if kind == 'ml' else 1.0)
+    fit = DeviceFit(f.bijection, dev, n, lr=0.0)
+    assert fit.wide
+    fit.opt.beta1, fit.opt.weight_decay = 0.0, 0.0
+    before = fit.params.clone()
+    if kind == 'ml':
+        fit.step(rows.to(dev), 0)
+        loss = -of.log_prob(rows).mean()
+    else:
+        pot = {'sum': SumOfSquares((d,)), 'funnel': Funnel((d,), 3.0),
+               'diag': DiagonalGaussian((d,), torch.linspace(-0.5, 0.5, d), torch.linspace(0.6, 1.7, d))}[kind]
+        fit.step_variational(rows.to(dev), pot.descriptor(dev), 0)
+        x, ld = of.bijection.inverse(rows)
+        loss = (of.base_log_prob(rows) - ld + pot(x)).mean()
+    loss.backward()
+    loss_gpu, applied, _val = (float(v) for v in fit.status.cpu())
+    assert applied == 1.0 and torch.equal(fit.params, before)
+    np.testing.assert_allclose(loss_gpu, float(loss.detach()), rtol=3e-5, atol=3e-5)
+    gflow = copy.deepcopy(f)
+    fit.write_back(fit.m, bijection=gflow.bijection)
+    want = dict(of.named_parameters())
+    for name, p in gflow.named_parameters():
+        w = want[name].grad
+        scale = max(float(w.abs().max()), 1e-3)
+        np.testing.assert_allclose(p.detach().cpu().numpy(), w.numpy(), atol=2e-4 * scale, rtol=0, err_msg=name)
+    # both orientations of every matrix: identical gradients (so AdamW keeps the copies equal)
+    for p_, off, r, c, rs, cs in fit._layout(f.bijection):
+        if r > 1 and rs != 1:
+            a = fit.m[off:off + r * rs].view(r, rs)[:, :c]
+            twin = [q for q in fit._layout(f.bijection) if q[0] is p_ and q[4] == 1]
+            (_p2, off2, _r2, _c2, _rs2, cs2), = twin
+            b = fit.m[off2:off2 + c * cs2].view(c, cs2)[:, :r].t()
+            assert torch.equal(a, b)
+
+
+def test_wide_conditioner_variational_fit_runs_on_the_device_and_learns(dev, monkeypatch):
+    """`Flow.variational_fit` of C4's flow (d = 128, conditioner 128 x 2) to the funnel: the run goes through
+    nfmc_flow_fit_epochs_f32 (spied), the reverse-KL estimate falls, the flow's kernels see the trained weights (the weight
+    blob is the trainable vector), and the eager torch loop (NFMC_FIT_TORCH=1) reaches a comparable loss."""
+    from nfmc_amd import flow_training as ft
+    from nfmc_amd.flows import Flow, RealNVP
+    from nfmc_amd.potentials import Funnel
+    d = 128
+    pot = Funnel((d,), 3.0)
+    res = {}
+    for torch_path in ('0', '1'):
+        monkeypatch.setenv('NFMC_FIT_TORCH', torch_path)
+        calls = []
+        orig = ft.DeviceFit.run_calls
+        monkeypatch.setattr(ft.DeviceFit, 'run_calls',
+                            lambda self, ctl, z, c0, k, _o=orig, **kw: (calls.append(k), _o(self, ctl, z, c0, k, **kw))[1])
+        torch.manual_seed(1)
+        f = Flow(RealNVP((d,), conditioner_kwargs={'n_hidden': 128, 'n_layers': 2})).to(dev)
+
+        def rkl():
+            z = torch.randn(4096, d, generator=torch.Generator().manual_seed(5)).to(dev)
+            x, ld = f.bijection.inverse(z)
+            return float((-0.5 * (z * z).sum(1) - ld + pot(x)).mean())
+        l0 = rkl()
+        torch.manual_seed(2)
+        f.variational_fit(lambda v: -pot(v), n_epochs=60, lr=0.01, n_samples=1024, early_stopping=False, keep_best_weights=True,
+                          show_progress=False, potential=pot)
+        res[torch_path] = (l0, rkl(), len(calls))
+        monkeypatch.setattr(ft.DeviceFit, 'run_calls', orig)
+    (l0, la, ca), (_l0, lb, cb) = res['0'], res['1']
+    assert ca == 60 and cb == 0
+    assert la < l0 - 5.0 and lb < l0 - 5.0, res
+    assert abs(la - lb) < 0.25 * abs(l0 - lb), res

@@ -753,3 +753,24 @@ def test_refit_split_permutation_matches_the_oracle_and_is_a_permutation():
     counts = np.bincount(np.asarray(a) * 16 // n, minlength=16)          # 128 expected per sixteenth
     assert counts.min() > 80 and counts.max() < 180, counts.tolist()
     assert lib.nfmc_rows_sample_index(n, 11, n) == -1 and lib.nfmc_rows_sample_index(0, 1, 0) == -1
+
+
+def test_streamed_kernels_workspace_is_bounded_and_caller_supplied():
+    """include/nfmc_hip.h: the library never allocates.  The streamed matrix-core kernels (wide conditioner at d = 256 / 512
+    ...) take their slab from NfmcRealNVP.scratch; its size is bounded by the workgroup slots (256 x 128 rows of d floats, x 2
+    with the gradient), not by n, and 0 for every shape that runs register- or LDS-resident."""
+    import ctypes as C
+    from nfmc_amd import hip
+    lib = hip.lib()
+
+    def need(d, H, n, grad):
+        st = hip.NfmcRealNVP(d, 2, H, 2, 1e-3, 0, None, None, None, None, None, 0, 0.0, 0)
+        return int(lib.nfmc_flow_scratch_bytes(C.byref(st), n, grad))
+    assert need(256, 128, 100, 0) == 128 * 256 * 4 and need(256, 128, 100, 1) == 2 * 128 * 256 * 4      # one workgroup slot
+    assert need(256, 128, 10 ** 9, 1) == need(256, 128, 256 * 128, 1) == 2 * 256 * 128 * 256 * 4       # bounded by 256 slots
+    assert need(512, 64, 70000, 0) == 256 * 128 * 512 * 4
+    for d, H in ((128, 128), (64, 64), (256, 8), (256, 32), (100, 128)):
+        assert need(d, H, 4096, 1) == 0, (d, H)
+    # the composed wide trajectory's scratch contains the gradient kernel's slab
+    sb = lib.nfmc_neutra_scratch_bytes
+    assert sb(1000, 256, 128, 2, 2) == 4 * (4 * 1000 * 256 + 3000 + 2 * 8 * 128 * 256)
