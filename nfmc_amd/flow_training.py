@@ -399,6 +399,20 @@ class DeviceFit:
         half = (n_calls_done & 1) * self.hip.FIT_STATE_FLOATS
         return self.run_state[half:half + self.hip.FIT_STATE_FLOATS].tolist()
 
+    def state_later(self, n_calls_done):
+        """The same without stalling the stream: the state is copied to pinned host memory behind the run's kernels and an
+        event recorded; `PendingFit.result()` waits for THAT event only (kernels enqueued after the run keep the GPU busy)."""
+        half = (n_calls_done & 1) * self.hip.FIT_STATE_FLOATS
+        if self.__dict__.get('_pinned') is None:
+            self._pinned = [torch.empty(self.hip.FIT_STATE_FLOATS, dtype=torch.float32).pin_memory() for _ in range(2)]
+            self._pin_turn = 0
+        self._pin_turn ^= 1
+        host = self._pinned[self._pin_turn]
+        host.copy_(self.run_state[half:half + self.hip.FIT_STATE_FLOATS], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return PendingFit(host, ev)
+
     def nll(self, x):
         """Mean NLL of rows x under the CURRENT trainable vector (forward kernel), as a device scalar."""
         n = int(x.shape[0])
@@ -423,6 +437,27 @@ class DeviceFit:
             bij._pack_cache = {0: (bij._version_key(self.dev) + (0,), (self._struct(vec), keep))}
 
 
+class PendingFit:
+    """Outcome of a device fit whose check was deferred (`Flow.fit(..., defer_check=True)`): `result()` waits for the fit's
+    own kernels (not for what was enqueued after them), raises the ValueError of a diverged run (jump.py:150) and returns
+    the best monitored loss."""
+
+    def __init__(self, host_state=None, event=None, state=None):
+        self._host, self._event, self._state = host_state, event, state
+
+    def result(self):
+        from . import hip
+        if self._state is None:
+            if self._event is not None:
+                self._event.synchronize()
+            self._state = self._host.tolist() if self._host is not None else None
+            self._host = self._event = None
+        st = self._state
+        if st is not None and st[hip.FIT_DIVERGED]:
+            raise ValueError('flow training diverged (non-finite loss)')
+        return st[hip.FIT_BEST_LOSS] if st is not None else math.inf
+
+
 def _run_chunk(time_limit_seconds, early_stopping):
     """Calls enqueued between two looks at the run's state (one 32-byte read each): everything at once when nothing can
     end the run early, 64 epochs when early stopping can (calls after the end are no-ops, but they are still launches), 16
@@ -432,7 +467,8 @@ def _run_chunk(time_limit_seconds, early_stopping):
     return 64 if early_stopping else 1 << 30
 
 
-def _fit_device(flow, xt, xv, n_epochs, lr, early_stopping, early_stopping_threshold, keep_best_weights, time_limit_seconds):
+def _fit_device(flow, xt, xv, n_epochs, lr, early_stopping, early_stopping_threshold, keep_best_weights, time_limit_seconds,
+                defer=False):
     """`_loop` for the full-batch maximum-likelihood fit, on the device end to end.  Same order of events per epoch e --
     loss at the weights w_e, step unless it is not finite, validation at the new weights w_{e+1}, best-so-far / early
     stopping bookkeeping -- but decided in the fold kernel (csrc/fit_kernels.hip: fit_fold_kernel): call c reports the batch
@@ -446,6 +482,12 @@ def _fit_device(flow, xt, xv, n_epochs, lr, early_stopping, early_stopping_thres
     n_epochs = int(n_epochs)
     ctl = fitter.control(n_epochs, early_stopping, early_stopping_threshold, keep_best_weights)
     total = n_epochs + (1 if xv is not None else 0)
+    if defer and time_limit_seconds is None and not early_stopping and total > 0:
+        # nothing can end the run early: every call and the write-back are enqueued, the state follows the stream to pinned
+        # memory, and the caller checks it when it next needs to (the refit of jump.py:193-201: at the next refit)
+        fitter.run_calls(ctl, xt, 0, total)
+        fitter.write_back(fitter.best if keep_best_weights else None)
+        return fitter.state_later(total)
     t0 = time.time()
     done, st = 0, None
     try:
@@ -476,22 +518,30 @@ def _fit_device(flow, xt, xv, n_epochs, lr, early_stopping, early_stopping_thres
 
 def fit(flow, x_train, x_val=None, n_epochs: int = 500, lr: float = 0.05, batch_size='adaptive',
         shuffle: bool = True, show_progress: bool = False, keep_best_weights: bool = True,
-        early_stopping: bool = False, early_stopping_threshold: int = 50, time_limit_seconds=None, **_ignored):
-    """Maximum-likelihood fit: minimise -mean log q(x_train)."""
+        early_stopping: bool = False, early_stopping_threshold: int = 50, time_limit_seconds=None, defer_check: bool = False,
+        **_ignored):
+    """Maximum-likelihood fit: minimise -mean log q(x_train).
+    `defer_check` (beyond the reference's keywords): on the device path, return a `PendingFit` instead of waiting for the
+    run -- its `result()` raises the ValueError of a diverged fit; the samplers' per-iteration refit uses it so that the GPU
+    is never idle behind a fit."""
+    import os
     dev = _train_device(flow)
-    flow.to(dev)
+    resident = flow.bijection.__dict__.get('_device_fit')
+    first_param = next(flow.parameters(), None)
+    resident = resident is not None and resident.dev == dev and first_param is not None and first_param.device == dev
+    if not resident:       # a flow that was fitted here before is on the device already (checked again by the fitter)
+        flow.to(dev)
     xt = x_train.detach().to(dev, torch.float32).reshape(x_train.shape[0], -1)
     xv = x_val.detach().to(dev, torch.float32).reshape(x_val.shape[0], -1) if x_val is not None and len(x_val) else None
     n = xt.shape[0]
     if n == 0:
-        return
+        return PendingFit() if defer_check else None
     bs = n if batch_size == 'adaptive' or batch_size is None else max(1, min(int(batch_size), n))
-    import os
-    if (bs >= n and os.environ.get('NFMC_FIT_TORCH') != '1' and DeviceFit.supported(flow.bijection, dev)):
+    if (bs >= n and os.environ.get('NFMC_FIT_TORCH') != '1' and (resident or DeviceFit.supported(flow.bijection, dev))):
         # full-batch fit of a RealNVP the fit kernels cover: every epoch is two launches of libnfmc_hip (fit_kernels.hip)
-        _fit_device(flow, xt.contiguous(), xv.contiguous() if xv is not None else None, n_epochs, lr, early_stopping,
-                    early_stopping_threshold, keep_best_weights, time_limit_seconds)
-        return
+        out = _fit_device(flow, xt.contiguous(), xv.contiguous() if xv is not None else None, n_epochs, lr, early_stopping,
+                          early_stopping_threshold, keep_best_weights, time_limit_seconds, defer=defer_check)
+        return out if defer_check else None
     gen = torch.Generator(device='cpu').manual_seed(int(torch.randint(0, 2 ** 31, ()).item()))
 
     def nll(x):
@@ -507,6 +557,7 @@ def fit(flow, x_train, x_val=None, n_epochs: int = 500, lr: float = 0.05, batch_
     val_fn = (lambda: nll(xv)) if xv is not None else None
     _loop(flow, loss_fn, val_fn, n_epochs, lr, early_stopping, early_stopping_threshold, keep_best_weights,
           show_progress, time_limit_seconds)
+    return PendingFit() if defer_check else None
 
 
 def _variational_fit_device(flow, potential, dev, n_epochs, lr, n_samples, early_stopping, early_stopping_threshold,

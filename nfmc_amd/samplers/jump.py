@@ -255,6 +255,17 @@ class JumpNFMC(Sampler):
     def name(self):
         return 'Jump MCMC'
 
+    def _refit(self, flow, x_train, x_val):
+        """jump.py:201 `self.kernel.flow.fit(x_train=..., x_val=..., **flow_fit_kwargs)`.  The build's own Flow takes
+        `defer_check`: the run's kernels are enqueued and the divergence check (ValueError) is made when the next refit
+        starts / when sampling ends, so that the next inner launch is queued behind the fit without a host round trip; a
+        foreign flow object is called exactly as the reference calls it."""
+        from ..flows import Flow
+        if isinstance(flow, Flow):
+            return flow.fit(x_train=x_train, x_val=x_val, **{'defer_check': True, **self.params.flow_fit_kwargs})
+        flow.fit(x_train=x_train, x_val=x_val, **self.params.flow_fit_kwargs)
+        return None
+
     def warmup(self, x0, show_progress: bool = True, time_limit_seconds=None) -> MCMCOutput:
         """jump.py:104-154: tune the inner sampler, then MLE-fit the flow on its samples (rollback on ValueError)."""
         inner_limit = 0.7 * time_limit_seconds if time_limit_seconds is not None else None
@@ -299,6 +310,7 @@ class JumpNFMC(Sampler):
         store = DeviceSampleStore(n, d, run.dev, T * (K + 1), getattr(self.params, 'thinning', 1),
                                   getattr(self.params, 'max_samples', None)) if (self.params.store_samples and T > 0) else None
         fit_buf = torch.empty(K, n, d, dtype=torch.float32, device=run.dev) if self.params.fit_nf else None
+        pending_fit = None     # the latest refit's deferred check (flow_training.PendingFit)
         logq = torch.empty(n, dtype=torch.float32, device=run.dev)
         # Can the jump run on the flow-MH kernels?  The answer needs the packed weights (host work, a small upload): asked
         # before the first launch only when the jump is to ride behind the inner kernel, otherwise after the first inner
@@ -355,7 +367,9 @@ class JumpNFMC(Sampler):
                                                  train_pct=self.params.train_pct,
                                                  max_train_size=self.params.max_train_size,
                                                  max_val_size=self.params.max_val_size, shard=self.shard)
-                flow.fit(x_train=x_train, x_val=x_val, **self.params.flow_fit_kwargs)
+                if pending_fit is not None:
+                    pending_fit.result()     # the previous refit: a diverged run raises here (jump.py:201 raises at once)
+                pending_fit = self._refit(flow, x_train, x_val)
             # ---- the jump (jump.py:205-243)
             if tail_done:
                 jump_target_calls += 2 * n if self.params.adjusted_jumps else 0
@@ -376,6 +390,8 @@ class JumpNFMC(Sampler):
         # end of the call, ordered for the GPU: the copy of the final state and the statistics fold are enqueued right
         # behind the last kernel, and the one device-to-host copy of the totals is the only synchronisation (with a
         # synchronize first, then the fold, then host work, then the clone, the stream sat idle ~110 us per call)
+        if pending_fit is not None:
+            pending_fit.result()
         last_sample = run.x.reshape(n, *event_shape).clone()
         inner._cur_run = None
         sum_x, sum_x2, cnt, jc = run.stats.host_totals()

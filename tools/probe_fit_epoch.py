@@ -26,7 +26,8 @@ def ev_ms(fn, reps=5):
 def main():
     dev = torch.device('cuda', 0)
     g = torch.Generator().manual_seed(0)
-    for d, n, nv, H in ((256, 4096, 4096, None), (256, 2867, 1229, None), (64, 4096, 1024, None), (64, 1024, 0, None), (128, 4096, 4096, 16)):
+    for d, n, nv, H in ((256, 4096, 4096, None), (256, 2867, 1229, None), (64, 4096, 1024, None), (64, 1024, 0, None), (128, 4096, 4096, 16),
+                        (128, 4096, 4096, 128), (128, 1024, 0, 128), (64, 1024, 0, 64)):
         torch.manual_seed(1)
         ck = {'conditioner_kwargs': {'n_hidden': H, 'n_layers': 2}} if H else {}
         f = Flow(RealNVP((d,), **ck)).to(dev)
@@ -40,6 +41,21 @@ def main():
         per_epoch = ev_ms(lambda: fit.run_calls(ctl, x, 0, 200)) / 200
         print('d=%d H=%d rows=%d val=%d: %.1f us per epoch (n_params %d)' % (d, f.bijection.n_hidden, n, nv, per_epoch * 1e3,
                                                                                 fit.n_params), flush=True)
+    # C4's warmup: the variational fit of the 128 x 2 conditioner at d = 128 to the funnel, 1024 latents per epoch
+    from nfmc_amd.potentials import Funnel
+    pot = Funnel((128,), 3.0)
+    for path in ('0', '1'):
+        os.environ['NFMC_FIT_TORCH'] = path
+        torch.manual_seed(1)
+        f = Flow(RealNVP((128,), conditioner_kwargs={'n_hidden': 128, 'n_layers': 2})).to(dev)
+        f.variational_fit(lambda v: -pot(v), n_epochs=3, lr=0.01, n_samples=1024, early_stopping=False, potential=pot)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        f.variational_fit(lambda v: -pot(v), n_epochs=200, lr=0.01, n_samples=1024, early_stopping=False, potential=pot)
+        torch.cuda.synchronize()
+        print('Flow.variational_fit, d=128, H=128x2, 200 epochs of 1024 latents (%s): %.1f ms' % (
+            'eager torch loop' if path == '1' else 'device', 1e3 * (time.perf_counter() - t0)), flush=True)
+    os.environ['NFMC_FIT_TORCH'] = '0'
     # the refit as the sampler issues it: split of a (5, 32768, 256) block + Flow.fit(2 epochs)
     d, K, nch = 256, 5, 32768
     torch.manual_seed(1)
