@@ -377,7 +377,17 @@ __global__ void __launch_bounds__(kBlock, (CPL == 8 && HP == 4 && FAST && NB == 
 #pragma unroll
     for (int q = 0; q < CPL; ++q) sx[q] = sxx[q] = 0.f;
     // a wave looks at 64 consecutive rows at a time (their dwell times off the accept masks) and runs the flow pass
-    // only for the rows it has to visit, CPW of them per pass: most 64-row chunks need one or two passes
+    // only for the rows it has to visit, CPW of them per pass: most 64-row chunks need one or two passes.
+    // Round 4 measured two ways of filling the passes better (at C2 a look finds ~17 rows: 2 full passes + 1 of one row,
+    // 2.6 passes per look on average where 2.1 would do) -- both parity-green, both SLOWER, neither kept (tools/ab_c2.sh,
+    // rocprofv3, the 1000-transition call: 0.450 ms for this loop):
+    //   a sliding 64-row window per wave over a contiguous row range that only runs full passes and moves to the first row
+    //   still to be served: 0.678 ms (a third more looks, each an exposed load round trip);
+    //   256 rows per look (four mask-word pairs per lane in one round trip, passes filled across the four windows: 2.2 passes
+    //   per 64 rows, a quarter of the looks): 0.488 ms (four permutes and a rank search per pass, 16 spilled registers at the
+    //   128-register cap).
+    // The passes are not what the kernel waits for: at 43 % VALU-busy the issue time of its ~600-instruction passes is
+    // ~0.22 ms; the rest is the dependent chain of a pass with four waves per SIMD to cover it.
     for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         const int64_t r0 = (tile * kWavesPerBlock + wave) * kWave;
         if (r0 >= total) continue;                                // wave-uniform
