@@ -557,48 +557,81 @@ __global__ void __launch_bounds__(kMfmaBlock, 2) realnvp_inverse_wide_kernel(Nfm
 }
 
 // ------------------------------------------------------------------------------------------------
-// NeuTra HMC (neutra.py:109-129 over hmc.py:61-77,96-126) at these shapes: no fused trajectory kernel; the transition is
-// composed HERE, on the stream, from the gradient kernel above and three elementwise kernels -- momentum draw + H0 + the
-// first half / full step; the steps between two gradients; the Hamiltonian test, masked update and statistics -- with
-// the arithmetic, the Philox streams and the one-gradient-per-position leapfrog of neutra_leapfrog_mfma_kernel.
-// A wave owns a chain: lane l holds the 16-byte blocks l, l + 64, ... of its row (one block = one Philox block).
-struct WideHmc {
-    float *p, *gz, *zq, *gq, *uz, *h0, *uq;   // caller scratch: momentum, grad at the state, proposal position and its grad, U~, H0, U~ at the proposal
+// ------------------------------------------------------------------------------------------------
+// Round 4: ONE launch per NeuTra-HMC transition at these shapes too (neutra_leapfrog_mfma_kernel's structure on the streamed
+// state).  A workgroup slot's slab holds THREE private rows per lane group -- position, gradient, momentum -- in tile-position
+// order; a chain tile's whole trajectory runs on them: momentum draw + H0 + the first half / full step, n_leapfrog times
+// {gradient of the adjusted potential on the slab (the body of neutra_grad_wide_kernel), the steps between two gradients},
+// the Hamiltonian test, the masked update of (z, grad, U~) in the caller's arrays, the kept row and the statistics.  What
+// the composed version (round 3: a gradient launch + an elementwise launch per leapfrog step, 2 L + 3 launches per
+// transition) paid for between the gradients -- launch gaps, the ramp and tail of 2 L + 3 grids, z and the gradient through
+// (n, d) arrays -- is gone; H0 and the trajectory's U~ never leave registers.
+struct WideLeapArgs {
+    NfmcNeutraHmcArgs a;
+    float *gz, *uz;       // caller scratch: gradient and U~ at the current state (n, d) / (n)
+    float* slab;          // 3 x grid x 128 rows of d floats
+    int step;             // transition index within this call
+    float* sample_row;    // store row this transition is kept in, or NULL
 };
-constexpr int kEwBlock = 256, kEwChains = kEwBlock / kWave;
 
-__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-__device__ __forceinline__ void st4(float* p, const f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
-__device__ __forceinline__ f32x4 mass4(const float* m, int b) {
-    f32x4 one;
-    one[0] = one[1] = one[2] = one[3] = 1.f;
-    return m ? ld4(m + 4 * b) : one;
-}
-__device__ __forceinline__ float wave_sum_f(float v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
-    return v;
-}
-
-__global__ void __launch_bounds__(kEwBlock) wide_hmc_begin_kernel(NfmcNeutraHmcArgs a, WideHmc w, int s) {
+template <int TH, int NHL>
+__global__ void __launch_bounds__(kMfmaBlock, 2) neutra_leapfrog_wide_kernel(WideLeapArgs A, int64_t tiles, int dp) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int hp = 16 * TH;
+    constexpr int kSB = (TH == 8 && NHL == 2) ? 1 : 2;
+    const NfmcNeutraHmcArgs& a = A.a;
+    const NfmcRealNVP& f = a.flow;
+    const int d = f.d, TD = f.d / 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int d = a.flow.d;
+    const bool rev = (f.n_coupling & 1) != 0;
     const int64_t n = a.n;
     const float h = a.step_size, hh = a.step_size / 2;
-    for (int64_t row = (int64_t)blockIdx.x * kEwChains + wave; row < n; row += (int64_t)gridDim.x * kEwChains) {
-        const uint32_t gchain = (uint32_t)(a.rng.chain_offset + (uint64_t)row);
+    const int s = A.step;
+    WideCtx c;
+    wide_ctx_init(c, lds, f, lane);
+    const int64_t srow = (int64_t)blockIdx.x * kMfmaChains + wave * 16 + c.col;
+    const int64_t slot_rows = (int64_t)gridDim.x * kMfmaChains;
+    c.xs = A.slab + srow * d + 4 * c.q;
+    c.gs = A.slab + (slot_rows + srow) * d + 4 * c.q;
+    float* const ps = A.slab + (2 * slot_rows + srow) * d + 4 * c.q;
+    double* const red = reinterpret_cast<double*>(lds);   // per-tile statistics: [8 waves][2 d] doubles over the (idle) weight images
+    double* const out = a.stats.sum_x ? a.stats.scratch + (size_t)blockIdx.x * (2 * dp + kStatTail) : nullptr;
+    auto mass_tile = [&](int m) {
+        f32x4 one;
+        one[0] = one[1] = one[2] = one[3] = 1.f;
+        if (!a.inv_mass_diag) return one;
+        return rev ? vec_tile_rev(a.inv_mass_diag, m, c.q, d) : vec_tile(a.inv_mass_diag, m, c.q);
+    };
+    uint32_t n_acc = 0, n_bad = 0;
+    bool first = true;
+    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int64_t row = tile * kMfmaChains + wave * 16 + c.col;
+        const bool active = row < n;
+        const int64_t rrow = active ? row : n - 1;
+        const float* zr = a.z + rrow * d;
+        const float* gr = A.gz + rrow * d;
+        const uint32_t gchain = (uint32_t)(a.rng.chain_offset + (uint64_t)rrow);
+        // ---- start of the trajectory: state and gradient into the slab (tile positions in latent order), momentum draw,
+        // H0, the first half step and the first position (hmc.py:100-106, 68-70)
         float kin = 0.f;
-        for (int b = lane; b < d / 4; b += kWave) {
+        for (int m = 0; m < TD; ++m) {
+            const int p0 = 16 * m + 4 * c.q;
+            f32x4 x = rev ? vec_tile_rev(zr, m, c.q, d) : vec_tile(zr, m, c.q);
+            const f32x4 g = rev ? vec_tile_rev(gr, m, c.q, d) : vec_tile(gr, m, c.q);
             float zz[4];
             if (a.rng.replay_normals) {
-                const f32x4 r = ld4(a.rng.replay_normals + ((int64_t)s * n + row) * d + 4 * b);
+                const float* src = a.rng.replay_normals + ((int64_t)s * n + rrow) * d;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) zz[j] = r[j];
+                for (int j = 0; j < 4; ++j) zz[j] = src[rev ? d - 1 - (p0 + j) : p0 + j];
             } else {
-                philox_normal4(gchain, a.rng.step0 + (uint32_t)s, (uint32_t)b, kTagNoise, (uint32_t)a.rng.seed, (uint32_t)(a.rng.seed >> 32), zz);
+                const int blk = rev ? (d - 4 - p0) >> 2 : p0 >> 2;
+                float w4[4];
+                philox_normal4(gchain, a.rng.step0 + (uint32_t)s, (uint32_t)blk, kTagNoise, (uint32_t)a.rng.seed, (uint32_t)(a.rng.seed >> 32), w4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) zz[j] = rev ? w4[3 - j] : w4[j];
             }
-            const f32x4 mass = mass4(a.inv_mass_diag, b), g = ld4(w.gz + row * d + 4 * b);
-            f32x4 z = ld4(a.z + row * d + 4 * b), p;
+            const f32x4 mass = mass_tile(m);
+            f32x4 p;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float mm = mass[j];
@@ -606,136 +639,159 @@ __global__ void __launch_bounds__(kEwBlock) wide_hmc_begin_kernel(NfmcNeutraHmcA
                 kin = fmaf(v * v, mm, kin);
                 v = fmaf(-hh, g[j], v);                 // hmc.py:68-70
                 p[j] = v;
-                z[j] = fmaf(h, v * mm, z[j]);
+                x[j] = fmaf(h, v * mm, x[j]);
             }
-            st4(w.p + row * d + 4 * b, p);
-            st4(w.zq + row * d + 4 * b, z);
+            tile_st(c.xs, m, x);
+            tile_st(ps, m, p);
         }
-        kin = wave_sum_f(kin);
-        if (lane == 0) w.h0[row] = w.uz[row] + 0.5f * kin;   // hmc.py:103-106
-    }
-}
-
-// after the gradient at the new position: the closing half step of this leapfrog step and, unless it was the last, the
-// opening half step of the next (the same gradient) and the next position
-__global__ void __launch_bounds__(kEwBlock) wide_hmc_step_kernel(NfmcNeutraHmcArgs a, WideHmc w, int last) {
-    const int d = a.flow.d;
-    const int64_t blocks4 = a.n * (int64_t)(d / 4);
-    const float h = a.step_size, hh = a.step_size / 2;
-    for (int64_t e = (int64_t)blockIdx.x * kEwBlock + threadIdx.x; e < blocks4; e += (int64_t)gridDim.x * kEwBlock) {
-        const int b = (int)(e % (d / 4));
-        const f32x4 g = ld4(w.gq + 4 * e);
-        f32x4 p = ld4(w.p + 4 * e);
+        kin = chain_sum(kin);
+        const float h0 = A.uz[rrow] + 0.5f * kin;   // hmc.py:103-106
+        float u = 0.f;
+        for (int l = 0; l < a.n_leapfrog; ++l) {
+            // ---- U~ and its gradient at the position in the slab (neutra_grad_wide_kernel's body; the position is rebuilt)
+            float ldp = wide_ea<kEaInverse>(c, f.ea1_log_scale, f.ea1_shift, rev);
+            for (int ll = f.n_coupling - 1; ll >= 0; --ll)
+                ldp += wide_coupling<TH, NHL, true, kSB>(c, mfma_layer(f.weights + ll * f.layer_stride, d, hp, NHL), (ll & 1) == 0);
+            ldp += wide_ea<kEaInverse>(c, f.ea0_log_scale, f.ea0_shift, false);
+            const float ux = wide_potential_grad(c, a.pot, lane);
+            wide_ea<kEaBackward>(c, f.ea0_log_scale, f.ea0_shift, false);
+            for (int ll = 0; ll < f.n_coupling; ++ll)
+                wide_coupling_backward<TH, NHL, kSB>(c, mfma_layer(f.weights + ll * f.layer_stride, d, hp, NHL), (ll & 1) == 0);
+            wide_ea<kEaBackward>(c, f.ea1_log_scale, f.ea1_shift, rev);
+            u = ux - chain_sum(ldp);
+            // ---- the closing half step and, unless this was the last, the next step's opening half and position
+            const bool last = l + 1 == a.n_leapfrog;
+            for (int m0 = 0; m0 < TD; m0 += 4) {
+                f32x4 g4[4], p4[4], x4[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) p[j] = fmaf(-hh, g[j], p[j]);   // hmc.py:71
-        if (!last) {
-            const f32x4 mass = mass4(a.inv_mass_diag, b);
-            f32x4 z = ld4(w.zq + 4 * e);
+                for (int j = 0; j < 4; ++j)
+                    if (m0 + j < TD) {
+                        g4[j] = tile_ld(c.gs, m0 + j);
+                        p4[j] = tile_ld(ps, m0 + j);
+                        if (!last) x4[j] = tile_ld(c.xs, m0 + j);
+                    }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                p[j] = fmaf(-hh, g[j], p[j]);
-                z[j] = fmaf(h, p[j] * mass[j], z[j]);
+                for (int j = 0; j < 4; ++j)
+                    if (m0 + j < TD) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) p4[j][t] = fmaf(-hh, g4[j][t], p4[j][t]);   // hmc.py:71
+                        if (!last) {
+                            const f32x4 mass = mass_tile(m0 + j);
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) {
+                                p4[j][t] = fmaf(-hh, g4[j][t], p4[j][t]);
+                                x4[j][t] = fmaf(h, p4[j][t] * mass[t], x4[j][t]);
+                            }
+                            tile_st(c.xs, m0 + j, x4[j]);
+                        }
+                        tile_st(ps, m0 + j, p4[j]);
+                    }
             }
-            st4(w.zq + 4 * e, z);
         }
-        st4(w.p + 4 * e, p);
-    }
-}
-
-// Hamiltonian test, masked update (state, its gradient and potential), kept row, statistics slab of the workgroup
-__global__ void __launch_bounds__(kEwBlock) wide_hmc_end_kernel(NfmcNeutraHmcArgs a, WideHmc w, int s, float* sample_row, int dp) {
-    __shared__ double red[kEwChains][2 * 512 + 2];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int d = a.flow.d;
-    const int64_t n = a.n;
-    constexpr int kOwn = 512 / 4 / kWave;   // 16-byte blocks of a row a lane owns at most
-    double sx[kOwn][4], sxx[kOwn][4];
-#pragma unroll
-    for (int o = 0; o < kOwn; ++o)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) sx[o][j] = sxx[o][j] = 0.0;
-    uint32_t n_acc = 0, n_bad = 0;
-    for (int64_t row = (int64_t)blockIdx.x * kEwChains + wave; row < n; row += (int64_t)gridDim.x * kEwChains) {
+        // ---- end of the trajectory: Hamiltonian test, masked update, kept row, statistics
         bool accept = true;
         float lr = 0.f;
         if (a.adjust) {
-            float kin = 0.f;
-            for (int b = lane; b < d / 4; b += kWave) {
-                const f32x4 mass = mass4(a.inv_mass_diag, b), p = ld4(w.p + row * d + 4 * b);
+            float k2 = 0.f;
+            wide_tiles(TD, [&](int m) { return tile_ld(ps, m); },
+                       [&](int m, const f32x4& p) {
+                           const f32x4 mass = mass_tile(m);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) kin = fmaf(p[j] * p[j], mass[j], kin);
-            }
-            kin = wave_sum_f(kin);
-            lr = w.h0[row] - (w.uq[row] + 0.5f * kin);   // hmc.py:107-111
+                           for (int t = 0; t < 4; ++t) k2 = fmaf(p[t] * p[t], mass[t], k2);
+                       });
+            k2 = chain_sum(k2);
+            lr = h0 - (u + 0.5f * k2);   // hmc.py:107-111
             float uni;
             if (a.rng.replay_uniforms) {
-                uni = a.rng.replay_uniforms[(int64_t)s * n + row];
+                uni = a.rng.replay_uniforms[(int64_t)s * n + rrow];
             } else {
                 const uint32_t step = a.rng.step0 + (uint32_t)s;
-                const uint4 r = philox4x32_10((uint32_t)(a.rng.chain_offset + (uint64_t)row), step >> 2, 0u, kTagAccept, (uint32_t)a.rng.seed,
-                                              (uint32_t)(a.rng.seed >> 32));
+                const uint4 r = philox4x32_10(gchain, step >> 2, 0u, kTagAccept, (uint32_t)a.rng.seed, (uint32_t)(a.rng.seed >> 32));
                 uni = u32_to_uniform(pick_word(r, step & 3u));
             }
             accept = fast_ln(uni) < lr;   // hmc.py:112-113
-            if (lane == 0 && !(fabsf(lr) <= 3.0e38f)) n_bad++;
+            if (active && c.q == 0 && !(fabsf(lr) <= 3.0e38f)) n_bad++;
         }
-        if (lane == 0) {
+        accept = accept && active;
+        if (active && c.q == 0) {
             if (accept) {
-                w.uz[row] = w.uq[row];
+                A.uz[row] = u;
                 n_acc++;
             }
             if (a.masks_out) a.masks_out[(int64_t)s * n + row] = accept ? 1 : 0;
             if (a.log_ratio_out) a.log_ratio_out[(int64_t)s * n + row] = lr;
         }
-#pragma unroll
-        for (int o = 0; o < kOwn; ++o) {
-            const int b = lane + o * kWave;
-            if (b < d / 4) {
-                f32x4 zc;
-                if (accept) {
-                    zc = ld4(w.zq + row * d + 4 * b);
-                    st4(a.z + row * d + 4 * b, zc);
-                    st4(w.gz + row * d + 4 * b, ld4(w.gq + row * d + 4 * b));
+        __syncthreads();   // the weight images are idle: their memory takes this tile's statistics
+        for (int m = 0; m < TD; ++m) {
+            const int p0 = 16 * m + 4 * c.q;
+            f32x4 zc;
+            if (accept) {
+                zc = tile_ld(c.xs, m);
+                const f32x4 gc = tile_ld(c.gs, m);
+                if (!rev) {
+                    *reinterpret_cast<f32x4*>(a.z + row * d + p0) = zc;
+                    *reinterpret_cast<f32x4*>(A.gz + row * d + p0) = gc;
                 } else {
-                    zc = ld4(a.z + row * d + 4 * b);
+                    *reinterpret_cast<f32x4*>(a.z + row * d + (d - 4 - p0)) = rev4(zc);
+                    *reinterpret_cast<f32x4*>(A.gz + row * d + (d - 4 - p0)) = rev4(gc);
                 }
-                if (sample_row) st4(sample_row + row * d + 4 * b, zc);
+            } else {
+                zc = rev ? vec_tile_rev(zr, m, c.q, d) : vec_tile(zr, m, c.q);
+            }
+            if (active && A.sample_row) {
+                if (!rev) *reinterpret_cast<f32x4*>(A.sample_row + row * d + p0) = zc;
+                else *reinterpret_cast<f32x4*>(A.sample_row + row * d + (d - 4 - p0)) = rev4(zc);
+            }
+            if (a.stats.sum_x) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    sx[o][j] += (double)zc[j];
-                    sxx[o][j] += (double)zc[j] * (double)zc[j];
+                for (int t = 0; t < 4; ++t) {
+                    const float zv = active ? zc[t] : 0.f;
+                    double v1 = (double)zv, v2 = (double)zv * (double)zv;
+                    for (int k = 1; k < 16; k <<= 1) {
+                        v1 += __shfl_xor(v1, k, kWave);
+                        v2 += __shfl_xor(v2, k, kWave);
+                    }
+                    if (c.col == 0) {
+                        const int pos = p0 + t;
+                        const int cc = rev ? d - 1 - pos : pos;  // logical latent coordinate
+                        red[wave * 2 * d + cc] = v1;
+                        red[wave * 2 * d + d + cc] = v2;
+                    }
                 }
             }
         }
-    }
-    if (!a.stats.sum_x) return;
-#pragma unroll
-    for (int o = 0; o < kOwn; ++o) {
-        const int b = lane + o * kWave;
-        if (b < d / 4) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                red[wave][4 * b + j] = sx[o][j];
-                red[wave][d + 4 * b + j] = sxx[o][j];
+        if (a.stats.sum_x) {
+            __syncthreads();
+            for (int i = threadIdx.x; i < 2 * dp; i += kMfmaBlock) {
+                const int half = i / dp, cc = i - half * dp;
+                double v = 0.0;
+                if (cc < d)
+                    for (int w8 = 0; w8 < kMfmaWaves; ++w8) v += red[w8 * 2 * d + half * d + cc];
+                out[i] = first ? v : out[i] + v;
             }
         }
+        __syncthreads();   // the images are free again for the next tile's stagings
+        first = false;
     }
-    if (lane == 0) {
-        red[wave][2 * d] = (double)n_acc;
-        red[wave][2 * d + 1] = (double)n_bad;
-    }
-    __syncthreads();
-    double* out = a.stats.scratch + (size_t)blockIdx.x * (2 * dp + kStatTail);
-    for (int i = threadIdx.x; i < 2 * dp + kStatTail; i += kEwBlock) {
-        int srci = -1;
-        if (i < dp) srci = i < d ? i : -1;
-        else if (i < 2 * dp) srci = (i - dp) < d ? d + (i - dp) : -1;
-        else if (i == 2 * dp) srci = 2 * d;
-        else if (i == 2 * dp + 1) srci = 2 * d + 1;
-        double v = 0.0;
-        if (srci >= 0)
-            for (int wv = 0; wv < kEwChains; ++wv) v += red[wv][srci];
-        out[i] = v;
+    if (a.stats.sum_x) {
+        for (int m = 1; m < 16; m <<= 1) {   // counted on lane group 0 only
+            n_acc += __shfl_xor(n_acc, m, kWave);
+            n_bad += __shfl_xor(n_bad, m, kWave);
+        }
+        __syncthreads();
+        if (lane == 0) {
+            red[2 * wave] = (double)n_acc;
+            red[2 * wave + 1] = (double)n_bad;
+        }
+        __syncthreads();
+        if (threadIdx.x < 2) {
+            double v = 0.0;
+            for (int w8 = 0; w8 < kMfmaWaves; ++w8) v += red[2 * w8 + threadIdx.x];
+            out[2 * dp + threadIdx.x] = v;
+        }
+        if (first)   // a workgroup without a tile (never launched: grid <= tiles): keep the slab well defined
+            for (int i = threadIdx.x; i < 2 * dp; i += kMfmaBlock) out[i] = 0.0;
+        if (threadIdx.x >= 2 && threadIdx.x < kStatTail) out[2 * dp + threadIdx.x] = 0.0;
     }
 }
 
@@ -845,10 +901,10 @@ int nfmc::nfmc_neutra_potential_grad_wide_f32(const NfmcRealNVP* flow, const Nfm
     return grad_wide_launch(flow, pot, z, n, u_out, grad_out, slab, st);
 }
 
-// scratch of the composed trajectory: p, gz, zq, gq (n d floats each), then uz, h0, uq (n each, the three rounded up to a
-// multiple of 4 floats), then the gradient kernel's slab (state and gradient rows of the workgroup slots)
+// scratch of the fused trajectory: the gradient at the state (n d floats), U~ at the state (n, rounded up to a multiple of
+// 4 floats), then the slab: position, gradient and momentum rows of the workgroup slots
 int64_t nfmc::nfmc_neutra_wide_scratch_floats(int64_t n, int32_t d) {
-    return 4 * n * (int64_t)d + (3 * n + 3) / 4 * 4 + nfmc_wide_slab_floats(n, d, 2);
+    return n * (int64_t)d + (n + 3) / 4 * 4 + nfmc_wide_slab_floats(n, d, 3);
 }
 
 int nfmc::nfmc_neutra_hmc_steps_wide_f32(const NfmcNeutraHmcArgs* args, float* scratch, int64_t scratch_bytes, nfmc_stream_t stream) {
@@ -858,52 +914,39 @@ int nfmc::nfmc_neutra_hmc_steps_wide_f32(const NfmcNeutraHmcArgs* args, float* s
     const int64_t n = a.n;
     if (!nfmc_mfma_wide_supported(d, a.flow.n_hidden, a.flow.n_hidden_layers)) return NFMC_EUNSUPPORTED;
     if (scratch_bytes < nfmc_neutra_wide_scratch_floats(n, d) * (int64_t)sizeof(float)) return NFMC_ESCRATCH;
-    if ((((uintptr_t)a.z) | ((uintptr_t)scratch) | ((uintptr_t)a.inv_mass_diag) | ((uintptr_t)a.samples.base) |
-         ((uintptr_t)a.rng.replay_normals)) & 15u)
-        return NFMC_EUNSUPPORTED;   // 16-byte row blocks
+    if ((((uintptr_t)a.z) | ((uintptr_t)scratch) | ((uintptr_t)a.inv_mass_diag) | ((uintptr_t)a.samples.base)) & 15u)
+        return NFMC_EUNSUPPORTED;   // 16-byte tiles
     hipStream_t st = (hipStream_t)stream;
-    WideHmc w;
-    w.p = scratch;
-    w.gz = w.p + n * d;
-    w.zq = w.gz + n * d;
-    w.gq = w.zq + n * d;
-    w.uz = w.gq + n * d;
-    w.h0 = w.uz + n;
-    w.uq = w.h0 + n;
+    WideLeapArgs A;
+    A.a = a;
+    A.gz = scratch;
+    A.uz = A.gz + n * d;
+    A.slab = A.uz + (n + 3) / 4 * 4;
     const int dp = padded_d(d);
-    const int64_t groups = (n + kEwChains - 1) / kEwChains;
-    const int grid_c = (int)(groups < kMaxGrid ? groups : kMaxGrid);                      // one wave per chain
-    const int64_t eblocks = (n * (int64_t)(d / 4) + kEwBlock - 1) / kEwBlock;
-    const int grid_e = (int)(eblocks < 4 * kMaxGrid ? eblocks : 4 * kMaxGrid);            // one thread per 16-byte block
-    if (a.stats.sum_x && a.stats.scratch_bytes < (int64_t)grid_c * (2 * dp + kStatTail) * (int64_t)sizeof(double)) return NFMC_ESCRATCH;
-    int rc = grad_wide_check(&a.flow, &a.pot, a.z, n, w.gz);
+    const int64_t tiles = (n + kMfmaChains - 1) / kMfmaChains;
+    const int grid = wide_grid(n);
+    if (a.stats.sum_x && a.stats.scratch_bytes < (int64_t)grid * (2 * dp + kStatTail) * (int64_t)sizeof(double)) return NFMC_ESCRATCH;
+    int rc = grad_wide_check(&a.flow, &a.pot, a.z, n, A.gz);
     if (rc) return rc;
-    // ONE slab for the gradients of the whole call, behind the trajectory's arrays in the caller's scratch
-    float* slab = scratch + 4 * n * (int64_t)d + (3 * n + 3) / 4 * 4;
-    // U~ and its gradient at the state (also after the caller changed z)
-    rc = grad_wide_launch(&a.flow, &a.pot, a.z, n, w.uz, w.gz, slab, st);
-    int countdown = a.samples.countdown, srow = a.samples.row;   // one pass per transition: the store cursor runs here
+    // U~ and its gradient at the state (also after the caller changed z), on the first two copies of the slab
+    rc = grad_wide_launch(&a.flow, &a.pot, a.z, n, A.uz, A.gz, A.slab, st);
+    const NfmcRealNVP* flow = &a.flow;
+    int countdown = a.samples.countdown, srow = a.samples.row;   // one launch per transition: the store cursor runs here
     for (int s = 0; s < a.n_steps && rc == NFMC_OK; ++s) {
-        float* sample_row = nullptr;
+        A.step = s;
+        A.sample_row = nullptr;
         if (a.samples.base) {
             if (countdown > 0) {
                 --countdown;
             } else {
-                sample_row = a.samples.base + (int64_t)srow * n * d;
+                A.sample_row = a.samples.base + (int64_t)srow * n * d;
                 srow = srow + 1 == a.samples.ring_rows ? 0 : srow + 1;
                 countdown = a.samples.stride - 1;
             }
         }
-        hipLaunchKernelGGL(wide_hmc_begin_kernel, dim3(grid_c), dim3(kEwBlock), 0, st, a, w, s);
-        for (int l = 0; l < a.n_leapfrog; ++l) {
-            rc = grad_wide_launch(&a.flow, &a.pot, w.zq, n, w.uq, w.gq, slab, st);
-            if (rc) break;
-            hipLaunchKernelGGL(wide_hmc_step_kernel, dim3(grid_e), dim3(kEwBlock), 0, st, a, w, l + 1 == a.n_leapfrog ? 1 : 0);
-        }
-        if (rc) break;
-        hipLaunchKernelGGL(wide_hmc_end_kernel, dim3(grid_c), dim3(kEwBlock), 0, st, a, w, s, sample_row, dp);
-        if (a.stats.sum_x)
-            hipLaunchKernelGGL(stats_finish_kernel<true>, dim3(stats_finish_grid(dp)), dim3(kFinishBlock), 0, st, a.stats.scratch, grid_c, dp, d,
+        NFMC_WIDE_DISPATCH(neutra_leapfrog_wide_kernel, A, tiles, dp)
+        if (rc == NFMC_OK && a.stats.sum_x)
+            hipLaunchKernelGGL(stats_finish_kernel<true>, dim3(stats_finish_grid(dp)), dim3(kFinishBlock), 0, st, a.stats.scratch, grid, dp, d,
                                a.stats, (unsigned long long)n);
     }
     const hipError_t le = hipGetLastError();

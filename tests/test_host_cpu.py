@@ -771,6 +771,7 @@ def test_streamed_kernels_workspace_is_bounded_and_caller_supplied():
     assert need(512, 64, 70000, 0) == 256 * 128 * 512 * 4
     for d, H in ((128, 128), (64, 64), (256, 8), (256, 32), (100, 128)):
         assert need(d, H, 4096, 1) == 0, (d, H)
-    # the composed wide trajectory's scratch contains the gradient kernel's slab
+    # the fused wide trajectory's scratch: gradient and U~ at the state + three slab rows (position, gradient, momentum) per
+    # lane group of a workgroup slot
     sb = lib.nfmc_neutra_scratch_bytes
-    assert sb(1000, 256, 128, 2, 2) == 4 * (4 * 1000 * 256 + 3000 + 2 * 8 * 128 * 256)
+    assert sb(1000, 256, 128, 2, 2) == 4 * (1000 * 256 + 1000 + 3 * 8 * 128 * 256)

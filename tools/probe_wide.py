@@ -56,6 +56,18 @@ def main():
         except Exception as e:   # d = 512: the wave tile and the hidden buffer exceed the LDS
             print('d=%d  forward (VALU tile kernels)   no kernel (%s)' % (d, type(e).__name__))
         del os.environ['NFMC_FLOW_NO_MFMA']
+        # one NeuTra-HMC trajectory (L = 10) of 32768 chains through the sampler: the fused trajectory kernel (round 4)
+        from nfmc_amd.sample import create_sampler
+        nt = 32768
+        smp = create_sampler(Funnel((d,), 3.0), strategy='neutra_hmc', flow='realnvp',
+                             flow_kwargs={'conditioner_kwargs': {'n_hidden': 128, 'n_layers': 2}},
+                             inner_kernel_kwargs={'n_leapfrog_steps': 10, 'step_size': 0.02},
+                             param_kwargs={'n_iterations': 20, 'store_samples': False})
+        smp.kernel.flow.load_state_dict(f.state_dict())
+        smp.seed = 0
+        z0 = 0.5 * x[:nt]
+        t = timed(lambda: smp.sample(z0, show_progress=False), 3)
+        print('d=%d  neutra_hmc, L = 10, %d chains: %8.3f ms per trajectory (20 in one call)' % (d, nt, t / 20))
         nb = min(n, 8192)
         f.to(dev)
 
