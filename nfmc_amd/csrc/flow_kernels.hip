@@ -332,9 +332,9 @@ extern "C" int nfmc_realnvp_forward_f32(const NfmcRealNVP* flow, const float* x,
     if (rc) return rc;
     if (!x || n <= 0) return NFMC_EINVAL;
     if (use_mfma_flow(flow) && al16(x) && al16(z)) return nfmc_realnvp_forward_mfma_f32(flow, x, n, z, logdet, log_prob, stream);
-    if (use_mfma_wide(flow) && al16(x) && al16(z)) {   // "unsupported" from there = no stream-ordered allocator: the kernels below
+    if (use_mfma_wide(flow) && al16(x) && al16(z)) {   // a caller that brought no workspace (NfmcRealNVP.scratch): the kernels below
         rc = nfmc_realnvp_forward_wide_f32(flow, x, n, z, logdet, log_prob, stream);
-        if (rc != NFMC_EUNSUPPORTED) return rc;
+        if (!(rc == NFMC_ESCRATCH && !flow->scratch)) return rc;
     }
     const int64_t tiles = (n + 63) / 64;
     const int grid = (int)(tiles < 4 * kMaxGrid ? tiles : 4 * kMaxGrid);
@@ -361,7 +361,7 @@ extern "C" int nfmc_realnvp_inverse_f32(const NfmcRealNVP* flow, const float* z,
     if (use_mfma_flow(flow) && al16(x) && al16(z)) return nfmc_realnvp_inverse_mfma_f32(flow, z, n, x, logdet, log_q, &r, stream);
     if (use_mfma_wide(flow) && al16(x) && al16(z)) {
         rc = nfmc_realnvp_inverse_wide_f32(flow, z, n, x, logdet, log_q, &r, stream);
-        if (rc != NFMC_EUNSUPPORTED) return rc;
+        if (!(rc == NFMC_ESCRATCH && !flow->scratch)) return rc;
     }
     const int64_t tiles = (n + 63) / 64;
     const int grid = (int)(tiles < 4 * kMaxGrid ? tiles : 4 * kMaxGrid);
@@ -402,8 +402,13 @@ extern "C" int nfmc_flow_mh_supported_f32(const NfmcFlowMhArgs* args) {
     if (use_mfma_flow(&a.flow) && al16(a.x) && al16(a.samples.base)) return NFMC_OK;
     // wide conditioners at the streamed matrix-core shapes (mfma_wide.hip): the caller composes the step from the flow's
     // own passes, which run there (d = 256, H = 128 x 2, 65536 chains: 0.53 ms per pass against 5.3 for the
-    // one-chain-per-lane kernel this entry point would use; nfmc_flow_mh_steps_f32 itself still takes the call)
-    if (use_mfma_wide(&a.flow)) return NFMC_EUNSUPPORTED;
+    // one-chain-per-lane kernel this entry point would use; nfmc_flow_mh_steps_f32 itself still takes the call).  Round 4: the
+    // streamed matrix-core kernel takes them when the caller supplies its workspace and the rows are 16-byte aligned
+    if (use_mfma_wide(&a.flow))
+        return (a.flow.scratch && a.flow.scratch_bytes >= nfmc_flow_scratch_bytes(&a.flow, a.n, 1) && al16(a.x) && al16(a.samples.base) &&
+                rng_rounds(a.rng) == 10)
+                   ? NFMC_OK
+                   : NFMC_EUNSUPPORTED;
     return flow_mh_tile_lds(a.flow) <= kMaxLdsBytes ? NFMC_OK : NFMC_EUNSUPPORTED;
 }
 
@@ -421,6 +426,10 @@ extern "C" int nfmc_flow_mh_steps_f32(const NfmcFlowMhArgs* args, nfmc_stream_t 
     if (rc == NFMC_EUNSUPPORTED && use_mfma_flow(&a.flow) && al16(a.x) && al16(a.samples.base)) {
         // wide conditioners at d = 64 / 128 (16-byte aligned rows): matrix cores
         rc = nfmc_flow_mh_steps_mfma_f32(a, stream, &grid, &dp);
+        if (rc) return rc;
+    } else if (rc == NFMC_EUNSUPPORTED && use_mfma_wide(&a.flow) && a.flow.scratch && al16(a.x) && al16(a.samples.base)) {
+        // wide conditioners at the other multiples of 32 up to d = 512: matrix cores, state streamed through the caller's slab
+        rc = nfmc_flow_mh_steps_wide_f32(a, stream, &grid, &dp);
         if (rc) return rc;
     } else if (rc == NFMC_EUNSUPPORTED) {  // wider conditioners: one chain per lane, wave tiles in LDS
         dp = padded_d(d);

@@ -314,6 +314,7 @@ int nfmc_realnvp_forward_wide_f32(const NfmcRealNVP* flow, const float* x, int64
                                   nfmc_stream_t stream);
 int nfmc_realnvp_inverse_wide_f32(const NfmcRealNVP* flow, const float* z, int64_t n, float* x, float* logdet, float* log_q,
                                   const NfmcRng* rng, nfmc_stream_t stream);
+int nfmc_flow_mh_steps_wide_f32(const NfmcFlowMhArgs& a, nfmc_stream_t stream, int* grid_out, int* dp_out);
 // entry points of flow_mfma.hip used by the C ABI in flow_kernels.hip (shapes: nfmc_mfma_supported)
 int nfmc_realnvp_forward_mfma_f32(const NfmcRealNVP* f, const float* x, int64_t n, float* z, float* logdet,
                                   float* log_prob, nfmc_stream_t stream);

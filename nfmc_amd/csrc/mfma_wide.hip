@@ -795,6 +795,211 @@ __global__ void __launch_bounds__(kMfmaBlock, 2) neutra_leapfrog_wide_kernel(Wid
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Round 4: the flow-proposal Metropolis step (the jump of jump.py:205-243, the loop body of imh.py:214-249) at these shapes
+// in ONE launch (flow_mh_mfma_kernel's contract on the streamed state).  Until now a wide conditioner at d = 256 / 512
+// composed the transition from three launches (inverse pass, forward pass, accept / select).  The slab of a workgroup slot
+// holds two private rows per lane group: the working row of the flow passes and the chain's current state.
+__device__ __forceinline__ float wide_potential_value(const WideCtx& c, const float* row, const NfmcPotential& p, int lane) {
+    const int TD = c.d / 16;
+    auto xtile = [&](int m) { return tile_ld(row, m); };
+    if (p.kind == NFMC_POT_FUNNEL) {
+        const f32x4 t0 = tile_ld(row, 0);
+        const float x0 = __shfl(t0[0], lane & 15, kWave);   // coordinate 0 = tile 0, register 0, lane group 0
+        float s = 0.f;
+        wide_tiles(TD, xtile, [&](int m, const f32x4& x) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) s = fmaf(x[t], (m == 0 && t == 0 && c.q == 0) ? 0.f : x[t], s);
+        });
+        s = chain_sum(s);
+        const float inv_s2 = 1.f / (p.a_scalar * p.a_scalar);
+        return 0.5f * x0 * x0 * inv_s2 + 0.5f * fast_exp(-x0) * s + 0.5f * (float)(c.d - 1) * x0;
+    }
+    float u = 0.f;
+    wide_tiles(TD, xtile, [&](int m, const f32x4& x) {
+        f32x4 a, b;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            a[t] = p.a_scalar;
+            b[t] = p.b_scalar;
+        }
+        if (p.a) a = vec_tile(p.a, m, c.q);
+        if (p.b) b = vec_tile(p.b, m, c.q);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float dlt = x[t] - b[t];
+            u = fmaf(a[t] * dlt, dlt, u);
+        }
+    });
+    return chain_sum(u);
+}
+
+template <int TH, int NHL>
+__global__ void __launch_bounds__(kMfmaBlock, 2) flow_mh_wide_kernel(NfmcFlowMhArgs a, float* __restrict__ slab, int64_t tiles, int dp) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int hp = 16 * TH;
+    const NfmcRealNVP& f = a.flow;
+    const int d = f.d, TD = f.d / 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool rev = (f.n_coupling & 1) != 0;
+    const int64_t n = a.n;
+    const float base_c = -0.5f * (float)d * kLog2Pi;
+    WideCtx c;
+    wide_ctx_init(c, lds, f, lane);
+    const int64_t srow = (int64_t)blockIdx.x * kMfmaChains + wave * 16 + c.col;
+    c.xs = slab + srow * d + 4 * c.q;                                                   // working row of the flow passes
+    float* const cs = slab + ((int64_t)gridDim.x * kMfmaChains + srow) * d + 4 * c.q;  // the chain's current state
+    double* const red = reinterpret_cast<double*>(lds);   // statistics of one transition: [8 waves][2 d] doubles over the idle images
+    const bool defer = a.stats.defer != 0;   // deferred: add to the caller-zeroed slab (nfmc_stats_fold_f32)
+    const int slot = defer ? a.stats.tail_slot : 0;
+    double* const out = a.stats.sum_x ? a.stats.scratch + (size_t)blockIdx.x * (2 * dp + kStatTail) : nullptr;
+    uint32_t n_acc = 0, n_bad = 0;
+    bool first = !defer;
+    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int64_t row = tile * kMfmaChains + wave * 16 + c.col;
+        const bool active = row < n;
+        const int64_t rrow = active ? row : n - 1;
+        const float* xr = a.x + rrow * d;
+        wide_tiles(TD, [&](int m) { return vec_tile(xr, m, c.q); },
+                   [&](int m, const f32x4& v) {
+                       tile_st(cs, m, v);
+                       tile_st(c.xs, m, v);
+                   });
+        float u_x = wide_potential_value(c, cs, a.pot, lane);                       // jump.py:212 / imh.py:224
+        float f_x;
+        if (a.logq_cached) {
+            f_x = a.logq[rrow];
+        } else {                                                                    // flow.log_prob(x): jump.py:218 / imh.py:214
+            float ldp = wide_ea<kEaForward>(c, f.ea0_log_scale, f.ea0_shift, false);
+            for (int l = 0; l < f.n_coupling; ++l)
+                ldp += wide_coupling<TH, NHL, false, 4>(c, mfma_layer(f.weights + l * f.layer_stride, d, hp, NHL), (l & 1) == 0);
+            ldp += wide_ea<kEaForward>(c, f.ea1_log_scale, f.ea1_shift, rev);
+            f_x = -0.5f * wide_sum_squares(c) + base_c + chain_sum(ldp);
+        }
+        StoreCursor keep(a.samples);
+        const uint32_t gchain = (uint32_t)(a.rng.chain_offset + (uint64_t)rrow);
+        for (int s = 0; s < a.n_steps; ++s) {
+            // ---- flow.sample: the latent (Philox stream kTagLatent, one block per 4 logical coordinates; or replayed), x' = f^-1(z)
+            float ss = 0.f;
+            for (int m = 0; m < TD; ++m) {
+                const int p0 = 16 * m + 4 * c.q;
+                f32x4 v;
+                if (a.rng.replay_normals) {
+                    const float* src = a.rng.replay_normals + ((int64_t)s * n + rrow) * d;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = src[rev ? d - 1 - (p0 + j) : p0 + j];
+                } else {
+                    const int blk = rev ? (d - 4 - p0) >> 2 : p0 >> 2;
+                    float w4[4];
+                    philox_normal4(gchain, a.rng.step0 + (uint32_t)s, (uint32_t)blk, kTagLatent, (uint32_t)a.rng.seed,
+                                   (uint32_t)(a.rng.seed >> 32), w4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = rev ? w4[3 - j] : w4[j];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ss = fmaf(v[j], v[j], ss);
+                tile_st(c.xs, m, v);
+            }
+            ss = chain_sum(ss);
+            float ldp = wide_ea<kEaInverse>(c, f.ea1_log_scale, f.ea1_shift, rev);
+            for (int l = f.n_coupling - 1; l >= 0; --l)
+                ldp += wide_coupling<TH, NHL, true, 4>(c, mfma_layer(f.weights + l * f.layer_stride, d, hp, NHL), (l & 1) == 0);
+            ldp += wide_ea<kEaInverse>(c, f.ea0_log_scale, f.ea0_shift, false);
+            const float f_xp = -0.5f * ss + base_c - chain_sum(ldp);
+            const float u_xp = wide_potential_value(c, c.xs, a.pot, lane);            // jump.py:213 / imh.py:225
+            const float lr = (-u_xp) - (-u_x) + f_x - f_xp;                           // util.py:392
+            bool accept = true;
+            if (a.adjusted) {
+                float u;
+                if (a.rng.replay_uniforms) {
+                    u = a.rng.replay_uniforms[(int64_t)s * n + rrow];
+                } else {
+                    const uint4 r = philox4x32_10(gchain, a.rng.step0 + (uint32_t)s, 0u, kTagJump, (uint32_t)a.rng.seed, (uint32_t)(a.rng.seed >> 32));
+                    u = u32_to_uniform(r.x);
+                }
+                accept = fast_ln(u) < lr;                                             // jump.py:225 / imh.py:229-230
+                if (active && c.q == 0 && !(fabsf(lr) <= 3.0e38f)) n_bad++;
+            }
+            accept = accept && active;
+            if (accept) {                                                             // jump.py:231 / imh.py:232-233
+                f_x = f_xp;
+                u_x = u_xp;
+                if (c.q == 0) n_acc++;
+            }
+            float* kept = keep.next(n * (int64_t)d);
+            if (active && c.q == 0) {
+                if (a.masks_out) a.masks_out[(int64_t)s * n + row] = accept ? 1 : 0;
+                if (a.log_ratio_out) a.log_ratio_out[(int64_t)s * n + row] = lr;
+            }
+            __syncthreads();   // the weight images are idle: their memory takes this transition's statistics
+            for (int m = 0; m < TD; ++m) {
+                f32x4 xc;
+                if (accept) {
+                    xc = tile_ld(c.xs, m);
+                    tile_st(cs, m, xc);
+                } else {
+                    xc = tile_ld(cs, m);
+                }
+                if (active && kept) *reinterpret_cast<f32x4*>(kept + row * d + 16 * m + 4 * c.q) = xc;
+                if (a.stats.sum_x) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const float xv = active ? xc[t] : 0.f;
+                        double v1 = (double)xv, v2 = (double)xv * (double)xv;
+                        for (int k = 1; k < 16; k <<= 1) {
+                            v1 += __shfl_xor(v1, k, kWave);
+                            v2 += __shfl_xor(v2, k, kWave);
+                        }
+                        if (c.col == 0) {
+                            const int cc = 16 * m + 4 * c.q + t;   // x-space: position = coordinate
+                            red[wave * 2 * d + cc] = v1;
+                            red[wave * 2 * d + d + cc] = v2;
+                        }
+                    }
+                }
+            }
+            if (a.stats.sum_x) {
+                __syncthreads();
+                for (int i = threadIdx.x; i < 2 * dp; i += kMfmaBlock) {
+                    const int hf = i / dp, cc = i - hf * dp;
+                    double v = 0.0;
+                    if (cc < d)
+                        for (int w8 = 0; w8 < kMfmaWaves; ++w8) v += red[w8 * 2 * d + hf * d + cc];
+                    out[i] = first ? v : out[i] + v;
+                }
+            }
+            __syncthreads();   // the images are free again for the next staging
+            first = false;
+        }
+        if (active) {
+            float* xo = a.x + row * d;
+            wide_tiles(TD, [&](int m) { return tile_ld(cs, m); },
+                       [&](int m, const f32x4& v) { *reinterpret_cast<f32x4*>(xo + 16 * m + 4 * c.q) = v; });
+            if (c.q == 0) a.logq[row] = f_x;
+        }
+    }
+    if (a.stats.sum_x) {
+        for (int m = 1; m < 16; m <<= 1) {   // counted on lane group 0 only
+            n_acc += __shfl_xor(n_acc, m, kWave);
+            n_bad += __shfl_xor(n_bad, m, kWave);
+        }
+        __syncthreads();
+        if (lane == 0) {
+            red[2 * wave] = (double)n_acc;
+            red[2 * wave + 1] = (double)n_bad;
+        }
+        __syncthreads();
+        if (threadIdx.x < kStatTail) {
+            double v = 0.0;
+            const int k = (int)threadIdx.x - slot;
+            if (k == 0 || k == 1)
+                for (int w8 = 0; w8 < kMfmaWaves; ++w8) v += red[2 * w8 + k];
+            out[2 * dp + threadIdx.x] = defer ? out[2 * dp + threadIdx.x] + v : v;
+        }
+    }
+}
+
 }  // namespace nfmc
 
 using namespace nfmc;
@@ -952,4 +1157,24 @@ int nfmc::nfmc_neutra_hmc_steps_wide_f32(const NfmcNeutraHmcArgs* args, float* s
     const hipError_t le = hipGetLastError();
     if (rc) return rc;
     return le == hipSuccess ? NFMC_OK : (int)le;
+}
+
+int nfmc::nfmc_flow_mh_steps_wide_f32(const NfmcFlowMhArgs& a, nfmc_stream_t stream, int* grid_out, int* dp_out) {
+    const NfmcRealNVP* flow = &a.flow;
+    const int d = a.flow.d;
+    if (!nfmc_mfma_wide_supported(d, a.flow.n_hidden, a.flow.n_hidden_layers)) return NFMC_EUNSUPPORTED;
+    if ((((uintptr_t)a.x) | ((uintptr_t)a.samples.base)) & 15u) return NFMC_EUNSUPPORTED;   // 16-byte tiles
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t tiles = (a.n + kMfmaChains - 1) / kMfmaChains;
+    const int grid = wide_grid(a.n), dp = padded_d(d);
+    if (a.stats.sum_x && a.stats.scratch_bytes < (int64_t)grid * (2 * dp + kStatTail) * (int64_t)sizeof(double)) return NFMC_ESCRATCH;
+    if (check_defer(a.stats, dp, d)) return NFMC_EINVAL;
+    float* slab = nullptr;
+    int rc = wide_slab(&slab, flow, a.n, 2);   // working row + current state: what nfmc_flow_scratch_bytes(.., with_gradient = 1) sizes
+    if (rc) return rc;
+    NFMC_WIDE_DISPATCH(flow_mh_wide_kernel, a, slab, tiles, dp)
+    if (rc) return rc;
+    *grid_out = grid;
+    *dp_out = dp;
+    return NFMC_OK;
 }

@@ -1401,8 +1401,10 @@ def test_two_chains_per_lane_group_equals_one_chain_kernel(dev, d, n, strategy, 
                                               (256, 128, 2, 'jump_mala'), (160, 64, 1, 'imh')])
 def test_wide_flow_metropolis_on_matrix_cores_equals_valu_kernels(dev, d, nh, cl, strategy, monkeypatch):
     """Wide conditioners at d = 64 / 128: forward / inverse / flow-MH run on the matrix cores (flow_mfma.hip); at the other
-    multiples of 32 the step is composed from the streamed matrix-core passes (mfma_wide.hip).  The one-chain-per-lane
-    kernels (NFMC_FLOW_NO_MFMA=1) simulate the same chains from the same Philox streams."""
+    multiples of 32 -- round 4 -- on the streamed matrix-core flow-MH kernel (mfma_wide.hip: flow_mh_wide_kernel, one launch
+    per step; until then the step was composed from three launches).  The one-chain-per-lane kernels (NFMC_FLOW_NO_MFMA=1)
+    simulate the same chains from the same Philox streams.  The matrix-core leg must go through nfmc_flow_mh_steps_f32."""
+    from nfmc_amd.samplers import imh as imh_mod, jump as jump_mod
     from nfmc_amd.sample import create_sampler
     from nfmc_amd.flows import Flow, RealNVP
     from nfmc_amd.potentials import SumOfSquares
@@ -1411,6 +1413,14 @@ def test_wide_flow_metropolis_on_matrix_cores_equals_valu_kernels(dev, d, nh, cl
     torch.manual_seed(d + nh)
     of = oflow.perturb_(oflow.Flow(oflow.RealNVP((d,), n_layers=2, conditioner_kwargs=ck)), 4, 0.05, 0.75)
     outs = []
+    fused_calls = []
+    orig = jump_mod.launch_flow_mh
+
+    def spy(*args, **kwargs):
+        fused_calls.append(1)
+        return orig(*args, **kwargs)
+    monkeypatch.setattr(jump_mod, 'launch_flow_mh', spy)
+    monkeypatch.setattr(imh_mod, 'launch_flow_mh', spy)
     for no_mfma in (False, True):
         if no_mfma:
             monkeypatch.setenv('NFMC_FLOW_NO_MFMA', '1')
@@ -1421,6 +1431,8 @@ def test_wide_flow_metropolis_on_matrix_cores_equals_valu_kernels(dev, d, nh, cl
         s.seed = 17
         torch.manual_seed(9)
         outs.append(s.sample(torch.randn(300, d) * 0.7, show_progress=False))
+        if not no_mfma:
+            assert fused_calls, 'the matrix-core leg did not go through the fused flow-MH entry point'
     a, b = outs
     assert a.samples.shape == b.samples.shape
     close = ((a.samples - b.samples).abs().amax(dim=(0, 2)) < 2e-3).float().mean()

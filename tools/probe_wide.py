@@ -68,6 +68,15 @@ def main():
         z0 = 0.5 * x[:nt]
         t = timed(lambda: smp.sample(z0, show_progress=False), 3)
         print('d=%d  neutra_hmc, L = 10, %d chains: %8.3f ms per trajectory (20 in one call)' % (d, nt, t / 20))
+        # the flow-proposal Metropolis step (imh: one inverse pass + U + accept per transition) on the streamed kernel (round 4)
+        from nfmc_amd.potentials import SumOfSquares
+        imh = create_sampler(SumOfSquares((d,)), strategy='imh', flow='realnvp',
+                             flow_kwargs={'conditioner_kwargs': {'n_hidden': 128, 'n_layers': 2}},
+                             param_kwargs={'n_iterations': 20, 'store_samples': False})
+        imh.kernel.flow.load_state_dict(f.state_dict())
+        imh.seed = 0
+        t = timed(lambda: imh.sample(z0, show_progress=False), 3)
+        print('d=%d  imh, %d chains: %8.3f ms per transition (20 in one call; forward pass of the first state included)' % (d, nt, t / 20))
         nb = min(n, 8192)
         f.to(dev)
 
