@@ -2011,12 +2011,21 @@ def test_edge_every_entry_point_rejects_null_and_zeroed_arguments(dev):
         'normals': lambda: L.nfmc_philox_normals_f32(z(hip.NfmcRng), hip.TAG_NOISE, 4, 8, None, st),
         'uniforms': lambda: L.nfmc_philox_uniforms_f32(z(hip.NfmcRng), hip.TAG_ACCEPT, 4, None, st),
         'limits': lambda: L.nfmc_limits(None),
+        'fit_step': lambda: L.nfmc_flow_fit_step_f32(z(hip.NfmcFlowFit), None, 4, z(hip.NfmcAdamW), st),
+        'fit_variational': lambda: L.nfmc_flow_variational_fit_step_f32(z(hip.NfmcFlowFit), z(hip.NfmcPotential), None, 4, z(hip.NfmcAdamW), st),
+        'fit_epochs': lambda: L.nfmc_flow_fit_epochs_f32(z(hip.NfmcFlowFit), None, None, 4, 0, z(hip.NfmcAdamW), z(hip.NfmcFitControl), 0, 1, st),
+        'fit_epochs_no_control': lambda: L.nfmc_flow_fit_epochs_f32(z(hip.NfmcFlowFit), None, None, 4, 0, z(hip.NfmcAdamW), None, 0, 1, st),
+        'rows_sample': lambda: L.nfmc_rows_sample_f32(None, 4, 8, 1, 0, None, 2, None, st),
+        'blob_copy': lambda: L.nfmc_flow_blob_copy_f32(None, None, 1, 1, st),
     }
     for name, call in calls.items():
         rc = int(call())
         assert rc < 0, (name, rc)
         with pytest.raises(ValueError):
             hip.check(rc, name)
+    # size queries answer 0 for what they have no kernel / no workspace for
+    assert int(L.nfmc_flow_scratch_bytes(None, 4, 1)) == 0 and int(L.nfmc_flow_scratch_bytes(z(hip.NfmcRealNVP), 4, 1)) == 0
+    assert int(L.nfmc_flow_fit_workspace(None, 4, 0, 16, None)) == 0 and int(L.nfmc_flow_fit_supported_f32(None)) == 0
     for name in ('mala', 'hmc', 'flow_mh', 'neutra_hmc', 'select', 'imh_parallel'):   # NULL struct pointers
         fn = {'mala': L.nfmc_mala_steps_f32, 'hmc': L.nfmc_hmc_steps_f32, 'flow_mh': L.nfmc_flow_mh_steps_f32,
               'neutra_hmc': L.nfmc_neutra_hmc_steps_f32, 'select': L.nfmc_mh_accept_select_f32}.get(name)
