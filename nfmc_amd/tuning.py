@@ -82,7 +82,7 @@ def train_val_split(x: torch.Tensor, train_pct: float, max_train_size: int, max_
         total = rows.shape[0]
         cut = int(train_pct * total)
         n_train, n_val = min(cut, int(max_train_size)), min(total - cut, int(max_val_size))
-        if rows.is_cuda and rows.dtype == torch.float32 and rows.is_contiguous() and total > 0:
+        if rows.is_cuda and rows.dtype == torch.float32 and rows.is_contiguous() and total > 0 and n_train + n_val > 0:
             # ONE launch (csrc/fit_support.hip: nfmc_rows_sample_f32): rows pi(0 .. n_train + n_val - 1) of a keyed
             # pseudo-random permutation pi of the pooled rows -- positions [0, n_train) and [cut, cut + n_val) of a uniform
             # shuffle are, in distribution, any n_train + n_val distinct positions of it.  The key comes from torch's CPU
