@@ -400,8 +400,8 @@ int nfmc_philox_uniforms_f32(const NfmcRng* rng, int32_t tag, int64_t n, float* 
  * layers (n_coupling * layer_stride floats, VALU layout above), then at `ea_off` the four ElementwiseAffine vectors
  * (ea0 log-scale, ea0 shift, ea1 log-scale, ea1 shift; d4 = d rounded up to 4 floats each) -- and `flow`'s pointers must be
  * views of it (weights = params, ea0_log_scale = params + ea_off, ...), so the sampling kernels see every step at once.
- * Shapes: affine / additive couplings (n_bins = 0), one or two hidden layers; n_hidden <= 32 at d <= 256, n_hidden 33..128
- * at d = 64 / 128 (nfmc_flow_fit_supported_f32); other flows are trained by the host package's torch path.
+ * Shapes: affine / additive couplings (n_bins = 0), one or two hidden layers; n_hidden <= 8 at d <= 512, n_hidden 9..32 at
+ * d <= 256, n_hidden 33..128 at d = 64 / 128 (nfmc_flow_fit_supported_f32); other flows are trained by the host package's torch path.
  * Conditioners of width <= 8 (every default flow) run on the row-per-wave kernel (csrc/fit_rows.hpp: up to 1024 waves per
  * launch); it needs `params` 16-byte aligned and layer_stride, ea_off multiples of 4 floats (NFMC_EALIGN otherwise). */
 typedef struct {

@@ -613,8 +613,8 @@ static bool fit_rows_shape(const NfmcRealNVP* f, int64_t n_params, int* hp_out, 
     const int hp = nfmc_realnvp_padded_hidden(f->n_hidden);
     if (hp != 4 && hp != 8) return false;
     const int d_b = f->d - f->d / 2;
-    const int ch = d_b <= 64 ? 1 : 2;
-    if (d_b > 128) return false;
+    const int ch = d_b <= 64 ? 1 : (d_b <= 128 ? 2 : 4);
+    if (d_b > 256) return false;
     if (fit_rows_lds_bytes(n_params, hp, ch) > 160 * 1024) return false;
     *hp_out = hp;
     *ch_out = ch;
@@ -632,7 +632,7 @@ static bool fit_wide(const NfmcRealNVP* f);
 static int64_t mfma_layer_floats_of(const NfmcRealNVP& f) { return nfmc_realnvp_layer_floats(f.d, f.n_hidden, f.n_hidden_layers); }
 static bool fit_supported(const NfmcRealNVP* f) {
     if (fit_wide(f)) return true;
-    if (!f || f->n_bins != 0 || f->d <= 0 || f->d > 256 || f->n_coupling < 0) return false;
+    if (!f || f->n_bins != 0 || f->d <= 0 || f->d > 512 || f->n_coupling < 0) return false;
     if (f->n_hidden <= 0 || f->n_hidden > 32 || f->n_hidden_layers < 1 || f->n_hidden_layers > 2) return false;
     const int hp = nfmc_realnvp_padded_hidden(f->n_hidden);
     if (hp <= 0) return false;
@@ -640,7 +640,7 @@ static bool fit_supported(const NfmcRealNVP* f) {
         int h, c;
         return fit_rows_shape(f, fit_min_params(f), &h, &c);
     }
-    return fit_lds_bytes(f->d, hp) <= 160 * 1024;
+    return f->d <= 256 && fit_lds_bytes(f->d, hp) <= 160 * 1024;   // widths 9..32: the row-per-lane kernel, d <= 256
 }
 
 // conditioners of width 33..128 at d = 64 / 128: the matrix-core kernel (fit_mfma.hip), blob in the matrix-core layout
@@ -722,8 +722,8 @@ static int fit_call(const NfmcFlowFit* fit, const NfmcPotential* pot, const floa
     } else if (fit_rows_shape(&f, fit->n_params, &rhp, &rch)) {
         if ((f.layer_stride & 3) != 0 || (fit->ea_off & 3) != 0 || (reinterpret_cast<uintptr_t>(fit->params) & 15) != 0)
             return NFMC_EALIGN;
-        // rows per wave tile: 4 when that still gives every SIMD of the machine a tile, else 1
-        const int S = (n_train + nv) >= 4096 ? 4 : 1;
+        // rows per wave tile: 4 (2 at CH = 4: register budget) when that still gives every SIMD of the machine a tile, else 1
+        const int S = (n_train + nv) >= 4096 ? (rch == 4 ? 2 : 4) : 1;
         const int64_t tiles = (n_train + S - 1) / S, tiles4 = (tiles + kFrWaves - 1) / kFrWaves * kFrWaves;
         const int64_t vtiles = (nv + S - 1) / S;
         const int64_t wgs = (tiles4 + vtiles + kFrWaves - 1) / kFrWaves;

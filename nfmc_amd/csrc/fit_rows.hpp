@@ -6,7 +6,7 @@
 // weight loads (280 us per epoch at the C5 refit shape, < 1 % of any roof).  An epoch is ~0.2 GFLOP and 4 MB: the only
 // thing that matters is the length of the longest dependent chain, so the row is the unit of PARALLELISM here:
 //   * lanes = coordinates.  A wave owns S rows at a time (slots: S independent chains the scheduler interleaves); lane g
-//     holds, per row, elements g, g + 64, ... of the two physical halves of the row (CH registers per half, d <= 128 CH).
+//     holds, per row, elements g, g + 64, ... of the two physical halves of the row (CH = 1 / 2 / 4 registers per half: d <= 128 CH).
 //     A coupling layer's conditioner input is one half, its targets the other; the reversal between layers only swaps the
 //     roles and reverses the ORDER in which the weight rows are read -- the state never moves across lanes.
 //   * the first conditioner GEMV is a per-lane partial (CH x HP multiply-adds) + a reduce-scatter over the wave that leaves
@@ -55,10 +55,13 @@ struct FitRowsArgs {
 
 template <int HP, int CH>
 __host__ __device__ constexpr int fit_rows_nacc() { return 3 * CH * HP + 2 * CH + HP + 2; }
+// accumulator registers a wave stages per flush round: all of them up to CH = 2, half of them at CH = 4 (d <= 512)
+__host__ __device__ constexpr int fit_rows_nstage(int hp, int ch) {
+    return ch <= 2 ? 3 * ch * hp + 2 * ch + hp + 2 : (3 * ch * hp + 2 * ch + hp + 2 + 1) / 2;
+}
 
 __host__ __device__ inline size_t fit_rows_lds_bytes(int64_t n_params, int hp, int ch) {
-    const int nacc = 3 * ch * hp + 2 * ch + hp + 2;
-    return ((size_t)((n_params + 3) / 4 * 4) + (size_t)kFrWaves * nacc * 64 + (size_t)kFrWaves * kFitTailFloats) * sizeof(float);
+    return ((size_t)((n_params + 3) / 4 * 4) + (size_t)kFrWaves * fit_rows_nstage(hp, ch) * 64 + (size_t)kFrWaves * kFitTailFloats) * sizeof(float);
 }
 
 // ---- quad-major reduce-scatter / all-gather over the 64 lanes of a wave.  Lane g owns hidden unit u = g % HP.
@@ -348,7 +351,8 @@ template <int HP, bool RKL, int CH, int S>
 __global__ void __launch_bounds__(kFrThreads) fit_rows_kernel(FitRowsArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     if (a.run_state && (a.run_state[3] != 0.f || a.run_state[4] != 0.f)) return;   // the run has ended: nothing to do
-    constexpr int NACC = fit_rows_nacc<HP, CH>();
+    constexpr int NACC = fit_rows_nacc<HP, CH>(), NSTAGE = fit_rows_nstage(HP, CH);
+    static_assert(NSTAGE >= 4 * CH, "the elementwise-affine flush stages 4 CH registers");
     const NfmcRealNVP& f = a.f;
     const int d = f.d, d_a = d / 2, d_b = d - d_a, n_hl = f.n_hidden_layers, n_coupling = f.n_coupling;
     const bool odd = d_b != d_a;
@@ -356,8 +360,8 @@ __global__ void __launch_bounds__(kFrThreads) fit_rows_kernel(FitRowsArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int np4 = (int)((a.n_params + 3) / 4 * 4);
     float* const pl = lds;                                   // the trainable vector
-    float* const stage = lds + np4;                          // [wave][NACC][64]
-    float* const tails = stage + kFrWaves * NACC * 64;       // [wave][4]
+    float* const stage = lds + np4;                          // [wave][NSTAGE][64]
+    float* const tails = stage + kFrWaves * NSTAGE * 64;     // [wave][4]
     const FitOffsets o = fit_rows_offsets(d_a, d_b, n_hl, HP);
     const bool rev_last = (n_coupling & 1) != 0;
     // ---- the trainable vector into LDS: every thread issues all its 16-byte loads before its first LDS store
@@ -410,7 +414,7 @@ __global__ void __launch_bounds__(kFrThreads) fit_rows_kernel(FitRowsArgs a) {
     float* const P = a.partial + (int64_t)blockIdx.x * a.pstride;
     bool first = true;
     float loss_acc = 0.f, rows_acc = 0.f, vloss_acc = 0.f, vrows_acc = 0.f;
-    float* const mystage = stage + wave * NACC * 64;
+    float* const mystage = stage + wave * NSTAGE * 64;
 
     for (int64_t pass = 0; pass < passes; ++pass) {
         const int64_t tile0 = pass * W + (int64_t)blockIdx.x * kFrWaves;   // the workgroup's first tile of this pass
@@ -625,8 +629,8 @@ __global__ void __launch_bounds__(kFrThreads) fit_rows_kernel(FitRowsArgs a) {
 #pragma unroll
             for (int k = 0; k < 4 * CH; ++k) {
                 if ((k & 3) != wave) continue;
-                const float v = stage[(0 * NACC + k) * 64 + lane] + stage[(1 * NACC + k) * 64 + lane] +
-                                stage[(2 * NACC + k) * 64 + lane] + stage[(3 * NACC + k) * 64 + lane];
+                const float v = stage[(0 * NSTAGE + k) * 64 + lane] + stage[(1 * NSTAGE + k) * 64 + lane] +
+                                stage[(2 * NSTAGE + k) * 64 + lane] + stage[(3 * NSTAGE + k) * 64 + lane];
                 const int kk = k % (2 * CH), i = kk % CH;
                 const bool blockB = kk >= CH;
                 const bool ok = blockB ? okB[i] : okA[i];
@@ -730,78 +734,71 @@ __global__ void __launch_bounds__(kFrThreads) fit_rows_kernel(FitRowsArgs a) {
                         }
                 }
             }
-            // ---- the four waves' accumulators -> LDS -> added in wave order into the workgroup's slab
-            __syncthreads();
+            // ---- the four waves' accumulators -> LDS -> added in wave order into the workgroup's slab.  NSTAGE registers per
+            // wave and round (all of them in one round up to d = 256; two rounds at CH = 4, where staging all 114 next to the
+            // staged vector would exceed the LDS); register r of a round is folded and written by wave r mod 4.
+            float acc[NACC];
             {
                 int r = 0;
 #pragma unroll
                 for (int i = 0; i < CH; ++i)
 #pragma unroll
-                    for (int q = 0; q < HP; ++q) mystage[(r++) * 64 + lane] = A.w1[i][q];
+                    for (int q = 0; q < HP; ++q) acc[r++] = A.w1[i][q];
 #pragma unroll
                 for (int i = 0; i < CH; ++i)
 #pragma unroll
-                    for (int q = 0; q < HP; ++q) mystage[(r++) * 64 + lane] = A.wa[i][q];
+                    for (int q = 0; q < HP; ++q) acc[r++] = A.wa[i][q];
 #pragma unroll
                 for (int i = 0; i < CH; ++i)
 #pragma unroll
-                    for (int q = 0; q < HP; ++q) mystage[(r++) * 64 + lane] = A.wb[i][q];
+                    for (int q = 0; q < HP; ++q) acc[r++] = A.wb[i][q];
 #pragma unroll
-                for (int i = 0; i < CH; ++i) mystage[(r++) * 64 + lane] = A.ba[i];
+                for (int i = 0; i < CH; ++i) acc[r++] = A.ba[i];
 #pragma unroll
-                for (int i = 0; i < CH; ++i) mystage[(r++) * 64 + lane] = A.bb[i];
+                for (int i = 0; i < CH; ++i) acc[r++] = A.bb[i];
 #pragma unroll
-                for (int q = 0; q < HP; ++q) mystage[(r++) * 64 + lane] = A.wh[q];
-                mystage[(r++) * 64 + lane] = A.b1;
-                mystage[(r++) * 64 + lane] = A.bh;
+                for (int q = 0; q < HP; ++q) acc[r++] = A.wh[q];
+                acc[r++] = A.b1;
+                acc[r++] = A.bh;
             }
-            __syncthreads();
-            auto folded = [&](int r) {
-                return stage[(0 * NACC + r) * 64 + lane] + stage[(1 * NACC + r) * 64 + lane] +
-                       stage[(2 * NACC + r) * 64 + lane] + stage[(3 * NACC + r) * 64 + lane];
-            };
-            auto emit = [&](int64_t idx, float v) { P[idx] = first ? v : P[idx] + v; };
             const int u = lane % HP;
-            if (wave == 0) {   // W1T rows of the lane's source elements
 #pragma unroll
-                for (int i = 0; i < CH; ++i)
-                    if (L.jrow[i] >= 0) {
+            for (int r0 = 0; r0 < NACC; r0 += NSTAGE) {
+                __syncthreads();   // the stage is free (the previous round's readers are done)
 #pragma unroll
-                        for (int q = 0; q < HP; ++q)
-                            emit(L0 + o.w1t + L.jrow[i] + unit_of<HP>(q, lane), folded(i * HP + q));
+                for (int r = r0; r < r0 + NSTAGE && r < NACC; ++r) mystage[(r - r0) * 64 + lane] = acc[r];
+                __syncthreads();
+#pragma unroll
+                for (int r = r0; r < r0 + NSTAGE && r < NACC; ++r) {
+                    if (((r - r0) & 3) != wave) continue;   // wave-uniform
+                    const int sl = r - r0;
+                    const float v = stage[(0 * NSTAGE + sl) * 64 + lane] + stage[(1 * NSTAGE + sl) * 64 + lane] +
+                                    stage[(2 * NSTAGE + sl) * 64 + lane] + stage[(3 * NSTAGE + sl) * 64 + lane];
+                    int64_t idx = -1;
+                    if (r < CH * HP) {                              // W1T rows of the lane's source elements
+                        const int i = r / HP, q = r % HP;
+                        if (L.jrow[i] >= 0) idx = L0 + o.w1t + L.jrow[i] + unit_of<HP>(q, lane);
+                    } else if (r < 2 * CH * HP) {                   // W3 alpha rows of its target elements
+                        const int i = (r - CH * HP) / HP, q = r % HP;
+                        if (L.trow[i] >= 0) idx = L0 + o.w3 + L.trow[i] + unit_of<HP>(q, lane);
+                    } else if (r < 3 * CH * HP) {                   // W3 beta rows
+                        const int i = (r - 2 * CH * HP) / HP, q = r % HP;
+                        if (L.trow[i] >= 0) idx = L0 + o.w3 + (int64_t)d_b * HP + L.trow[i] + unit_of<HP>(q, lane);
+                    } else if (r < 3 * CH * HP + CH) {              // b3, alpha half
+                        const int i = r - 3 * CH * HP;
+                        if (L.trow[i] >= 0) idx = L0 + o.b3 + L.trow[i] / HP;
+                    } else if (r < 3 * CH * HP + 2 * CH) {          // b3, beta half
+                        const int i = r - 3 * CH * HP - CH;
+                        if (L.trow[i] >= 0) idx = L0 + o.b3 + d_b + L.trow[i] / HP;
+                    } else if (r < 3 * CH * HP + 2 * CH + HP) {     // WhT row of the lane's hidden unit
+                        const int q = r - 3 * CH * HP - 2 * CH;
+                        if (lane < HP && n_hl > 1) idx = L0 + o.wht + u * HP + unit_of<HP>(q, lane);
+                    } else if (r == 3 * CH * HP + 2 * CH + HP) {    // b1
+                        if (lane < HP) idx = L0 + o.b1 + u;
+                    } else {                                        // bh
+                        if (lane < HP && n_hl > 1) idx = L0 + o.bh + u;
                     }
-            } else if (wave == 1) {   // W3 alpha rows
-#pragma unroll
-                for (int i = 0; i < CH; ++i)
-                    if (L.trow[i] >= 0) {
-#pragma unroll
-                        for (int q = 0; q < HP; ++q)
-                            emit(L0 + o.w3 + L.trow[i] + unit_of<HP>(q, lane), folded(CH * HP + i * HP + q));
-                    }
-            } else if (wave == 2) {   // W3 beta rows
-#pragma unroll
-                for (int i = 0; i < CH; ++i)
-                    if (L.trow[i] >= 0) {
-#pragma unroll
-                        for (int q = 0; q < HP; ++q)
-                            emit(L0 + o.w3 + (int64_t)d_b * HP + L.trow[i] + unit_of<HP>(q, lane),
-                                 folded(2 * CH * HP + i * HP + q));
-                    }
-            } else {   // b3, WhT rows, b1, bh
-#pragma unroll
-                for (int i = 0; i < CH; ++i)
-                    if (L.trow[i] >= 0) {
-                        emit(L0 + o.b3 + L.trow[i] / HP, folded(3 * CH * HP + i));
-                        emit(L0 + o.b3 + d_b + L.trow[i] / HP, folded(3 * CH * HP + CH + i));
-                    }
-                if (lane < HP) {
-                    if (n_hl > 1) {
-#pragma unroll
-                        for (int q = 0; q < HP; ++q)
-                            emit(L0 + o.wht + u * HP + unit_of<HP>(q, lane), folded(3 * CH * HP + 2 * CH + q));
-                        emit(L0 + o.bh + u, folded(3 * CH * HP + 2 * CH + HP + 1));
-                    }
-                    emit(L0 + o.b1 + u, folded(3 * CH * HP + 2 * CH + HP));
+                    if (idx >= 0) P[idx] = first ? v : P[idx] + v;
                 }
             }
         }
@@ -870,9 +867,11 @@ __global__ void __launch_bounds__(kFrThreads) fit_rows_kernel(FitRowsArgs a) {
     int NAME(bool rkl, int ch, int s, const FitRowsArgs& a, int grid, size_t lds, hipStream_t st) {                        \
         if (rkl) {                                                                                                         \
             if (ch == 1) return s == 1 ? fit_rows_go<true, 1, 1>(a, grid, lds, st) : fit_rows_go<true, 1, 4>(a, grid, lds, st); \
-            return s == 1 ? fit_rows_go<true, 2, 1>(a, grid, lds, st) : fit_rows_go<true, 2, 4>(a, grid, lds, st);         \
+            if (ch == 2) return s == 1 ? fit_rows_go<true, 2, 1>(a, grid, lds, st) : fit_rows_go<true, 2, 4>(a, grid, lds, st); \
+            return s == 1 ? fit_rows_go<true, 4, 1>(a, grid, lds, st) : fit_rows_go<true, 4, 2>(a, grid, lds, st);         \
         }                                                                                                                  \
         if (ch == 1) return s == 1 ? fit_rows_go<false, 1, 1>(a, grid, lds, st) : fit_rows_go<false, 1, 4>(a, grid, lds, st); \
-        return s == 1 ? fit_rows_go<false, 2, 1>(a, grid, lds, st) : fit_rows_go<false, 2, 4>(a, grid, lds, st);           \
+        if (ch == 2) return s == 1 ? fit_rows_go<false, 2, 1>(a, grid, lds, st) : fit_rows_go<false, 2, 4>(a, grid, lds, st); \
+        return s == 1 ? fit_rows_go<false, 4, 1>(a, grid, lds, st) : fit_rows_go<false, 4, 2>(a, grid, lds, st);           \
     }                                                                                                                      \
     }

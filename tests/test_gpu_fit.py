@@ -35,7 +35,7 @@ def _flow(d, n_hidden, n_hl, n_layers, seed, nice=False):
 SHAPES = [  # d, n_hidden, hidden layers, coupling layers, rows, NICE
     (6, 4, 2, 2, 50, False), (7, 3, 1, 3, 64, False), (25, 4, 2, 2, 200, False), (64, 4, 2, 2, 333, False),
     (64, 8, 2, 2, 128, False), (64, 16, 1, 2, 70, False), (100, 7, 2, 3, 129, False), (128, 32, 2, 2, 65, False),
-    (256, 7, 2, 2, 700, False), (16, 5, 2, 2, 90, True),
+    (256, 7, 2, 2, 700, False), (16, 5, 2, 2, 90, True), (300, 7, 2, 2, 150, False), (512, 7, 2, 2, 130, False), (511, 6, 1, 3, 70, False),
 ]
 
 
@@ -145,6 +145,7 @@ def test_flow_fit_api_goes_through_the_device_path(dev, monkeypatch):
 RKL_CASES = [  # d, n_hidden, hidden layers, coupling layers, rows, potential
     (6, 4, 2, 2, 40, 'sum'), (7, 3, 1, 3, 64, 'diag'), (25, 4, 2, 2, 130, 'sum'), (64, 8, 2, 2, 100, 'diag'),
     (16, 5, 2, 3, 70, 'funnel'), (128, 4, 2, 2, 65, 'funnel'), (256, 7, 2, 2, 200, 'sum'), (1, 4, 2, 2, 10, 'sum'),
+    (400, 7, 2, 2, 90, 'diag'), (512, 8, 2, 2, 66, 'funnel'),
 ]
 
 
@@ -282,8 +283,17 @@ def test_gradient_with_four_rows_per_wave_matches_autograd(dev):
     """Batches of >= 4096 rows take the S = 4 instantiation of the row-per-wave kernel (four rows per wave tile, their
     outer products accumulated in registers before the workgroup fold) and, beyond 1024 wave tiles, a second pass that
     ADDS into the workgroup's slab: 4200 train + 300 validation rows, d = 64, against autograd of the CPU restatement."""
+    _four_rows_case(dev, 64, 6, 4200, 300)
+
+
+def test_gradient_at_d512_with_two_rows_per_wave_matches_autograd(dev):
+    """d = 512 (four registers per half and lane, the accumulators flushed in two rounds) with a batch large enough for the
+    two-rows-per-wave instantiation."""
+    _four_rows_case(dev, 512, 7, 4100, 60)
+
+
+def _four_rows_case(dev, d, H, n, nv):
     from nfmc_amd.flow_training import DeviceFit
-    d, H, n, nv = 64, 6, 4200, 300
     of, f = _flow(d, H, 2, 2, 41)
     g0 = torch.Generator().manual_seed(9)
     x = torch.randn(n, d, generator=g0) * 0.8
