@@ -734,72 +734,151 @@ __global__ void __launch_bounds__(kFrThreads) fit_rows_kernel(FitRowsArgs a) {
                         }
                 }
             }
-            // ---- the four waves' accumulators -> LDS -> added in wave order into the workgroup's slab.  NSTAGE registers per
-            // wave and round (all of them in one round up to d = 256; two rounds at CH = 4, where staging all 114 next to the
-            // staged vector would exceed the LDS); register r of a round is folded and written by wave r mod 4.
-            float acc[NACC];
-            {
-                int r = 0;
-#pragma unroll
-                for (int i = 0; i < CH; ++i)
-#pragma unroll
-                    for (int q = 0; q < HP; ++q) acc[r++] = A.w1[i][q];
-#pragma unroll
-                for (int i = 0; i < CH; ++i)
-#pragma unroll
-                    for (int q = 0; q < HP; ++q) acc[r++] = A.wa[i][q];
-#pragma unroll
-                for (int i = 0; i < CH; ++i)
-#pragma unroll
-                    for (int q = 0; q < HP; ++q) acc[r++] = A.wb[i][q];
-#pragma unroll
-                for (int i = 0; i < CH; ++i) acc[r++] = A.ba[i];
-#pragma unroll
-                for (int i = 0; i < CH; ++i) acc[r++] = A.bb[i];
-#pragma unroll
-                for (int q = 0; q < HP; ++q) acc[r++] = A.wh[q];
-                acc[r++] = A.b1;
-                acc[r++] = A.bh;
-            }
-            const int u = lane % HP;
-#pragma unroll
-            for (int r0 = 0; r0 < NACC; r0 += NSTAGE) {
-                __syncthreads();   // the stage is free (the previous round's readers are done)
-#pragma unroll
-                for (int r = r0; r < r0 + NSTAGE && r < NACC; ++r) mystage[(r - r0) * 64 + lane] = acc[r];
+            if constexpr (CH <= 2) {
+                // ---- the four waves' accumulators -> LDS -> added in wave order into the workgroup's slab
                 __syncthreads();
+                {
+                    int r = 0;
 #pragma unroll
-                for (int r = r0; r < r0 + NSTAGE && r < NACC; ++r) {
-                    if (((r - r0) & 3) != wave) continue;   // wave-uniform
-                    const int sl = r - r0;
-                    const float v = stage[(0 * NSTAGE + sl) * 64 + lane] + stage[(1 * NSTAGE + sl) * 64 + lane] +
-                                    stage[(2 * NSTAGE + sl) * 64 + lane] + stage[(3 * NSTAGE + sl) * 64 + lane];
-                    int64_t idx = -1;
-                    if (r < CH * HP) {                              // W1T rows of the lane's source elements
-                        const int i = r / HP, q = r % HP;
-                        if (L.jrow[i] >= 0) idx = L0 + o.w1t + L.jrow[i] + unit_of<HP>(q, lane);
-                    } else if (r < 2 * CH * HP) {                   // W3 alpha rows of its target elements
-                        const int i = (r - CH * HP) / HP, q = r % HP;
-                        if (L.trow[i] >= 0) idx = L0 + o.w3 + L.trow[i] + unit_of<HP>(q, lane);
-                    } else if (r < 3 * CH * HP) {                   // W3 beta rows
-                        const int i = (r - 2 * CH * HP) / HP, q = r % HP;
-                        if (L.trow[i] >= 0) idx = L0 + o.w3 + (int64_t)d_b * HP + L.trow[i] + unit_of<HP>(q, lane);
-                    } else if (r < 3 * CH * HP + CH) {              // b3, alpha half
-                        const int i = r - 3 * CH * HP;
-                        if (L.trow[i] >= 0) idx = L0 + o.b3 + L.trow[i] / HP;
-                    } else if (r < 3 * CH * HP + 2 * CH) {          // b3, beta half
-                        const int i = r - 3 * CH * HP - CH;
-                        if (L.trow[i] >= 0) idx = L0 + o.b3 + d_b + L.trow[i] / HP;
-                    } else if (r < 3 * CH * HP + 2 * CH + HP) {     // WhT row of the lane's hidden unit
-                        const int q = r - 3 * CH * HP - 2 * CH;
-                        if (lane < HP && n_hl > 1) idx = L0 + o.wht + u * HP + unit_of<HP>(q, lane);
-                    } else if (r == 3 * CH * HP + 2 * CH + HP) {    // b1
-                        if (lane < HP) idx = L0 + o.b1 + u;
-                    } else {                                        // bh
-                        if (lane < HP && n_hl > 1) idx = L0 + o.bh + u;
-                    }
-                    if (idx >= 0) P[idx] = first ? v : P[idx] + v;
+                    for (int i = 0; i < CH; ++i)
+#pragma unroll
+                        for (int q = 0; q < HP; ++q) mystage[(r++) * 64 + lane] = A.w1[i][q];
+#pragma unroll
+                    for (int i = 0; i < CH; ++i)
+#pragma unroll
+                        for (int q = 0; q < HP; ++q) mystage[(r++) * 64 + lane] = A.wa[i][q];
+#pragma unroll
+                    for (int i = 0; i < CH; ++i)
+#pragma unroll
+                        for (int q = 0; q < HP; ++q) mystage[(r++) * 64 + lane] = A.wb[i][q];
+#pragma unroll
+                    for (int i = 0; i < CH; ++i) mystage[(r++) * 64 + lane] = A.ba[i];
+#pragma unroll
+                    for (int i = 0; i < CH; ++i) mystage[(r++) * 64 + lane] = A.bb[i];
+#pragma unroll
+                    for (int q = 0; q < HP; ++q) mystage[(r++) * 64 + lane] = A.wh[q];
+                    mystage[(r++) * 64 + lane] = A.b1;
+                    mystage[(r++) * 64 + lane] = A.bh;
                 }
+                __syncthreads();
+                auto folded = [&](int r) {
+                    return stage[(0 * NSTAGE + r) * 64 + lane] + stage[(1 * NSTAGE + r) * 64 + lane] +
+                           stage[(2 * NSTAGE + r) * 64 + lane] + stage[(3 * NSTAGE + r) * 64 + lane];
+                };
+                auto emit = [&](int64_t idx, float v) { P[idx] = first ? v : P[idx] + v; };
+                const int u = lane % HP;
+                if (wave == 0) {   // W1T rows of the lane's source elements
+#pragma unroll
+                    for (int i = 0; i < CH; ++i)
+                        if (L.jrow[i] >= 0) {
+#pragma unroll
+                            for (int q = 0; q < HP; ++q)
+                                emit(L0 + o.w1t + L.jrow[i] + unit_of<HP>(q, lane), folded(i * HP + q));
+                        }
+                } else if (wave == 1) {   // W3 alpha rows
+#pragma unroll
+                    for (int i = 0; i < CH; ++i)
+                        if (L.trow[i] >= 0) {
+#pragma unroll
+                            for (int q = 0; q < HP; ++q)
+                                emit(L0 + o.w3 + L.trow[i] + unit_of<HP>(q, lane), folded(CH * HP + i * HP + q));
+                        }
+                } else if (wave == 2) {   // W3 beta rows
+#pragma unroll
+                    for (int i = 0; i < CH; ++i)
+                        if (L.trow[i] >= 0) {
+#pragma unroll
+                            for (int q = 0; q < HP; ++q)
+                                emit(L0 + o.w3 + (int64_t)d_b * HP + L.trow[i] + unit_of<HP>(q, lane),
+                                     folded(2 * CH * HP + i * HP + q));
+                        }
+                } else {   // b3, WhT rows, b1, bh
+#pragma unroll
+                    for (int i = 0; i < CH; ++i)
+                        if (L.trow[i] >= 0) {
+                            emit(L0 + o.b3 + L.trow[i] / HP, folded(3 * CH * HP + i));
+                            emit(L0 + o.b3 + d_b + L.trow[i] / HP, folded(3 * CH * HP + CH + i));
+                        }
+                    if (lane < HP) {
+                        if (n_hl > 1) {
+#pragma unroll
+                            for (int q = 0; q < HP; ++q)
+                                emit(L0 + o.wht + u * HP + unit_of<HP>(q, lane), folded(3 * CH * HP + 2 * CH + q));
+                            emit(L0 + o.bh + u, folded(3 * CH * HP + 2 * CH + HP + 1));
+                        }
+                        emit(L0 + o.b1 + u, folded(3 * CH * HP + 2 * CH + HP));
+                    }
+                }
+        
+            } else {
+                // ---- the four waves' accumulators -> LDS -> added in wave order into the workgroup's slab.  NSTAGE registers per
+                // wave and round (all of them in one round up to d = 256; two rounds at CH = 4, where staging all 114 next to the
+                // staged vector would exceed the LDS); register r of a round is folded and written by wave r mod 4.
+                float acc[NACC];
+                {
+                    int r = 0;
+#pragma unroll
+                    for (int i = 0; i < CH; ++i)
+#pragma unroll
+                        for (int q = 0; q < HP; ++q) acc[r++] = A.w1[i][q];
+#pragma unroll
+                    for (int i = 0; i < CH; ++i)
+#pragma unroll
+                        for (int q = 0; q < HP; ++q) acc[r++] = A.wa[i][q];
+#pragma unroll
+                    for (int i = 0; i < CH; ++i)
+#pragma unroll
+                        for (int q = 0; q < HP; ++q) acc[r++] = A.wb[i][q];
+#pragma unroll
+                    for (int i = 0; i < CH; ++i) acc[r++] = A.ba[i];
+#pragma unroll
+                    for (int i = 0; i < CH; ++i) acc[r++] = A.bb[i];
+#pragma unroll
+                    for (int q = 0; q < HP; ++q) acc[r++] = A.wh[q];
+                    acc[r++] = A.b1;
+                    acc[r++] = A.bh;
+                }
+                const int u = lane % HP;
+#pragma unroll
+                for (int r0 = 0; r0 < NACC; r0 += NSTAGE) {
+                    __syncthreads();   // the stage is free (the previous round's readers are done)
+#pragma unroll
+                    for (int r = r0; r < r0 + NSTAGE && r < NACC; ++r) mystage[(r - r0) * 64 + lane] = acc[r];
+                    __syncthreads();
+#pragma unroll
+                    for (int r = r0; r < r0 + NSTAGE && r < NACC; ++r) {
+                        if (((r - r0) & 3) != wave) continue;   // wave-uniform
+                        const int sl = r - r0;
+                        const float v = stage[(0 * NSTAGE + sl) * 64 + lane] + stage[(1 * NSTAGE + sl) * 64 + lane] +
+                                        stage[(2 * NSTAGE + sl) * 64 + lane] + stage[(3 * NSTAGE + sl) * 64 + lane];
+                        int64_t idx = -1;
+                        if (r < CH * HP) {                              // W1T rows of the lane's source elements
+                            const int i = r / HP, q = r % HP;
+                            if (L.jrow[i] >= 0) idx = L0 + o.w1t + L.jrow[i] + unit_of<HP>(q, lane);
+                        } else if (r < 2 * CH * HP) {                   // W3 alpha rows of its target elements
+                            const int i = (r - CH * HP) / HP, q = r % HP;
+                            if (L.trow[i] >= 0) idx = L0 + o.w3 + L.trow[i] + unit_of<HP>(q, lane);
+                        } else if (r < 3 * CH * HP) {                   // W3 beta rows
+                            const int i = (r - 2 * CH * HP) / HP, q = r % HP;
+                            if (L.trow[i] >= 0) idx = L0 + o.w3 + (int64_t)d_b * HP + L.trow[i] + unit_of<HP>(q, lane);
+                        } else if (r < 3 * CH * HP + CH) {              // b3, alpha half
+                            const int i = r - 3 * CH * HP;
+                            if (L.trow[i] >= 0) idx = L0 + o.b3 + L.trow[i] / HP;
+                        } else if (r < 3 * CH * HP + 2 * CH) {          // b3, beta half
+                            const int i = r - 3 * CH * HP - CH;
+                            if (L.trow[i] >= 0) idx = L0 + o.b3 + d_b + L.trow[i] / HP;
+                        } else if (r < 3 * CH * HP + 2 * CH + HP) {     // WhT row of the lane's hidden unit
+                            const int q = r - 3 * CH * HP - 2 * CH;
+                            if (lane < HP && n_hl > 1) idx = L0 + o.wht + u * HP + unit_of<HP>(q, lane);
+                        } else if (r == 3 * CH * HP + 2 * CH + HP) {    // b1
+                            if (lane < HP) idx = L0 + o.b1 + u;
+                        } else {                                        // bh
+                            if (lane < HP && n_hl > 1) idx = L0 + o.bh + u;
+                        }
+                        if (idx >= 0) P[idx] = first ? v : P[idx] + v;
+                    }
+                }
+        
             }
         }
         // ---- the sweep's last elementwise layer going backward: ML the FIRST ElementwiseAffine, RKL the LAST one inverted

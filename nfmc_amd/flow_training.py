@@ -192,7 +192,12 @@ class DeviceFit:
         self.C, self.hip, self.bij, self.dev = C, hip, bijection, device
         lib = hip.lib()
         self.d = d = bijection.d
-        self.H, self.nhl = bijection.n_hidden, bijection.n_hidden_layers
+        # the width the flow's kernels are presented with by default (flows.RealNVP.default_min_hidden: a conditioner 9..32 wide
+        # at d = 64 / 128 runs zero-padded to 64 on the matrix cores; the padding's weights are zero, get zero gradients and
+        # stay zero): the fit trains THAT blob, on the matrix-core fit kernel, and it is what the sampling kernels read
+        self.min_hidden = int(bijection.default_min_hidden())
+        self.H_true = bijection.n_hidden
+        self.H, self.nhl = max(bijection.n_hidden, self.min_hidden), bijection.n_hidden_layers
         self.hp = int(lib.nfmc_realnvp_padded_hidden(self.H))
         # layer stride rounded to 16 bytes: the row-per-wave kernel reads the staged blob with 16-byte LDS loads
         self.layer_stride = (int(lib.nfmc_coupling_layer_floats(d, self.H, self.nhl, 0)) + 3) // 4 * 4
@@ -243,8 +248,8 @@ class DeviceFit:
         """The flow's resident fitter (created on first use), ready for a new fit: learning rate set, validation rows
         cleared, the vector equal to the flow's current parameters."""
         fitter = bijection.__dict__.get('_device_fit')
-        if (fitter is None or fitter.dev != device or fitter.bij is not bijection or fitter.H != bijection.n_hidden
-                or fitter.nhl != bijection.n_hidden_layers or fitter.d != bijection.d
+        if (fitter is None or fitter.dev != device or fitter.bij is not bijection or fitter.H_true != bijection.n_hidden
+                or fitter.min_hidden != int(bijection.default_min_hidden()) or fitter.nhl != bijection.n_hidden_layers or fitter.d != bijection.d
                 or fitter.ea_off < bijection.n_coupling * fitter.layer_stride):
             fitter = cls(bijection, device, n_rows, lr)
             bijection.__dict__['_device_fit'] = fitter
@@ -260,8 +265,8 @@ class DeviceFit:
         """True when the flow's pack cache still holds THIS vector for the parameters as they are now: nothing touched the
         nn.Parameters since the last write_back, so there is nothing to gather."""
         cache = self.bij._pack_cache if isinstance(self.bij._pack_cache, dict) else {}
-        hit = cache.get(0)
-        return bool(hit is not None and hit[0] == self.bij._version_key(self.dev) + (0,) and hit[1][1]
+        hit = cache.get(self.min_hidden)
+        return bool(hit is not None and hit[0] == self.bij._version_key(self.dev) + (self.min_hidden,) and hit[1][1]
                     and hit[1][1][0] is self.params)
 
     def _struct(self, vec):
@@ -274,7 +279,7 @@ class DeviceFit:
         """[(parameter tensor, offset in the vector, rows, cols, vector stride of a row, of a column)] in the VALU blob
         layout (include/nfmc_hip.h: W1T (d_a, HP) | b1 | [WhT (HP, HP) | bh] | W3 (2 d_b, HP) | b3 per coupling layer, then
         the four ElementwiseAffine vectors at ea_off)."""
-        H, hp, d = self.H, self.hp, self.d
+        H, hp, d = self.H_true, self.hp, self.d
         d_a, d_b = d // 2, d - d // 2
         out = []
         if self.wide:
@@ -434,7 +439,7 @@ class DeviceFit:
             bij, o, d4 = self.bij, self.ea_off, self.d4
             keep = [vec] + [vec[o + k * d4:o + k * d4 + self.d] for k in range(4)]
             # every other presentation of the weights (e.g. zero-padded to the matrix-core width) is stale now
-            bij._pack_cache = {0: (bij._version_key(self.dev) + (0,), (self._struct(vec), keep))}
+            bij._pack_cache = {self.min_hidden: (bij._version_key(self.dev) + (self.min_hidden,), (self._struct(vec), keep))}
 
 
 class PendingFit:

@@ -66,12 +66,12 @@ def test_nll_gradient_matches_autograd(dev, d, H, nhl, nl, n, nice):
         scale = max(float(w.abs().max()), 1e-3)
         np.testing.assert_allclose(p.detach().cpu().numpy(), w.numpy(), atol=2e-4 * scale, rtol=0, err_msg=name)
     # the padded entries of the blob (hidden units beyond n_hidden, alignment gaps) carry no gradient
+    # (every slot a parameter entry maps to -- for conditioners presented on the matrix cores both orientations of a matrix)
     used = torch.zeros_like(fit.m, dtype=torch.bool)
-    probe = copy.deepcopy(f)
-    marker = torch.arange(1, fit.n_params + 1, dtype=torch.float32, device=dev)
-    fit.write_back(marker, bijection=probe.bijection)
-    for p in probe.parameters():
-        used[(p.detach().reshape(-1).long() - 1)] = True
+    for _p, off, r, c, rs, cs in fit._layout(f.bijection):
+        idx = off + torch.arange(r, device=dev)[:, None] * rs + torch.arange(c, device=dev)[None, :] * cs
+        used[idx.reshape(-1)] = True
+    assert int(used.sum()) > 0
     assert float(fit.m[~used].abs().max() if (~used).any() else 0.0) == 0.0
 
 
