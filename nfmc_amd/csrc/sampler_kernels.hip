@@ -172,6 +172,77 @@ __global__ void __launch_bounds__(kFinishBlock) tune_finish_kernel(double* __res
     }
 }
 
+// Round 4: the tuning launches no longer run at a quarter of the machine.  With kTuneGrid workgroups a one-transition launch
+// of 65536 x 64 chains is 1024 waves, one per SIMD, each walking eight chain tiles one after the other (26 us); with the full
+// grid it is ~8 us, but leaves up to 2032 slabs -- which kTuneFoldWgs workgroups first fold 128 at a time (every thread has all
+// its loads in flight at once, as in tune_finish_kernel) into partial slabs at the END of the scratch, and tune_finish_kernel
+// then folds those.  Three launches per controller update instead of two, ~30 us instead of 47 (profiles/r04_warmup_probe.txt).
+constexpr int kTuneFoldSlabs = 128, kTuneFoldWgs = 16;
+__global__ void __launch_bounds__(kFinishBlock) tune_fold_kernel(double* __restrict__ scratch, int nblocks, int width,
+                                                                 double* __restrict__ partial) {
+    __shared__ double part[kFinishSlices][kFinishCols];
+    const int col = threadIdx.x % kFinishCols, slice = threadIdx.x / kFinishCols;
+    const int b0 = blockIdx.x * kTuneFoldSlabs;
+    double* __restrict__ dst = partial + (size_t)blockIdx.x * width;
+    constexpr int kGroups = 5, kRows = kTuneFoldSlabs / kFinishSlices;   // 20 fp64 loads in flight per thread
+    for (int t0 = 0; t0 < width; t0 += kGroups * kFinishCols) {
+        double v[kGroups][kRows];
+#pragma unroll
+        for (int gi = 0; gi < kGroups; ++gi) {
+            const int t = t0 + gi * kFinishCols + col;
+#pragma unroll
+            for (int u = 0; u < kRows; ++u) {
+                const int b = b0 + slice + u * kFinishSlices;
+                v[gi][u] = (t < width && b < nblocks) ? scratch[(size_t)b * width + t] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int gi = 0; gi < kGroups; ++gi) {
+            const int t = t0 + gi * kFinishCols + col;
+            double acc = 0.0;
+#pragma unroll
+            for (int u = 0; u < kRows; ++u) acc += v[gi][u];   // row order
+#pragma unroll
+            for (int u = 0; u < kRows; ++u) {
+                const int b = b0 + slice + u * kFinishSlices;
+                if (t < width && b < nblocks) scratch[(size_t)b * width + t] = 0.0;
+            }
+            __syncthreads();   // part[] of the previous column group has been consumed
+            part[slice][col] = acc;
+            __syncthreads();
+            if (slice == 0 && t < width) {
+                double sum = 0.0;
+#pragma unroll
+                for (int k = 0; k < kFinishSlices; ++k) sum += part[k][col];
+                dst[t] = sum;
+            }
+        }
+    }
+}
+
+// grid of a tuning launch and whether its slabs are folded in two levels (the scratch then holds the partial slabs behind
+// the last workgroup's)
+static int tune_grid(int64_t tiles, int dp, int64_t scratch_bytes, bool* two_level) {
+    const int64_t width = 2 * dp + kStatTail;
+    *two_level = tiles > kTuneGrid && scratch_bytes >= (int64_t)kMaxGrid * width * (int64_t)sizeof(double) && !getenv("NFMC_TUNE_ONE_LEVEL");
+    const int cap = *two_level ? kMaxGrid - kTuneFoldWgs : kTuneGrid;
+    return (int)(tiles < cap ? tiles : cap);
+}
+
+// the fold + controller of one update behind a tuning launch of `grid` workgroups
+static void tune_update(const NfmcStats& stats, const NfmcTune& tune, int grid, bool two_level, int dp, int d, unsigned long long attempted,
+                        hipStream_t st) {
+    const int width = 2 * dp + kStatTail;
+    if (two_level) {
+        double* partial = stats.scratch + (size_t)(kMaxGrid - kTuneFoldWgs) * width;
+        const int wgs = (grid + kTuneFoldSlabs - 1) / kTuneFoldSlabs;
+        hipLaunchKernelGGL(tune_fold_kernel, dim3(wgs), dim3(kFinishBlock), 0, st, stats.scratch, grid, width, partial);
+        hipLaunchKernelGGL(tune_finish_kernel<1>, dim3(1), dim3(kFinishBlock), 0, st, partial, wgs, dp, d, stats, tune, attempted);
+    } else {
+        hipLaunchKernelGGL(tune_finish_kernel<1>, dim3(1), dim3(kFinishBlock), 0, st, stats.scratch, grid, dp, d, stats, tune, attempted);
+    }
+}
+
 template <class Args>
 static int check_tune(const Args& a) {
     if (!a.tune.state) return NFMC_OK;
@@ -219,8 +290,8 @@ extern "C" int nfmc_mala_steps_f32(const NfmcMalaArgs* args, nfmc_stream_t strea
     const int dp = c.cpl * c.lpc;
     const int cpw = kWave / c.lpc;
     const int64_t tiles = (a.n + (int64_t)kWavesPerBlock * cpw - 1) / ((int64_t)kWavesPerBlock * cpw);
-    const int gmax = a.tune.state ? kTuneGrid : kMaxGrid;   // warmup: few slabs for the one-workgroup fold
-    const int grid = (int)(tiles < gmax ? tiles : gmax);
+    bool two_level = false;
+    const int grid = a.tune.state ? tune_grid(tiles, dp, a.stats.scratch_bytes, &two_level) : (int)(tiles < kMaxGrid ? tiles : kMaxGrid);
     if (a.stats.sum_x && a.stats.scratch_bytes < (int64_t)grid * (2 * dp + kStatTail) * (int64_t)sizeof(double))
         return NFMC_ESCRATCH;
     if (check_defer(a.stats, dp, a.d)) return NFMC_EINVAL;
@@ -244,8 +315,7 @@ extern "C" int nfmc_mala_steps_f32(const NfmcMalaArgs* args, nfmc_stream_t strea
             if (a.log_ratio_out) b.log_ratio_out = a.log_ratio_out + (int64_t)s0 * a.n;
             rc = launch_mala_j0(b, jd, c, fast, tiles, grid, sqrt2h, st);
             if (rc) return rc;
-            hipLaunchKernelGGL(tune_finish_kernel<1>, dim3(1), dim3(kFinishBlock), 0, st, a.stats.scratch, grid,
-                               dp, a.d, a.stats, a.tune, (unsigned long long)a.n * (unsigned long long)k);
+            tune_update(a.stats, a.tune, grid, two_level, dp, a.d, (unsigned long long)a.n * (unsigned long long)k, st);
             NFMC_HIP_CHECK_LAUNCH();
             store_advance(a.samples, k);
         }
@@ -278,8 +348,8 @@ extern "C" int nfmc_hmc_steps_f32(const NfmcHmcArgs* args, nfmc_stream_t stream)
     const int dp = c.cpl * c.lpc;
     const int cpw = kWave / c.lpc;
     const int64_t tiles = (a.n + (int64_t)kWavesPerBlock * cpw - 1) / ((int64_t)kWavesPerBlock * cpw);
-    const int gmax = a.tune.state ? kTuneGrid : kMaxGrid;   // warmup: few slabs for the one-workgroup fold
-    const int grid = (int)(tiles < gmax ? tiles : gmax);
+    bool two_level = false;
+    const int grid = a.tune.state ? tune_grid(tiles, dp, a.stats.scratch_bytes, &two_level) : (int)(tiles < kMaxGrid ? tiles : kMaxGrid);
     if (a.stats.sum_x && a.stats.scratch_bytes < (int64_t)grid * (2 * dp + kStatTail) * (int64_t)sizeof(double))
         return NFMC_ESCRATCH;
     if (check_defer(a.stats, dp, a.d)) return NFMC_EINVAL;
@@ -301,8 +371,7 @@ extern "C" int nfmc_hmc_steps_f32(const NfmcHmcArgs* args, nfmc_stream_t stream)
             if (a.log_ratio_out) b.log_ratio_out = a.log_ratio_out + (int64_t)s0 * a.n;
             rc = launch_hmc_j0(b, jd, c, fast, tiles, grid, st);
             if (rc) return rc;
-            hipLaunchKernelGGL(tune_finish_kernel<1>, dim3(1), dim3(kFinishBlock), 0, st, a.stats.scratch, grid,
-                               dp, a.d, a.stats, a.tune, (unsigned long long)a.n * (unsigned long long)k);
+            tune_update(a.stats, a.tune, grid, two_level, dp, a.d, (unsigned long long)a.n * (unsigned long long)k, st);
             NFMC_HIP_CHECK_LAUNCH();
             store_advance(a.samples, k);
         }

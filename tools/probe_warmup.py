@@ -34,6 +34,11 @@ def warmup(every, device=True):
 
 t_s = timed(sampling)
 print('sampling, %d transitions: %.2f ms' % (K, t_s))
-for every, device in [(1, False), (1, True), (5, True), (10, True), (25, True)]:
+for every, device, one_level in [(1, False, False), (1, True, True), (1, True, False), (5, True, False), (10, True, False), (25, True, False)]:
+    if one_level:   # round 2-3: tuning launches of 256 workgroups, one workgroup folds their slabs
+        os.environ['NFMC_TUNE_ONE_LEVEL'] = '1'
+    else:
+        os.environ.pop('NFMC_TUNE_ONE_LEVEL', None)
     t = timed(lambda: warmup(every, device))
-    print('warmup tune_every=%-3d %-6s: %.2f ms  (%.1fx sampling)  tuned step %.4f' % (every, 'device' if device else 'host', t, t / t_s, warmup(every, device)))
+    print('warmup tune_every=%-3d %-6s %-22s: %.2f ms  (%.1fx sampling)  tuned step %.4f' % (
+        every, 'device' if device else 'host', '(256 workgroups, 1 fold)' if one_level else '', t, t / t_s, warmup(every, device)))
