@@ -52,6 +52,21 @@ def _shuffled(rows: torch.Tensor) -> torch.Tensor:
     return rows[torch.randperm(rows.shape[0], device=rows.device)]
 
 
+def _sampled_rows(rows: torch.Tensor, m: int) -> torch.Tensor:
+    """The first m rows of a shuffle of `rows`, without materialising the shuffled buffer: on the GPU one launch of
+    nfmc_rows_sample_f32 (rows pi(0 .. m - 1) of a keyed pseudo-random permutation, key from torch's CPU generator)."""
+    total = rows.shape[0]
+    if rows.is_cuda and rows.dtype == torch.float32 and rows.is_contiguous() and 0 < m <= total:
+        from . import hip
+        flat = rows.reshape(total, -1)
+        out = torch.empty(m, flat.shape[1], dtype=torch.float32, device=rows.device)
+        seed = int(torch.randint(0, 2 ** 62, ()).item())
+        hip.check(hip.lib().nfmc_rows_sample_f32(hip.ptr(flat), total, flat.shape[1], seed, 0, hip.ptr(out), m, None, hip.stream()),
+                  'nfmc_rows_sample_f32')
+        return out.reshape(m, *rows.shape[1:])
+    return rows[torch.randperm(total, device=rows.device)[:m]].contiguous()
+
+
 def train_val_split(x: torch.Tensor, train_pct: float, max_train_size: int, max_val_size: int, shuffle: bool = True,
                     shard=None):
     """(n_iterations, n_chains, *event) -> (x_train, x_val): all (step, chain) rows pooled, shuffled, cut at
@@ -70,8 +85,11 @@ def train_val_split(x: torch.Tensor, train_pct: float, max_train_size: int, max_
         share = shard.all_reduce_min_int(min(share, rows.shape[0]))
         if share <= 0:
             raise ValueError('train_val_split: a rank has no rows to contribute to the refit buffer')
-        local = _shuffled(rows) if shuffle else rows
-        rows = shard.all_gather_rows(local[:share].contiguous())
+        if shuffle:
+            local = _sampled_rows(rows, share)      # this rank's share: the first rows of a shuffle of its own rows
+        else:
+            local = rows[:share].contiguous()
+        rows = shard.all_gather_rows(local)
         if shuffle:
             seed = shard.broadcast_int(int(torch.randint(0, 2 ** 62, ()).item()))
             perm = torch.randperm(rows.shape[0], generator=torch.Generator().manual_seed(seed))
@@ -87,13 +105,7 @@ def train_val_split(x: torch.Tensor, train_pct: float, max_train_size: int, max_
             # pseudo-random permutation pi of the pooled rows -- positions [0, n_train) and [cut, cut + n_val) of a uniform
             # shuffle are, in distribution, any n_train + n_val distinct positions of it.  The key comes from torch's CPU
             # generator, like the reference's randperm (tuning.py:58-59); no sort of all rows, no index tensors.
-            from . import hip
-            flat = rows.reshape(total, -1)
-            out = torch.empty(n_train + n_val, flat.shape[1], dtype=torch.float32, device=rows.device)
-            seed = int(torch.randint(0, 2 ** 62, ()).item())
-            hip.check(hip.lib().nfmc_rows_sample_f32(hip.ptr(flat), total, flat.shape[1], seed, 0, hip.ptr(out),
-                                                     n_train + n_val, None, hip.stream()), 'nfmc_rows_sample_f32')
-            out = out.reshape(n_train + n_val, *rows.shape[1:])
+            out = _sampled_rows(rows, n_train + n_val)
             return out[:n_train], out[n_train:]
         perm = torch.randperm(total, device=rows.device)
         return rows[perm[:cut][:max_train_size]], rows[perm[cut:][:max_val_size]]
