@@ -56,9 +56,23 @@ def _digest():
                 h.update(f.encode())
                 with open(p, 'rb') as fh:
                     h.update(fh.read())
-    h.update(' '.join(FLAGS).encode())
+    # the include paths enter the digest under their canonical names, not where this checkout happens to live: the same
+    # sources give the same digest in /root/repo, on the GPU box's scratch path and in a `git archive` copy
+    canon = [f.replace('-I' + INCLUDE, '-I/root/repo/include').replace('-I' + CSRC, '-I/root/repo/nfmc_amd/csrc') for f in FLAGS]
+    h.update(' '.join(canon).encode())
     h.update(repr(sorted(UNIT_FLAGS.items())).encode())
     return h.hexdigest()
+
+
+def _library_digest():
+    """The digest baked into the built library (nfmc_build_digest), or None."""
+    try:
+        import ctypes
+        fn = ctypes.CDLL(LIB).nfmc_build_digest
+        fn.restype = ctypes.c_char_p
+        return fn().decode()
+    except Exception:   # noqa: BLE001
+        return None
 
 
 _INCLUDE = None
@@ -83,7 +97,8 @@ def _unit_digest(src):
         h.update(os.path.basename(path).encode())
         with open(path, 'rb') as fh:
             h.update(fh.read())
-    h.update(' '.join(FLAGS + UNIT_FLAGS.get(src, [])).encode())
+    canon = [f.replace('-I' + INCLUDE, '-I/root/repo/include').replace('-I' + CSRC, '-I/root/repo/nfmc_amd/csrc') for f in FLAGS]
+    h.update(' '.join(canon + UNIT_FLAGS.get(src, [])).encode())
     return h.hexdigest()
 
 
@@ -110,8 +125,11 @@ def build(force=False, verbose=True):
         os.environ['NFMC_BUILD_ALL'] = '1'   # --force recompiles every unit
     stamp = os.path.join(OBJ, 'digest.txt')
     dig = _digest()
-    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == dig:
-        return LIB
+    if not force and os.path.exists(LIB):
+        # current when the stamp says so -- or, where the build directory did not travel (the GPU box gets the library but not
+        # csrc/build/), when the library itself reports the digest of these sources
+        if (os.path.exists(stamp) and open(stamp).read() == dig) or _library_digest() == dig:
+            return LIB
     if not os.path.exists(HIPCC):
         raise RuntimeError('hipcc not found at %s; cannot build libnfmc_hip.so' % HIPCC)
     srcs = sources()
