@@ -19,14 +19,33 @@
 //   W3^T              the same groups, in the second image; the reverse sweep FUSES the W3 product, the affine backward
 //                     and the W3^T product per target tile, so du / dv never exist as whole vectors
 //   W1^T (d_a x hp)   row slices, accumulating into gradient tiles streamed through the epilogue
-// One image at a time, a barrier before and after each staging (the register-resident kernels overlap the next copy with
-// the current GEMM; here the copy is 1/4 of a GEMM's time and the path is the fallback for shapes that used to run
-// through torch autograd).  The reverse sweep recomputes the hidden stack (no checkpoints).
+// The stagings alternate between the two images, one barrier each (WideCtx::buf; the reverse sweep's W3 / W3^T groups take
+// both images behind a full barrier): a wave stages GEMM k's operand right after its GEMM k - 1, under the late waves'
+// MFMAs.  Round 4: 0.756 -> 0.745 ms for the d = 256 gradient, 0.279 -> 0.272 ms forward, 0.503 -> 0.480 ms for the d = 512
+// inverse -- as in the register-resident kernels, the barriers were not the main loss.  The reverse sweep recomputes the
+// hidden stack (no checkpoints).
 #include "mfma_flow.hpp"
 
 namespace nfmc {
 
 constexpr int kWideSlice = 128;                 // source / target coordinates per weight image
+// 16-byte staging pieces a thread has in flight (stage_any's kBatch).  A 128 x 128 image is 8 pieces per thread: with ALL of
+// them requested before the first is stored a staging is one L2 round trip instead of eight.  Round 3 gave the gradient
+// kernels what 256 registers left without scratch (1 or 2); measured in round 4 (tools/probe_wide.py, d = 256, H = 128 x 2,
+// NFMC_WIDE_*_SB variants on one box) the round trips cost more than the spills that the deeper batch brings:
+//   gradient kernel      SB 1: 0.749 ms (225 VGPR, no scratch)   4: 0.704 (29 spilled)   8: 0.695 (16 spilled)
+//   one-launch leapfrog  SB 1: 3.42 ms per trajectory (45 spilled)   4: 3.21 (109)   8: 3.34 (101)
+//   forward / inverse    SB 4: 0.270 / 0.275 ms   8: 0.267 / 0.271 (no scratch either way)
+#ifndef NFMC_WIDE_FLOW_SB
+#define NFMC_WIDE_FLOW_SB 8
+#endif
+#ifndef NFMC_WIDE_GRAD_SB
+#define NFMC_WIDE_GRAD_SB 8
+#endif
+#ifndef NFMC_WIDE_LEAP_SB
+#define NFMC_WIDE_LEAP_SB 4
+#endif
+constexpr int kWideFlowSB = NFMC_WIDE_FLOW_SB, kWideGradSB = NFMC_WIDE_GRAD_SB, kWideLeapSB = NFMC_WIDE_LEAP_SB;
 constexpr size_t kWideLdsBytes = (size_t)(2 * kImgFloats + 2 * kVecFloats) * sizeof(float);
 
 __device__ __forceinline__ f32x4 rev4(const f32x4 a) {
@@ -45,7 +64,7 @@ __device__ __forceinline__ void stage_any(float* __restrict__ img, int ld, const
     const int k4 = 1 << k4log, N = R << k4log;
     // The weights sit in L2: a copy is latency, not bandwidth.  kBatch 16-byte pieces per thread are requested before the
     // first is stored (as a plain loop every piece was load -> wait -> store: 8 dependent round trips per 128 x 128 image);
-    // kBatch is what the calling kernel's register budget leaves (4 in the flow passes, 2 or 1 in the gradient kernel).
+    // kBatch per kernel: kWideFlowSB / kWideGradSB / kWideLeapSB.
     for (int base = threadIdx.x; base < N; base += kBatch * kMfmaBlock) {
         f32x4 v[kBatch];
 #pragma unroll
@@ -71,6 +90,12 @@ __device__ __forceinline__ int log2i(int v) { return 31 - __builtin_clz(v); }
 
 struct WideCtx {
     float *img0, *img1, *vec0;   // LDS
+    // The stagings ALTERNATE between the two weight images (and the two bias vectors): staging k writes the image GEMM
+    // k - 2 read, and a wave passes the barrier that closes staging k - 1 only after it has finished GEMM k - 2, so one
+    // barrier per staging is enough (the first version staged everything into image 0 and needed a second barrier in
+    // front of each staging).  A phase that uses BOTH images (the reverse sweep's W3 / W3^T groups, the statistics that
+    // borrow the image memory) opens with a full barrier, after which either image may be written.
+    mutable int buf;
     float* xs;                   // this lane's chain in the state slab: element (16 m + 4 q + t) of tile m at xs[16 m + t]
     float* gs;                   // the same in the gradient slab
     int d, D2, TS, nslice, ngroup;   // D2 = d / 2 = 16 TS; slices of 128 source coordinates, groups of 64 target coordinates (the last may be partial)
@@ -101,11 +126,19 @@ __device__ __forceinline__ void wide_ctx_init(WideCtx& c, float* lds, const Nfmc
     c.img0 = lds;
     c.img1 = lds + kImgFloats;
     c.vec0 = lds + 2 * kImgFloats;
+    c.buf = 0;
     c.d = f.d, c.D2 = f.d / 2, c.TS = f.d / 32, c.nslice = (f.d / 2 + kWideSlice - 1) / kWideSlice, c.ngroup = (f.d / 2 + 63) / 64;
     c.col = lane & 15, c.q = lane >> 4;
     c.mscale = f.min_scale;
     c.log1m = __logf(1.f - f.min_scale);
     c.gs = nullptr;
+}
+
+// the image and bias vector the next staging writes
+__device__ __forceinline__ void wide_next(const WideCtx& c, float*& img, float*& vec) {
+    c.buf ^= 1;
+    img = c.buf ? c.img1 : c.img0;
+    vec = c.vec0 + (c.buf ? kVecFloats : 0);
 }
 
 __device__ __forceinline__ float wide_sum_squares(const WideCtx& c) {
@@ -134,12 +167,13 @@ __device__ __forceinline__ void wide_hidden(const WideCtx& c, const MLayer& L, b
     constexpr int hp = 16 * TH;
     const float* xsrc = c.xs + 16 * (REV ? c.D2 / 16 : 0);
     for (int ks = 0; ks < c.nslice; ++ks) {
-        __syncthreads();   // the previous phase has finished reading image 0
+        float *img, *vec;
+        wide_next(c, img, vec);
         // source positions [128 ks, 128 ks + 128) of the half; a reversed layer's position p is column D2 - 1 - p
-        stage_any<SB>(c.img0, kWideSlice + 4, L.W1, c.D2, hp, 5, hp, c.D2 - kWideSlice * ks, 0, false,
+        stage_any<SB>(img, kWideSlice + 4, L.W1, c.D2, hp, 5, hp, c.D2 - kWideSlice * ks, 0, false,
                   REV ? c.D2 - 1 - kWideSlice * ks : kWideSlice * ks, REV);
         if (ks == 0)
-            for (int i = threadIdx.x; i < hp; i += kMfmaBlock) c.vec0[i] = L.b1[i];
+            for (int i = threadIdx.x; i < hp; i += kMfmaBlock) vec[i] = L.b1[i];
         f32x4 src[8];
 #pragma unroll
         for (int ms = 0; ms < 8; ++ms) {
@@ -147,8 +181,6 @@ __device__ __forceinline__ void wide_hidden(const WideCtx& c, const MLayer& L, b
             else src[ms][0] = src[ms][1] = src[ms][2] = src[ms][3] = 0.f;   // past the half (d_a not a multiple of 128)
         }
         __syncthreads();
-        const float* img = c.img0;
-        const float* vec = c.vec0;
         const int col = c.col, q = c.q;
         const bool first = ks == 0, last = ks + 1 == c.nslice;
         gemm_phase<8, TH>([&](int mo) { return img + (16 * mo + col) * (kWideSlice + 4) + 4 * q; },
@@ -161,12 +193,11 @@ __device__ __forceinline__ void wide_hidden(const WideCtx& c, const MLayer& L, b
                           });
     }
     if constexpr (NHL > 1) {
+        float *img, *vec;
+        wide_next(c, img, vec);
+        stage_any<SB>(img, hp + 4, L.Wh, hp, hp, log2i(hp / 4), hp, hp, 0, false, 0, false);
+        for (int i = threadIdx.x; i < hp; i += kMfmaBlock) vec[i] = L.bh[i];
         __syncthreads();
-        stage_any<SB>(c.img0, hp + 4, L.Wh, hp, hp, log2i(hp / 4), hp, hp, 0, false, 0, false);
-        for (int i = threadIdx.x; i < hp; i += kMfmaBlock) c.vec0[i] = L.bh[i];
-        __syncthreads();
-        const float* img = c.img0;
-        const float* vec = c.vec0;
         const int col = c.col, q = c.q;
         gemm_phase<TH, TH>([&](int mo) { return img + (16 * mo + col) * (hp + 4) + 4 * q; },
                            [&](int mo) { h2[mo] = vec_tile(vec, mo, q); }, [&](int mo) -> f32x4& { return h2[mo]; },
@@ -174,17 +205,17 @@ __device__ __forceinline__ void wide_hidden(const WideCtx& c, const MLayer& L, b
     }
 }
 
-// the alpha and beta rows (and biases) of target group gq -> image 0 rows [0, 64) and [64, 128), vec0[0, 128)
+// the alpha and beta rows (and biases) of target group gq -> rows [0, 64) and [64, 128) of `img`, vec[0, 128)
 template <int TH, int SB>
-__device__ __forceinline__ void wide_stage_w3(const WideCtx& c, const MLayer& L, bool REV, int gq) {
+__device__ __forceinline__ void wide_stage_w3(const WideCtx& c, const MLayer& L, bool REV, int gq, float* img, float* vec) {
     constexpr int hp = 16 * TH;
     const int rv = c.D2 - 64 * gq;                            // target positions [64 gq, 64 gq + 64) of the half that exist
     const int r0 = REV ? c.D2 - 1 - 64 * gq : 64 * gq;        // a reversed layer's target position p is output row D2 - 1 - p
-    stage_any<SB>(c.img0, hp + 4, L.W3, hp, 64, log2i(hp / 4), rv, hp, r0, REV, 0, false);
-    stage_any<SB>(c.img0 + 64 * (hp + 4), hp + 4, L.W3, hp, 64, log2i(hp / 4), rv, hp, c.D2 + r0, REV, 0, false);
+    stage_any<SB>(img, hp + 4, L.W3, hp, 64, log2i(hp / 4), rv, hp, r0, REV, 0, false);
+    stage_any<SB>(img + 64 * (hp + 4), hp + 4, L.W3, hp, 64, log2i(hp / 4), rv, hp, c.D2 + r0, REV, 0, false);
     for (int i = threadIdx.x; i < 128; i += kMfmaBlock) {
         const int r = i & 63, blk = i >> 6;
-        c.vec0[i] = r < rv ? L.b3[blk * c.D2 + (REV ? r0 - r : r0 + r)] : 0.f;
+        vec[i] = r < rv ? L.b3[blk * c.D2 + (REV ? r0 - r : r0 + r)] : 0.f;
     }
 }
 
@@ -199,11 +230,10 @@ __device__ __forceinline__ float wide_coupling(const WideCtx& c, const MLayer& L
     float* xt = c.xs + 16 * (REV ? 0 : c.D2 / 16);
     float ld = 0.f;
     for (int gq = 0; gq < c.ngroup; ++gq) {
+        float *img, *vec;
+        wide_next(c, img, vec);
+        wide_stage_w3<TH, SB>(c, L, REV, gq, img, vec);
         __syncthreads();
-        wide_stage_w3<TH, SB>(c, L, REV, gq);
-        __syncthreads();
-        const float* img = c.img0;
-        const float* vec = c.vec0;
         const int col = c.col, q = c.q;
         const float mscale = c.mscale, log1m = c.log1m;
         f32x4 ua2[2], ub2[2], y2[2];
@@ -257,8 +287,8 @@ __device__ __forceinline__ void wide_coupling_backward(const WideCtx& c, const M
     const int col = c.col, q = c.q;
     const float mscale = c.mscale, log1m = c.log1m;
     for (int gq = 0; gq < c.ngroup; ++gq) {
-        __syncthreads();
-        wide_stage_w3<TH, SB>(c, L, REV, gq);
+        __syncthreads();   // both images are written: every wave has finished the previous GEMMs
+        wide_stage_w3<TH, SB>(c, L, REV, gq, c.img0, c.vec0);
         // W3^T of the same four target tiles -> image 1, a tile's 16 alpha columns next to its 16 beta columns
         for (int mt = 0; mt < 4; ++mt) {
             const int p0 = 64 * gq + 16 * mt;                      // target position of the tile's first coordinate
@@ -303,10 +333,11 @@ __device__ __forceinline__ void wide_coupling_backward(const WideCtx& c, const M
 #pragma unroll
         for (int t = 0; t < 4; ++t) dh[mo][t] *= (1.f - hl[mo][t] * hl[mo][t]);
     if constexpr (NHL > 1) {
+        __syncthreads();   // after the last group, which read both images
+        float *img, *vec;
+        wide_next(c, img, vec);
+        stage_any<SB>(img, hp + 4, L.WhT, hp, hp, log2i(hp / 4), hp, hp, 0, false, 0, false);
         __syncthreads();
-        stage_any<SB>(c.img0, hp + 4, L.WhT, hp, hp, log2i(hp / 4), hp, hp, 0, false, 0, false);
-        __syncthreads();
-        const float* img = c.img0;
         gemm_phase<TH, TH>([&](int mo) { return img + (16 * mo + col) * (hp + 4) + 4 * q; },
                            [&](int mo) {
 #pragma unroll
@@ -320,11 +351,12 @@ __device__ __forceinline__ void wide_coupling_backward(const WideCtx& c, const M
     }
     float* gsrc = c.gs + 16 * (REV ? c.D2 / 16 : 0);
     for (int ks = 0; ks < c.nslice; ++ks) {
-        __syncthreads();
-        stage_any<SB>(c.img0, hp + 4, L.W1T, hp, kWideSlice, log2i(hp / 4), c.D2 - kWideSlice * ks, hp,
+        if (NHL == 1 && ks == 0) __syncthreads();   // after the last group, which read both images
+        float *img, *vec;
+        wide_next(c, img, vec);
+        stage_any<SB>(img, hp + 4, L.W1T, hp, kWideSlice, log2i(hp / 4), c.D2 - kWideSlice * ks, hp,
                   REV ? c.D2 - 1 - kWideSlice * ks : kWideSlice * ks, REV, 0, false);
         __syncthreads();
-        const float* img = c.img0;
         f32x4 acc2[2];
         gemm_phase<TH, 8>([&](int ms) { return img + (16 * ms + col) * (hp + 4) + 4 * q; },
                           [&](int ms) {
@@ -429,7 +461,7 @@ __global__ void __launch_bounds__(kMfmaBlock, 2) neutra_grad_wide_kernel(NfmcRea
                                                                       float* __restrict__ slab, int64_t tiles) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int hp = 16 * TH;
-    constexpr int kSB = (TH == 8 && NHL == 2) ? 1 : 2;   // staging pieces in flight: what is left of 256 registers (no scratch)
+    constexpr int kSB = kWideGradSB;
     const int d = f.d;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool rev_last = (f.n_coupling & 1) != 0;
@@ -488,7 +520,7 @@ __global__ void __launch_bounds__(kMfmaBlock, 2) realnvp_forward_wide_kernel(Nfm
         wide_tiles(d / 16, [&](int m) { return vec_tile(xr, m, c.q); }, [&](int m, const f32x4& v) { tile_st(c.xs, m, v); });
         float ldp = wide_ea<kEaForward>(c, f.ea0_log_scale, f.ea0_shift, false);
         for (int l = 0; l < f.n_coupling; ++l)
-            ldp += wide_coupling<TH, NHL, false, 4>(c, mfma_layer(f.weights + l * f.layer_stride, d, hp, NHL), (l & 1) == 0);
+            ldp += wide_coupling<TH, NHL, false, kWideFlowSB>(c, mfma_layer(f.weights + l * f.layer_stride, d, hp, NHL), (l & 1) == 0);
         ldp += wide_ea<kEaForward>(c, f.ea1_log_scale, f.ea1_shift, rev_last);
         const float ld = chain_sum(ldp);
         const float ss = wide_sum_squares(c);
@@ -543,7 +575,7 @@ __global__ void __launch_bounds__(kMfmaBlock, 2) realnvp_inverse_wide_kernel(Nfm
         const float ss = wide_sum_squares(c);
         float ldp = wide_ea<kEaInverse>(c, f.ea1_log_scale, f.ea1_shift, rev_last);
         for (int l = f.n_coupling - 1; l >= 0; --l)
-            ldp += wide_coupling<TH, NHL, true, 4>(c, mfma_layer(f.weights + l * f.layer_stride, d, hp, NHL), (l & 1) == 0);
+            ldp += wide_coupling<TH, NHL, true, kWideFlowSB>(c, mfma_layer(f.weights + l * f.layer_stride, d, hp, NHL), (l & 1) == 0);
         ldp += wide_ea<kEaInverse>(c, f.ea0_log_scale, f.ea0_shift, false);
         const float ld = chain_sum(ldp);
         if (active) {
@@ -578,7 +610,7 @@ template <int TH, int NHL>
 __global__ void __launch_bounds__(kMfmaBlock, 2) neutra_leapfrog_wide_kernel(WideLeapArgs A, int64_t tiles, int dp) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int hp = 16 * TH;
-    constexpr int kSB = (TH == 8 && NHL == 2) ? 1 : 2;
+    constexpr int kSB = kWideLeapSB;
     const NfmcNeutraHmcArgs& a = A.a;
     const NfmcRealNVP& f = a.flow;
     const int d = f.d, TD = f.d / 16;
@@ -873,7 +905,7 @@ __global__ void __launch_bounds__(kMfmaBlock, 2) flow_mh_wide_kernel(NfmcFlowMhA
         } else {                                                                    // flow.log_prob(x): jump.py:218 / imh.py:214
             float ldp = wide_ea<kEaForward>(c, f.ea0_log_scale, f.ea0_shift, false);
             for (int l = 0; l < f.n_coupling; ++l)
-                ldp += wide_coupling<TH, NHL, false, 4>(c, mfma_layer(f.weights + l * f.layer_stride, d, hp, NHL), (l & 1) == 0);
+                ldp += wide_coupling<TH, NHL, false, kWideFlowSB>(c, mfma_layer(f.weights + l * f.layer_stride, d, hp, NHL), (l & 1) == 0);
             ldp += wide_ea<kEaForward>(c, f.ea1_log_scale, f.ea1_shift, rev);
             f_x = -0.5f * wide_sum_squares(c) + base_c + chain_sum(ldp);
         }
@@ -904,7 +936,7 @@ __global__ void __launch_bounds__(kMfmaBlock, 2) flow_mh_wide_kernel(NfmcFlowMhA
             ss = chain_sum(ss);
             float ldp = wide_ea<kEaInverse>(c, f.ea1_log_scale, f.ea1_shift, rev);
             for (int l = f.n_coupling - 1; l >= 0; --l)
-                ldp += wide_coupling<TH, NHL, true, 4>(c, mfma_layer(f.weights + l * f.layer_stride, d, hp, NHL), (l & 1) == 0);
+                ldp += wide_coupling<TH, NHL, true, kWideFlowSB>(c, mfma_layer(f.weights + l * f.layer_stride, d, hp, NHL), (l & 1) == 0);
             ldp += wide_ea<kEaInverse>(c, f.ea0_log_scale, f.ea0_shift, false);
             const float f_xp = -0.5f * ss + base_c - chain_sum(ldp);
             const float u_xp = wide_potential_value(c, c.xs, a.pot, lane);            // jump.py:213 / imh.py:225
