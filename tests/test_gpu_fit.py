@@ -36,6 +36,7 @@ SHAPES = [  # d, n_hidden, hidden layers, coupling layers, rows, NICE
     (6, 4, 2, 2, 50, False), (7, 3, 1, 3, 64, False), (25, 4, 2, 2, 200, False), (64, 4, 2, 2, 333, False),
     (64, 8, 2, 2, 128, False), (64, 16, 1, 2, 70, False), (100, 7, 2, 3, 129, False), (128, 32, 2, 2, 65, False),
     (256, 7, 2, 2, 700, False), (16, 5, 2, 2, 90, True), (300, 7, 2, 2, 150, False), (512, 7, 2, 2, 130, False), (511, 6, 1, 3, 70, False),
+    (1, 4, 2, 2, 30, False), (2, 1, 1, 4, 5000, False),
 ]
 
 
@@ -63,6 +64,8 @@ def test_nll_gradient_matches_autograd(dev, d, H, nhl, nl, n, nice):
     want = dict(of.named_parameters())
     for name, p in g.named_parameters():
         w = want[name].grad
+        if w is None or w.numel() == 0:      # d = 1: the source half is empty, W1 has no entries
+            continue
         scale = max(float(w.abs().max()), 1e-3)
         np.testing.assert_allclose(p.detach().cpu().numpy(), w.numpy(), atol=2e-4 * scale, rtol=0, err_msg=name)
     # the padded entries of the blob (hidden units beyond n_hidden, alignment gaps) carry no gradient
