@@ -246,11 +246,14 @@ class RealNVP(nn.Module):
         return dev, n, v.detach().to(dev, torch.float32).reshape(n, self.d).contiguous()
 
     def beyond_kernels(self) -> bool:
-        """Shapes the flow kernels do not take (events wider than 512, conditioners wider than 128, 32 for splines):
+        """Shapes the flow kernels do not take (events wider than 512 or of one coordinate, conditioners wider than 128,
+        32 for splines):
         the passes are then composed from torch ops on the GPU (flow_training.forward_torch / inverse_torch, the same
         arithmetic the training path differentiates), so every flow strategy still runs -- through the samplers'
         split path -- instead of raising."""
         lim = hip.limits()
+        if self.d < 2 and self.n_coupling > 0:   # a one-coordinate event: the source half of every coupling is empty (the
+            return True                          # conditioner is its last bias); the kernels start at d = 2
         return self.d > lim.max_d_flow or self.n_hidden > (32 if self.n_bins else lim.max_hidden)
 
     def _composed(self, v, inverse: bool):

@@ -64,9 +64,21 @@ class QuadraticPotential(Potential):
     def __call__(self, x):
         n = x.shape[0]
         xf = x.reshape(n, -1)
-        a = self.a if isinstance(self.a, float) else self.a.to(xf)
-        b = self.b if isinstance(self.b, float) else self.b.to(xf)
+        a, b = self._params_like(xf)
         return torch.sum(a * (xf - b) ** 2, dim=-1)
+
+    def _params_like(self, xf):
+        """a, b next to `xf`: the device copies the descriptor uses are kept (a host-to-device copy per call would also keep
+        a fit step that evaluates the potential out of a HIP graph)"""
+        if isinstance(self.a, float) and isinstance(self.b, float):
+            return self.a, self.b
+        if xf.dtype == torch.float32 and xf.is_cuda:
+            key = str(xf.device)
+            if key not in self._dev:
+                self._dev[key] = tuple(None if isinstance(v, float) else v.to(xf.device) for v in (self.a, self.b))
+            da, db = self._dev[key]
+            return (self.a if da is None else da), (self.b if db is None else db)
+        return (self.a if isinstance(self.a, float) else self.a.to(xf)), (self.b if isinstance(self.b, float) else self.b.to(xf))
 
     def descriptor(self, device):
         key = str(device)

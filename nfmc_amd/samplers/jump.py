@@ -72,8 +72,7 @@ def flow_is_native(flow) -> bool:
     bij = getattr(flow, 'bijection', None)
     if not isinstance(bij, RealNVP):
         return False
-    lim = hip.limits()
-    return bij.d <= lim.max_d_flow and bij.n_hidden <= (32 if bij.n_bins else lim.max_hidden)
+    return not bij.beyond_kernels()
 
 
 def flow_fits_jump_tail(flow) -> bool:
@@ -133,7 +132,7 @@ def _flow_mh_probe_args(run: Run, flow, pot, logq, adjusted):
 
 
 def _supported(rc, what) -> bool:
-    if rc == hip.EUNSUPPORTED:
+    if rc in (hip.EUNSUPPORTED, hip.ESHAPE):   # a valid request no fused kernel covers (NfmcArgumentError.no_kernel)
         return False
     hip.check(rc, what)
     return True

@@ -65,7 +65,7 @@ class NeuTra(Sampler):
         n = _z.shape[0]
         dev = hip.require_gpu()
         grad_needed = torch.is_grad_enabled() and _z.requires_grad
-        if grad_needed and self._grad_kernel_ok and self._closed_form() is not None:
+        if grad_needed and self._grad_kernel_ok and self._closed_form() is not None and self._flow_on_kernels():
             try:
                 return _AdjustedPotential.apply(_z, self)
             except hip.NfmcArgumentError as e:
@@ -87,6 +87,10 @@ class NeuTra(Sampler):
         log_prob = -self.target(x)
         adjusted_potential = -(log_prob.reshape(-1) + log_det_inverse.to(log_prob).reshape(-1))
         return (adjusted_potential, x) if return_data else adjusted_potential
+
+    def _flow_on_kernels(self):
+        bij = getattr(self.kernel.flow, 'bijection', None)
+        return hasattr(bij, 'packed') and not bij.beyond_kernels()
 
     def _min_hidden(self):
         """Conditioner width to present to the kernels: d = 64 / 128 with one or two hidden layers runs on the
@@ -152,12 +156,12 @@ class NeuTra(Sampler):
             inner.rng_rounds = self.rng_rounds
             # a closed-form target on the gradient kernel is a deterministic function of z: the split path's HMC evaluates
             # the adjusted target once per position (a user's callable keeps the reference's 2 L + 2 calls per trajectory)
-            inner.one_evaluation_per_position = pot is not None and self._grad_kernel_ok
+            inner.one_evaluation_per_position = pot is not None and self._grad_kernel_ok and self._flow_on_kernels()
             out = inner.sample(x0, show_progress=show_progress, time_limit_seconds=time_limit_seconds)
             out.kernel.flow = self.kernel.flow
             return out
 
-        if not isinstance(inner, HMC) or pot is None:
+        if not isinstance(inner, HMC) or pot is None or not self._flow_on_kernels():
             return split()
         out = MCMCOutput(event_shape, store_samples=self.params.store_samples,
                          max_samples=getattr(self.params, 'max_samples', None))

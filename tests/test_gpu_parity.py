@@ -1207,8 +1207,10 @@ def test_edge_smallest_and_largest_shapes(dev):
     assert abs(float(out.variance.mean()) - 0.5) < 0.02 and out.mean.shape == (1024,)
     with pytest.raises(ValueError, match='supported range'):
         sample(SumOfSquares((1025,)), strategy='mala', n_chains=4, n_iterations=2, show_progress=False)
-    with pytest.raises(ValueError):   # a flow needs at least one pass-through coordinate
-        sample(_sumsq, event_shape=(1,), strategy='imh', n_chains=8, n_iterations=2, show_progress=False)
+    # a flow over ONE coordinate has no pass-through coordinate (every coupling's conditioner is its last bias): the kernels
+    # start at d = 2, the flow's passes are composed from torch ops and the sampler takes the split path
+    out = sample(_sumsq, event_shape=(1,), strategy='imh', n_chains=8, n_iterations=2, show_progress=False)
+    assert out.samples.shape == (2, 8, 1) and torch.isfinite(out.samples).all()
     out = sample(SumOfSquares((64,)), strategy='jump_mala', n_chains=100003, n_iterations=2, show_progress=False,
                  param_kwargs={'store_samples': False}, inner_param_kwargs={'n_iterations': 20})
     assert out.statistics.n_attempted_trajectories == 100003 * 40 and out.statistics.n_attempted_jumps == 100003 * 2
@@ -1948,6 +1950,7 @@ def test_every_flow_strategy_runs_on_awkward_shapes(dev, strategy):
     wide = 'realnvp%{"conditioner_kwargs":{"n_hidden":40}}'
     cases = [(d, 'realnvp') for d in (2, 3, 5, 31, 65, 129, 257, 300, 511, 512)]
     cases += [(d, fl) for d in (5, 65, 300) for fl in ('nice', 'c-rqnsf', wide)]
+    cases += [(1, fl) for fl in ('realnvp', 'nice', 'c-rqnsf')]   # one coordinate: every coupling's source half is empty
     for d, fl in cases:
         torch.manual_seed(0)
         out = sample(SumOfSquares((d,)), strategy=strategy, flow=fl, n_chains=37, n_iterations=3, show_progress=False, **kw)
