@@ -103,6 +103,21 @@ def main():
                 assert st.n_attempted_jumps == n * T and st.n_accepted_jumps == b.statistics.n_accepted_jumps
             last = a.running_samples.last_sample
             assert last is not None and tuple(last.shape) == (n,) + event and torch.isfinite(last).all()
+            if sa is not None and not warm and strategy != 'adaptive_imh' and rnd.random() < 0.5:
+                # f3: the kept states under thinning / max_samples equal the dense run cut by the reference's rule
+                # (sampling/base.py:249-263), bit for bit
+                thinning, max_samples = rnd.choice([1, 2, 3, 5]), rnd.choice([None, 1, 2, 4, 50])
+                kk = {k: (dict(v) if isinstance(v, dict) else v) for k, v in kw.items()}
+                kk['param_kwargs'] = dict(kk.get('param_kwargs', {}), thinning=thinning, max_samples=max_samples)
+                torch.manual_seed(sseed)
+                c = sample(target, event_shape=event, flow=fl, strategy=strategy, n_iterations=T, n_warmup_iterations=Tw,
+                           n_chains=n, warmup=False, show_progress=False, seed=sseed, **kk)
+                idx = [i for i in range(sa.shape[0]) if i % thinning == 0]
+                if max_samples:
+                    idx = idx[-max_samples:]
+                assert c.samples.shape[0] == len(idx), ('kept rows', c.samples.shape[0], len(idx), thinning, max_samples)
+                assert torch.equal(c.samples, sa[idx]), ('kept states differ from the dense run', thinning, max_samples)
+                assert torch.equal(c.running_samples.last_sample.cpu(), sa[-1].cpu())
             done += 1
             print('ok    %s  (%.0f s)' % (case, time.time() - t0), flush=True)
         except ValueError as e:
