@@ -29,7 +29,7 @@ def timed(fn, reps=5):
 def main():
     dev = hip.require_gpu()
     n = int(os.environ.get('N', 65536))
-    for d in (256, 512):
+    for d in [int(v) for v in os.environ.get('D', '256,512').split(',')]:   # D=256: one shape (counter passes)
         torch.manual_seed(d)
         f = Flow(RealNVP((d,), n_layers=2, conditioner_kwargs={'n_hidden': 128, 'n_layers': 2}))
         x = torch.randn(n, d, device=dev)

@@ -4,7 +4,8 @@ from collections import defaultdict
 
 
 def short(name):
-    for key in ('fit_rows_kernel', 'fit_grad_kernel', 'fit_fold_kernel', 'rows_sample_kernel', 'blob_copy_kernel', 'mala_kernel', 'flow_mh_b2_kernel', 'flow_mh_b_kernel', 'stats_finish_kernel', 'tune_finish_kernel', 'neutra_hmc_kernel', 'hmc_kernel',
+    for key in ('neutra_grad_wide_kernel', 'neutra_leapfrog_wide_kernel', 'realnvp_forward_wide_kernel', 'realnvp_inverse_wide_kernel', 'flow_mh_wide_kernel',
+                'fit_rows_kernel', 'fit_grad_kernel', 'fit_fold_kernel', 'rows_sample_kernel', 'blob_copy_kernel', 'mala_kernel', 'flow_mh_b2_kernel', 'flow_mh_b_kernel', 'stats_finish_kernel', 'tune_finish_kernel', 'neutra_hmc_kernel', 'hmc_kernel',
                 'imh_eval_kernel', 'imh_scan_kernel', 'imh_replay_kernel', 'neutra_leapfrog_mfma_kernel',
                 'neutra_grad_mfma_kernel', 'flow_mh_mfma_kernel', 'flow_mh_kernel', 'realnvp_forward', 'realnvp_inverse'):
         if key in name:
